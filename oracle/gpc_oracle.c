@@ -1,0 +1,643 @@
+/*
+ * gpc_oracle.c -- CPU ORACLE (test infrastructure only; see gpc_oracle.h header).
+ *
+ * Plain-C restatement of the reference arithmetic, following
+ *   src/rbf_kernel.cpp:15-18,61-71        src/gaussian_noise.cpp:9-18
+ *   src/gaussian_noise_3d.cpp:11-20       src/probit_noise.cpp:11-31
+ *   src/gaussian_process.cpp:15-64        src/sparse_gp.hpp:27-33,43-86,89-249,252-295,299-351,523-530,573-582
+ *   src/sparse_gp_field.hpp:14-17,29-57,59-215,219-263,268-320
+ *   src/gp_compressor.cpp:251-265,317-340,367-372
+ * (paths relative to /root/reference).  Build with -ffp-contract=off so that
+ * no FMA contraction changes the rounding sequence written here.
+ */
+#include "gpc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ a1 / a2 */
+
+/* src/rbf_kernel.cpp:15-18:  p(0)*exp(-0.5f / p(1) * (xi - xj).squaredNorm()) */
+double orc_rbf_kernel(double p0, double p1, double xi0, double xi1, double xj0, double xj1)
+{
+    double d0 = xi0 - xj0, d1 = xi1 - xj1;
+    double sq = d0 * d0 + d1 * d1;
+    return p0 * exp((double)(-0.5f) / p1 * sq);
+}
+
+/* src/rbf_kernel.cpp:61-71: row i of K is p(0)*exp(-0.5f/p(1)*||X_j - BV_i||^2) */
+void orc_rbf_construct_covariance_fast(double p0, double p1, int N, const double* x0, const double* x1,
+                                       int b, const double* BV, double* K)
+{
+    for (int i = 0; i < b; ++i) {
+        for (int j = 0; j < N; ++j) {
+            double d0 = x0[j] - BV[2 * i], d1 = x1[j] - BV[2 * i + 1];
+            double t = d0 * d0 + d1 * d1;
+            K[i + (size_t)j * b] = p0 * exp((double)(-0.5f) / p1 * t);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ a3 / a4 / a5 */
+
+/* src/gaussian_noise.cpp:9-12 */
+double orc_gaussian_dx_ln(double s20, double y, double x, double sigma_x)
+{
+    return (y - x) / (s20 + sigma_x);
+}
+
+/* src/gaussian_noise.cpp:15-18 */
+double orc_gaussian_dx2_ln(double s20, double y, double x, double sigma_x)
+{
+    (void)y; (void)x;
+    return (double)(-1.0f) / (s20 + sigma_x);
+}
+
+/* src/gaussian_noise_3d.cpp:11-14 */
+void orc_gaussian3d_dx_ln(double s20, int ny, const double* y, const double* x, double sigma_x, double* q)
+{
+    for (int c = 0; c < ny; ++c) q[c] = (y[c] - x[c]) / (s20 + sigma_x);
+}
+
+/* src/gaussian_noise_3d.cpp:17-20 */
+double orc_gaussian3d_dx2_ln(double s20, double sigma_x)
+{
+    return (double)(-1.0f) / (s20 + sigma_x);
+}
+
+/* `2.0f*sqrt(2.0f)` in src/probit_noise.cpp:15,26 is a C++ expression: <math.h> of libstdc++ exposes the
+ * sqrt(float) overload, so the product is evaluated in float and only then promoted (checked against the
+ * compiled reference object, tests/golden/noise_ref.json). */
+#define PROBIT_TWO_SQRT2 ((double)(2.0f * sqrtf(2.0f)))
+
+/* src/probit_noise.cpp:11-18 */
+double orc_probit_dx_ln(double s20, double y, double x, double sigma_x)
+{
+    double sigma = sqrt(s20 + sigma_x);
+    double z = y * x / sigma;
+    double ef = erf(z) / PROBIT_TWO_SQRT2;
+    double efprim = exp(-z * z / 2) / sqrt((double)2.0f * M_PI);
+    return y / sigma * efprim / ef;
+}
+
+/* src/probit_noise.cpp:21-31 */
+double orc_probit_dx2_ln(double s20, double y, double x, double sigma_x)
+{
+    double sigma2 = s20 + sigma_x;
+    double sigma = sqrt(sigma2);
+    double z = y * x / sigma;
+    double ef = erf(z) / PROBIT_TWO_SQRT2;
+    double efprim = exp(-z * z / (double)2.0f) / sqrt((double)2.0f * M_PI);
+    double efprimprim = -z * efprim;
+    double first = efprim / ef;
+    return (efprimprim / ef - first * first) / sigma2;
+}
+
+/* ------------------------------------------------------------------ a6 - a8: dense GP */
+
+void orc_dense_default_params(orc_dense_params* p)
+{
+    /* src/gaussian_process.h:21 with the squaring of src/gaussian_process.cpp:8-9 */
+    p->sigmaf_sq = 0.05 * 0.05;
+    p->l_sq = 3.0 * 3.0;
+    p->sigman_sq = 0.04 * 0.04;
+    p->ref_double_noise = 1;
+}
+
+/* src/gaussian_process.cpp:47-50 */
+static double squared_exp_distance(const orc_dense_params* p, double xi0, double xi1, double xj0, double xj1)
+{
+    double d0 = xi0 - xj0, d1 = xi1 - xj1;
+    double sq = d0 * d0 + d1 * d1;
+    return p->sigmaf_sq * exp((double)(-0.5f) / p->l_sq * sq);
+}
+
+int orc_dense_fit(const orc_dense_params* p, int n, const double* x0, const double* x1,
+                  const double* y, int ny, double* L, double* alpha)
+{
+    if (n <= 0) return 0;
+    size_t ld = (size_t)n;
+    /* covariance_matrix(K, X, X, true): src/gaussian_process.cpp:52-64 -- all n*n entries, no symmetry used */
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) {
+            double c = squared_exp_distance(p, x0[i], x1[i], x0[j], x1[j]);
+            if (i == j) c += p->sigman_sq;
+            L[i + j * ld] = c;
+        }
+    }
+    /* C = K; C.diagonal() += sigman_sq  (src/gaussian_process.cpp:20-21; the second addition, F5) */
+    if (p->ref_double_noise)
+        for (int i = 0; i < n; ++i) L[i + i * ld] += p->sigman_sq;
+    /* chol = C.llt()  (src/gaussian_process.cpp:22): lower Cholesky, left-looking column form */
+    int info = 0;
+    for (int j = 0; j < n; ++j) {
+        double d = L[j + j * ld];
+        for (int k = 0; k < j; ++k) d -= L[j + k * ld] * L[j + k * ld];
+        if (!(d > 0.0)) { info = 1 + j; break; }
+        d = sqrt(d);
+        L[j + j * ld] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = L[i + j * ld];
+            for (int k = 0; k < j; ++k) s -= L[i + k * ld] * L[j + k * ld];
+            L[i + j * ld] = s / d;
+        }
+    }
+    for (int j = 1; j < n; ++j)
+        for (int i = 0; i < j; ++i) L[i + j * ld] = 0.0;
+    if (info) {
+        for (int c = 0; c < ny; ++c)
+            for (int i = 0; i < n; ++i) alpha[i + (size_t)c * n] = NAN;
+        return info;
+    }
+    /* alpha = chol.solve(y)  (src/gaussian_process.cpp:24): L z = y, L^T alpha = z */
+    for (int c = 0; c < ny; ++c) {
+        double* a = alpha + (size_t)c * n;
+        const double* yc = y + (size_t)c * n;
+        for (int i = 0; i < n; ++i) {
+            double s = yc[i];
+            for (int k = 0; k < i; ++k) s -= L[i + k * ld] * a[k];
+            a[i] = s / L[i + i * ld];
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = a[i];
+            for (int k = i + 1; k < n; ++k) s -= L[k + i * ld] * a[k];
+            a[i] = s / L[i + i * ld];
+        }
+    }
+    return 0;
+}
+
+void orc_dense_predict(const orc_dense_params* p, int n, const double* x0, const double* x1,
+                       const double* L, const double* alpha, int ny,
+                       int m, const double* xs0, const double* xs1, double* f_star, double* v_star)
+{
+    size_t ld = (size_t)n;
+    double* kcol = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (int j = 0; j < m; ++j) {
+        /* K_star.col(j): covariance_matrix(K_star, X, X_star), src/gaussian_process.cpp:31,52-64 */
+        for (int i = 0; i < n; ++i) kcol[i] = squared_exp_distance(p, x0[i], x1[i], xs0[j], xs1[j]);
+        /* f_star = K_star^T alpha  (src/gaussian_process.cpp:32) */
+        for (int c = 0; c < ny; ++c) {
+            const double* a = alpha + (size_t)c * n;
+            double s = 0.0;
+            for (int i = 0; i < n; ++i) s += kcol[i] * a[i];
+            f_star[j + (size_t)c * m] = s;
+        }
+        if (v_star) {
+            /* v = chol.matrixL().solve(K_star); V_star(m) = k** - v^T v  (src/gaussian_process.cpp:35-43) */
+            double vv = 0.0;
+            for (int i = 0; i < n; ++i) {
+                double s = kcol[i];
+                for (int k = 0; k < i; ++k) s -= L[i + k * ld] * kcol[k];
+                kcol[i] = s / L[i + i * ld];
+                vv += kcol[i] * kcol[i];
+            }
+            double kss = squared_exp_distance(p, xs0[j], xs1[j], xs0[j], xs1[j]);
+            v_star[j] = kss - vv;
+        }
+    }
+    free(kcol);
+}
+
+int orc_dense_fit_predict_batch(const orc_dense_params* p, int P, const int32_t* off,
+                                const double* x0, const double* x1, const double* y, int ny,
+                                int m, const double* xs0, const double* xs1,
+                                double* f_star, double* v_star, int32_t* status, double* alpha_out)
+{
+    int nmax = 0;
+    for (int i = 0; i < P; ++i) {
+        int n = off[i + 1] - off[i];
+        if (n > nmax) nmax = n;
+    }
+    size_t N = (size_t)off[P];
+    double* L = (double*)malloc(sizeof(double) * (size_t)nmax * (size_t)nmax + 8);
+    double* alpha = (double*)malloc(sizeof(double) * (size_t)nmax * (size_t)ny + 8);
+    double* yb = (double*)malloc(sizeof(double) * (size_t)nmax * (size_t)ny + 8);
+    if (!L || !alpha || !yb) { free(L); free(alpha); free(yb); return -12; }
+    for (int i = 0; i < P; ++i) {
+        int o = off[i], n = off[i + 1] - off[i];
+        /* y is ny planes of N (plane c at y + c*N); gather the patch rows of each plane */
+        for (int c = 0; c < ny; ++c) memcpy(yb + (size_t)c * n, y + (size_t)c * N + o, sizeof(double) * (size_t)n);
+        int info = orc_dense_fit(p, n, x0 + o, x1 + o, yb, ny, L, alpha);
+        if (status) status[i] = info ? 1 : 0;
+        if (alpha_out)
+            for (int c = 0; c < ny; ++c) memcpy(alpha_out + (size_t)c * N + o, alpha + (size_t)c * n, sizeof(double) * (size_t)n);
+        double* fs = f_star + (size_t)i * ny * m;
+        orc_dense_predict(p, n, x0 + o, x1 + o, L, alpha, ny, m, xs0, xs1, fs, v_star ? v_star + (size_t)i * m : NULL);
+    }
+    free(L); free(alpha); free(yb);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ a9 - a13: sparse online GP */
+
+struct orc_sparse {
+    orc_sparse_params p;
+    int ld;            /* leading dimension / max basis vectors */
+    int b;             /* current_size */
+    int total_count;
+    double* alpha;     /* ny planes of ld */
+    double* C;         /* ld x ld col-major */
+    double* Q;
+    double* BV;        /* 2 x ld interleaved */
+    double* k;         /* scratch, ld each */
+    double* e_hat;
+    double* s;
+    double* t;
+    int32_t n_full, n_sparse, n_deleted;
+};
+
+void orc_sparse_default_params(orc_sparse_params* p, int ny)
+{
+    p->p0 = (double)100e-0f;              /* src/rbf_kernel.h:24 */
+    p->p1 = 1 * 1;
+    p->capacity = 100;                    /* src/sparse_gp.h:48, src/sparse_gp_field.h:43 */
+    p->ny = ny;
+    p->noise_model = 0;
+    p->field_delete_bug = 1;
+    if (ny == 1) {
+        p->s20 = (double)1e-1f;           /* src/sparse_gp.h:48 */
+        p->eps_tol = (double)1e-6f;       /* src/sparse_gp.hpp:30 */
+    } else {
+        p->s20 = (double)1e2f;            /* src/sparse_gp_field.h:43 */
+        p->eps_tol = (double)1e-4f;       /* src/sparse_gp_field.hpp:16 */
+    }
+}
+
+orc_sparse* orc_sparse_create(const orc_sparse_params* p, int max_bv)
+{
+    orc_sparse* g = (orc_sparse*)calloc(1, sizeof(orc_sparse));
+    if (!g) return NULL;
+    g->p = *p;
+    g->ld = max_bv < 2 ? 2 : max_bv;
+    size_t ld = (size_t)g->ld;
+    g->alpha = (double*)calloc(ld * (size_t)p->ny, sizeof(double));
+    g->C = (double*)calloc(ld * ld, sizeof(double));
+    g->Q = (double*)calloc(ld * ld, sizeof(double));
+    g->BV = (double*)calloc(2 * ld, sizeof(double));
+    g->k = (double*)calloc(ld, sizeof(double));
+    g->e_hat = (double*)calloc(ld, sizeof(double));
+    g->s = (double*)calloc(ld, sizeof(double));
+    g->t = (double*)calloc(ld, sizeof(double));
+    return g;
+}
+
+void orc_sparse_destroy(orc_sparse* g)
+{
+    if (!g) return;
+    free(g->alpha); free(g->C); free(g->Q); free(g->BV);
+    free(g->k); free(g->e_hat); free(g->s); free(g->t);
+    free(g);
+}
+
+/* src/sparse_gp.hpp:573-582 */
+void orc_sparse_reset(orc_sparse* g)
+{
+    g->total_count = 0;
+    g->b = 0;
+    g->n_full = g->n_sparse = g->n_deleted = 0;
+}
+
+int orc_sparse_size(const orc_sparse* g) { return g->b; }
+int orc_sparse_total_count(const orc_sparse* g) { return g->total_count; }
+
+#define Cm(i, j) g->C[(size_t)(i) + (size_t)(j) * ld]
+#define Qm(i, j) g->Q[(size_t)(i) + (size_t)(j) * ld]
+#define Al(c, i) g->alpha[(size_t)(c) * ld + (size_t)(i)]
+
+/* src/sparse_gp.hpp:252-295 (ny==1) and src/sparse_gp_field.hpp:219-263 (ny>1) */
+void orc_sparse_delete_bv(orc_sparse* g, int loc)
+{
+    const size_t ld = (size_t)g->ld;
+    const int b = g->b, last = b - 1, ny = g->p.ny;
+    double alphastar[8];
+    double* Cstar = g->s;   /* scratch vectors (length b-1 after the swap/shrink) */
+    double* Qstar = g->t;
+
+    /* First swap loc to the last spot (:256-258) */
+    for (int c = 0; c < ny; ++c) {
+        alphastar[c] = Al(c, loc);
+        Al(c, loc) = Al(c, last);
+    }
+    /* Now C (:261-270) */
+    double cstar = Cm(loc, loc);
+    for (int i = 0; i < b; ++i) Cstar[i] = Cm(i, loc);
+    Cstar[loc] = Cstar[last];
+    {
+        double* Crep = g->k;
+        for (int i = 0; i < b; ++i) Crep[i] = Cm(i, last);
+        Crep[loc] = Crep[last];
+        for (int i = 0; i < b; ++i) Cm(loc, i) = Crep[i];
+        for (int i = 0; i < b; ++i) Cm(i, loc) = Crep[i];
+    }
+    /* and Q (:273-281) */
+    double qstar = Qm(loc, loc);
+    for (int i = 0; i < b; ++i) Qstar[i] = Qm(i, loc);
+    Qstar[loc] = Qstar[last];
+    {
+        double* Qrep = g->k;
+        for (int i = 0; i < b; ++i) Qrep[i] = Qm(i, last);
+        Qrep[loc] = Qrep[last];
+        for (int i = 0; i < b; ++i) Qm(loc, i) = Qrep[i];
+        for (int i = 0; i < b; ++i) Qm(i, loc) = Qrep[i];
+    }
+    const int nb = b - 1;
+    /* the actual removal, Appendix G section g (:284-288) */
+    if (ny == 1) {
+        double f = alphastar[0] / (qstar + cstar);
+        for (int i = 0; i < nb; ++i) Al(0, i) -= f * (Qstar[i] + Cstar[i]);
+    } else {
+        /* src/sparse_gp_field.hpp:250-253: qc = (qstar + cstar)*(Qstar + Cstar)  -- multiplies (F8) */
+        for (int i = 0; i < nb; ++i) {
+            double qc = g->p.field_delete_bug ? (qstar + cstar) * (Qstar[i] + Cstar[i])
+                                              : (Qstar[i] + Cstar[i]) / (qstar + cstar);
+            for (int c = 0; c < ny; ++c) Al(c, i) -= alphastar[c] * qc;
+        }
+    }
+    for (int j = 0; j < nb; ++j) {
+        for (int i = 0; i < nb; ++i) {
+            double qq = (Qstar[i] * Qstar[j]) / qstar;
+            double qc = ((Qstar[i] + Cstar[i]) * (Qstar[j] + Cstar[j])) / (qstar + cstar);
+            Cm(i, j) += qq - qc;
+            Qm(i, j) -= qq;
+        }
+    }
+    /* And the BV (:291-292) */
+    g->BV[2 * loc] = g->BV[2 * last];
+    g->BV[2 * loc + 1] = g->BV[2 * last + 1];
+    g->b = nb;
+    g->n_deleted++;
+}
+
+/* src/sparse_gp.hpp:89-249 and src/sparse_gp_field.hpp:59-215 */
+void orc_sparse_add(orc_sparse* g, double x0, double x1, const double* y)
+{
+    const size_t ld = (size_t)g->ld;
+    const orc_sparse_params* P = &g->p;
+    const int ny = P->ny;
+    g->total_count++;
+    double kstar = orc_rbf_kernel(P->p0, P->p1, x0, x1, x0, x1);
+
+    if (g->b == 0) {
+        /* First point (:100-114): Equations 2.46 with q, r, s collapsed */
+        for (int c = 0; c < ny; ++c) Al(c, 0) = y[c] / (kstar + P->s20);
+        Cm(0, 0) = (double)(-1.0f) / (kstar + P->s20);
+        Qm(0, 0) = (double)(1.0f) / kstar;
+        g->b = 1;
+        g->BV[0] = x0;
+        g->BV[1] = x1;
+        g->n_full++;
+        return;   /* the reference only checks isnan(C(0,0)) after this (:245) */
+    }
+
+    int b = g->b;
+    double* k = g->k;
+    double* e_hat = g->e_hat;
+    /* construct_covariance(k, X, BV) (:119, :523-530) */
+    for (int i = 0; i < b; ++i) k[i] = orc_rbf_kernel(P->p0, P->p1, x0, x1, g->BV[2 * i], g->BV[2 * i + 1]);
+
+    /* m = alpha^T k ; s2 = kstar + k^T C k (:121-122) */
+    double m[8];
+    for (int c = 0; c < ny; ++c) {
+        double s = 0.0;
+        for (int i = 0; i < b; ++i) s += Al(c, i) * k[i];
+        m[c] = s;
+    }
+    double kCk = 0.0;
+    for (int j = 0; j < b; ++j) {
+        double tj = 0.0;
+        for (int i = 0; i < b; ++i) tj += k[i] * Cm(i, j);
+        kCk += tj * k[j];
+    }
+    double s2 = kstar + kCk;
+
+    /* r = noise.dx2_ln(y, m, s2); q = noise.dx_ln(y, m, s2) (:134-137) */
+    double r, q[8];
+    if (ny == 1 && P->noise_model == 1) {
+        r = orc_probit_dx2_ln(P->s20, y[0], m[0], s2);
+        q[0] = orc_probit_dx_ln(P->s20, y[0], m[0], s2);
+    } else if (ny == 1) {
+        r = orc_gaussian_dx2_ln(P->s20, y[0], m[0], s2);
+        q[0] = orc_gaussian_dx_ln(P->s20, y[0], m[0], s2);
+    } else {
+        r = orc_gaussian3d_dx2_ln(P->s20, s2);
+        orc_gaussian3d_dx_ln(P->s20, ny, y, m, s2, q);
+    }
+
+    /* e_hat = Q*k (:140); gamma = kstar - k^T e_hat (:144) */
+    for (int i = 0; i < b; ++i) e_hat[i] = 0.0;
+    for (int j = 0; j < b; ++j)
+        for (int i = 0; i < b; ++i) e_hat[i] += Qm(i, j) * k[j];
+    double ke = 0.0;
+    for (int i = 0; i < b; ++i) ke += k[i] * e_hat[i];
+    double gamma = kstar - ke;
+    if (gamma < (double)1e-12f) gamma = 0;   /* :146-151 */
+
+    double* s = g->s;
+    /* s.head = C*k (:160 / :171) */
+    for (int i = 0; i < b; ++i) s[i] = 0.0;
+    for (int j = 0; j < b; ++j)
+        for (int i = 0; i < b; ++i) s[i] += Cm(i, j) * k[j];
+
+    if (gamma < P->eps_tol && P->capacity != -1) {
+        /* sparse update (:155-163) */
+        double eta = 1 / (1 + gamma * r);
+        for (int i = 0; i < b; ++i) s[i] = s[i] + e_hat[i];      /* s_hat = C*k + e_hat */
+        for (int c = 0; c < ny; ++c) {
+            double qe = q[c] * eta;
+            for (int i = 0; i < b; ++i) Al(c, i) += s[i] * qe;
+        }
+        double re = r * eta;
+        for (int j = 0; j < b; ++j)
+            for (int i = 0; i < b; ++i) Cm(i, j) += (re * s[i]) * s[j];
+        g->n_sparse++;
+    } else {
+        /* full update (:164-203) */
+        s[b] = (double)1.0f;
+        for (int c = 0; c < ny; ++c) {
+            Al(c, b) = 0;
+            for (int i = 0; i <= b; ++i) Al(c, i) += q[c] * s[i];
+        }
+        for (int i = 0; i <= b; ++i) { Cm(b, i) = 0; Cm(i, b) = 0; }
+        for (int j = 0; j <= b; ++j)
+            for (int i = 0; i <= b; ++i) Cm(i, j) += (r * s[i]) * s[j];
+        g->BV[2 * b] = x0;
+        g->BV[2 * b + 1] = x1;
+        for (int i = 0; i <= b; ++i) { Qm(b, i) = 0; Qm(i, b) = 0; }
+        e_hat[b] = (double)(-1.0f);
+        double ig = (double)1.0f / gamma;
+        for (int j = 0; j <= b; ++j)
+            for (int i = 0; i <= b; ++i) Qm(i, j) += (ig * e_hat[i]) * e_hat[j];
+        g->b = b + 1;
+        g->n_full++;
+    }
+
+    /* Delete BVs if necessary (:206-223) */
+    while (g->b > P->capacity && P->capacity > 0) {
+        double minscore = 0, score;
+        int minloc = -1;
+        for (int i = 0; i < g->b; ++i) {
+            double a2 = 0.0;
+            for (int c = 0; c < ny; ++c) a2 += Al(c, i) * Al(c, i);   /* alpha(i)^2 / row squaredNorm (field :178) */
+            score = a2 / (Qm(i, i) + Cm(i, i));
+            if (i == 0 || score < minscore) { minscore = score; minloc = i; }
+        }
+        orc_sparse_delete_bv(g, minloc);
+    }
+    /* Delete for geometric reasons (:226-242) */
+    {
+        double minscore = 0, score;
+        int minloc = -1;
+        while (minscore < (double)1e-9f && g->b > 1) {
+            for (int i = 0; i < g->b; ++i) {
+                score = (double)1.0f / Qm(i, i);
+                if (i == 0 || score < minscore) { minscore = score; minloc = i; }
+            }
+            if (minscore < (double)1e-9f) orc_sparse_delete_bv(g, minloc);
+        }
+    }
+}
+
+/* src/sparse_gp.hpp:59-86 with the permutation made an explicit input (F7) */
+void orc_sparse_add_measurements(orc_sparse* g, int n, const double* x0, const double* x1,
+                                 const double* y, const int32_t* perm)
+{
+    double yy[8];
+    for (int i = 0; i < n; ++i) {
+        int r = perm ? perm[i] : i;
+        for (int c = 0; c < g->p.ny; ++c) yy[c] = y[(size_t)c * n + r];
+        orc_sparse_add(g, x0[r], x1[r], yy);
+    }
+}
+
+/* src/sparse_gp.hpp:299-351, src/sparse_gp_field.hpp:268-320 */
+void orc_sparse_predict(const orc_sparse* g, int m, const double* xs0, const double* xs1,
+                        double* f_star, double* sigconf, int conf)
+{
+    const size_t ld = (size_t)g->ld;
+    const orc_sparse_params* P = &g->p;
+    const int b = g->b, ny = P->ny;
+    double* k = (double*)malloc(sizeof(double) * (size_t)(b > 0 ? b : 1));
+    for (int p = 0; p < m; ++p) {
+        double kstar = orc_rbf_kernel(P->p0, P->p1, xs0[p], xs1[p], xs0[p], xs1[p]);
+        for (int i = 0; i < b; ++i) k[i] = orc_rbf_kernel(P->p0, P->p1, xs0[p], xs1[p], g->BV[2 * i], g->BV[2 * i + 1]);
+        double sigma;
+        if (b == 0) {
+            for (int c = 0; c < ny; ++c) f_star[(size_t)c * m + p] = 0;
+            sigma = kstar + P->s20;
+        } else {
+            for (int c = 0; c < ny; ++c) {
+                double s = 0.0;
+                for (int i = 0; i < b; ++i) s += Al(c, i) * k[i];
+                f_star[(size_t)c * m + p] = s;
+            }
+            double kCk = 0.0;
+            for (int j = 0; j < b; ++j) {
+                double tj = 0.0;
+                for (int i = 0; i < b; ++i) tj += k[i] * Cm(i, j);
+                kCk += tj * k[j];
+            }
+            sigma = P->s20 + kstar + kCk;
+        }
+        if (sigma < 0) sigma = 0;                         /* :334-337 (reference also prints) */
+        if (conf) {
+            sigma /= kstar + P->s20;
+            sigma = (double)100.0f * ((double)1.0f - sigma);
+        } else {
+            sigma = sqrt(sigma);
+        }
+        if (sigconf) sigconf[p] = sigma;
+    }
+    free(k);
+}
+
+void orc_sparse_get_state(const orc_sparse* g, double* alpha, double* C, double* Q, double* BV)
+{
+    const size_t ld = (size_t)g->ld;
+    const int b = g->b;
+    if (alpha)
+        for (int c = 0; c < g->p.ny; ++c)
+            for (int i = 0; i < b; ++i) alpha[(size_t)c * b + i] = Al(c, i);
+    for (int j = 0; j < b; ++j)
+        for (int i = 0; i < b; ++i) {
+            if (C) C[i + (size_t)j * b] = Cm(i, j);
+            if (Q) Q[i + (size_t)j * b] = Qm(i, j);
+        }
+    if (BV) memcpy(BV, g->BV, sizeof(double) * 2 * (size_t)b);
+}
+
+void orc_sparse_get_counters(const orc_sparse* g, int32_t* n_full, int32_t* n_sparse, int32_t* n_deleted)
+{
+    if (n_full) *n_full = g->n_full;
+    if (n_sparse) *n_sparse = g->n_sparse;
+    if (n_deleted) *n_deleted = g->n_deleted;
+}
+
+/* src/sparse_gp.hpp:43-56 */
+void orc_shuffle_libc(int n, int32_t* ind)
+{
+    for (int i = 0; i < n; ++i) ind[i] = i;
+    for (int i = n - 1; i > 0; --i) {
+        int r = rand() % i;
+        int32_t temp = ind[i];
+        ind[i] = ind[r];
+        ind[r] = temp;
+    }
+}
+
+void orc_shuffle_stream(int n, const uint32_t* rs, int32_t* ind)
+{
+    for (int i = 0; i < n; ++i) ind[i] = i;
+    int t = 0;
+    for (int i = n - 1; i > 0; --i) {
+        int r = (int)(rs[t++] % (uint32_t)i);
+        int32_t temp = ind[i];
+        ind[i] = ind[r];
+        ind[r] = temp;
+    }
+}
+
+/* ------------------------------------------------------------------ a15 */
+
+/* src/gp_compressor.cpp:317-332: y outer, x inner; X*(p,0) from x, X*(p,1) from y */
+void orc_grid(double res, int sz, double* xs0, double* xs1)
+{
+    int points = 0;
+    for (int y = 0; y < sz; ++y) {
+        for (int x = 0; x < sz; ++x) {
+            xs0[points] = res * (((double)x + (double)0.5f) / (double)sz - (double)0.5f);
+            xs1[points] = res * (((double)y + (double)0.5f) / (double)sz - (double)0.5f);
+            ++points;
+        }
+    }
+}
+
+/* src/gp_compressor.cpp:335-343: pt = R*(f, X*(m,0), X*(m,1)) + mean, stored as float */
+void orc_reproject(const double* R, const double* mean, double f, double a, double b, float* xyz)
+{
+    for (int i = 0; i < 3; ++i) {
+        double v = R[i + 0] * f + R[i + 3] * a + R[i + 6] * b;
+        xyz[i] = (float)(v + mean[i]);
+    }
+}
+
+/* src/gp_compressor.cpp:251-265.  x.cast<short>() is evaluated as on x86-64 (cvttsd2si then
+ * truncation to 16 bits), so e.g. 40000.0 wraps negative and flattens to 0, as the reference binary would. */
+void orc_flatten_colors(const double* c3, uint8_t* rgb)
+{
+    for (int i = 0; i < 3; ++i) {
+        double x = c3[i];
+        int v;
+        if (isnan(x) || isinf(x)) {
+            v = 255;
+        } else {
+            int32_t w = (x >= 2147483648.0 || x < -2147483648.0) ? INT32_MIN : (int32_t)x;
+            int16_t sh = (int16_t)(uint16_t)(uint32_t)w;
+            v = sh;
+            if (v < 0) v = 0;
+            else if (v > 255) v = 255;
+        }
+        rgb[i] = (uint8_t)v;
+    }
+}

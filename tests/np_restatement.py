@@ -1,0 +1,204 @@
+"""Second, independent restatement of the reference algorithm in NumPy matrix form (float64).
+
+Used only to cross-check oracle/gpc_oracle.c (different loop structure, BLAS-backed products) and to
+generate the small golden fixtures in tests/golden/ (tests/gen_golden.py).  Cites /root/reference files.
+"""
+import numpy as np
+
+F = lambda s: float(np.float32(s))  # the reference's float literals promoted to double
+
+
+def rbf(p0, p1, A, B):
+    """src/rbf_kernel.cpp:15-18 for all pairs: A (a,2), B (b,2) -> (a,b)."""
+    d = A[:, None, :] - B[None, :, :]
+    sq = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]
+    return p0 * np.exp(-0.5 / p1 * sq)
+
+
+# ---------------------------------------------------------------- dense GP (src/gaussian_process.cpp:15-45)
+
+def dense_fit(X, y, sigmaf_sq=0.05 * 0.05, l_sq=9.0, sigman_sq=0.04 * 0.04, double_noise=True):
+    n = X.shape[0]
+    K = rbf(sigmaf_sq, l_sq, X, X)
+    K[np.diag_indices(n)] += sigman_sq            # covariance_matrix(..., training=true)  :59-61
+    if double_noise:
+        K[np.diag_indices(n)] += sigman_sq        # C.diagonal() += sigman_sq              :21
+    L = np.linalg.cholesky(K)
+    z = np.linalg.solve(L, y.T)
+    alpha = np.linalg.solve(L.T, z).T
+    return L, alpha
+
+
+def dense_predict(X, L, alpha, Xs, sigmaf_sq=0.05 * 0.05, l_sq=9.0):
+    Ks = rbf(sigmaf_sq, l_sq, X, Xs)              # n x m
+    f = alpha @ Ks                                # (ny, m)
+    v = np.linalg.solve(L, Ks)
+    V = sigmaf_sq - np.sum(v * v, axis=0)
+    return f, V
+
+
+# ---------------------------------------------------------------- sparse online GP (src/sparse_gp.hpp, sparse_gp_field.hpp)
+
+class SparseGP:
+    def __init__(self, ny=1, capacity=100, s20=None, eps_tol=None, p0=F(100.0), p1=1.0,
+                 field_delete_bug=True, probit=False):
+        self.ny, self.capacity, self.p0, self.p1 = ny, capacity, p0, p1
+        self.s20 = (F(1e-1) if ny == 1 else F(1e2)) if s20 is None else s20
+        self.eps_tol = (F(1e-6) if ny == 1 else F(1e-4)) if eps_tol is None else eps_tol
+        self.field_delete_bug = field_delete_bug
+        self.probit = probit
+        self.reset()
+
+    def reset(self):
+        self.b = 0
+        self.alpha = np.zeros((0, self.ny))
+        self.C = np.zeros((0, 0))
+        self.Q = np.zeros((0, 0))
+        self.BV = np.zeros((0, 2))
+        self.n_full = self.n_sparse = self.n_deleted = 0
+
+    def _k(self, x):
+        return rbf(self.p0, self.p1, self.BV, x[None, :])[:, 0]
+
+    def _noise(self, y, m, s2):
+        if self.probit:                                   # src/probit_noise.cpp:11-31
+            import math
+            with np.errstate(all="ignore"):
+                sigma2 = np.float64(self.s20 + s2)
+                sigma = np.sqrt(sigma2)
+                z = np.float64(y[0] * m[0] / sigma)
+                two_sqrt2 = float(np.float32(2.0) * np.sqrt(np.float32(2.0)))
+                ef = np.float64(math.erf(z) if np.isfinite(z) else np.nan) / two_sqrt2
+                efp = np.exp(-z * z / 2) / math.sqrt(2.0 * math.pi)
+                q = np.array([y[0] / sigma * efp / ef])
+                first = efp / ef
+                r = ((-z * efp) / ef - first * first) / sigma2
+            return float(r), q
+        r = F(-1.0) / (self.s20 + s2)                     # src/gaussian_noise.cpp:15-18
+        q = (y - m) / (self.s20 + s2)                     # :9-12
+        return r, q
+
+    def add(self, x, y):                                  # src/sparse_gp.hpp:89-249
+        x = np.asarray(x, float)
+        y = np.atleast_1d(np.asarray(y, float))
+        kstar = self.p0
+        if self.b == 0:
+            self.alpha = (y / (kstar + self.s20))[None, :]
+            self.C = np.array([[-1.0 / (kstar + self.s20)]])
+            self.Q = np.array([[1.0 / kstar]])
+            self.BV = x[None, :].copy()
+            self.b = 1
+            self.n_full += 1
+            return
+        k = self._k(x)
+        m = self.alpha.T @ k
+        s2 = kstar + k @ self.C @ k
+        r, q = self._noise(y, m, s2)
+        e_hat = self.Q @ k
+        gamma = kstar - k @ e_hat
+        if gamma < F(1e-12):
+            gamma = 0.0
+        if gamma < self.eps_tol and self.capacity != -1:
+            eta = 1.0 / (1.0 + gamma * r)
+            s_hat = self.C @ k + e_hat
+            self.alpha = self.alpha + np.outer(s_hat, q * eta)
+            self.C = self.C + r * eta * np.outer(s_hat, s_hat)
+            self.n_sparse += 1
+        else:
+            s = np.concatenate([self.C @ k, [1.0]])
+            self.alpha = np.vstack([self.alpha, np.zeros((1, self.ny))]) + np.outer(s, q)
+            b = self.b
+            Cn = np.zeros((b + 1, b + 1))
+            Cn[:b, :b] = self.C
+            self.C = Cn + r * np.outer(s, s)
+            self.BV = np.vstack([self.BV, x[None, :]])
+            Qn = np.zeros((b + 1, b + 1))
+            Qn[:b, :b] = self.Q
+            e = np.concatenate([e_hat, [-1.0]])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                self.Q = Qn + (1.0 / gamma if gamma != 0 else np.inf) * np.outer(e, e)
+            self.b += 1
+            self.n_full += 1
+        while self.b > self.capacity and self.capacity > 0:            # :206-223
+            score = np.sum(self.alpha * self.alpha, axis=1) / (np.diag(self.Q) + np.diag(self.C))
+            self.delete_bv(int(np.argmin(score)))                      # first minimum, like the strict '<'
+        minscore = 0.0
+        while minscore < F(1e-9) and self.b > 1:                        # :226-242
+            score = 1.0 / np.diag(self.Q)
+            loc = int(np.argmin(score))
+            minscore = score[loc]
+            if minscore < F(1e-9):
+                self.delete_bv(loc)
+
+    def delete_bv(self, loc):                             # src/sparse_gp.hpp:252-295
+        b = self.b
+        last = b - 1
+        keep = list(range(b))
+        # "swap loc to the last spot": position loc now holds what was last; the last index disappears
+        keep[loc] = last
+        keep = keep[:last]
+        alphastar = self.alpha[loc].copy()
+        cstar = self.C[loc, loc]
+        qstar = self.Q[loc, loc]
+        Cstar = self.C[keep, loc].copy()
+        Qstar = self.Q[keep, loc].copy()
+        if loc != last:
+            # Cstar(loc) = Cstar(last): the element at position loc is C(last, loc)
+            Cstar[loc] = self.C[last, loc]
+            Qstar[loc] = self.Q[last, loc]
+        C = self.C[np.ix_(keep, keep)].copy()
+        Q = self.Q[np.ix_(keep, keep)].copy()
+        alpha = self.alpha[keep].copy()
+        if self.ny == 1 or not self.field_delete_bug:
+            alpha = alpha - np.outer(Qstar + Cstar, alphastar) / (qstar + cstar)
+        else:                                             # src/sparse_gp_field.hpp:250-253 (F8)
+            alpha = alpha - np.outer((qstar + cstar) * (Qstar + Cstar), alphastar)
+        C = C + np.outer(Qstar, Qstar) / qstar - np.outer(Qstar + Cstar, Qstar + Cstar) / (qstar + cstar)
+        Q = Q - np.outer(Qstar, Qstar) / qstar
+        self.alpha, self.C, self.Q = alpha, C, Q
+        self.BV = self.BV[keep].copy()
+        self.b = last
+        self.n_deleted += 1
+
+    def add_measurements(self, X, Y, perm=None):          # src/sparse_gp.hpp:59-86, explicit order (F7)
+        Y = np.asarray(Y, float).reshape(X.shape[0], -1)
+        order = range(X.shape[0]) if perm is None else perm
+        for i in order:
+            self.add(X[i], Y[i])
+
+    def predict(self, Xs, conf=False):                    # src/sparse_gp.hpp:299-351
+        m = Xs.shape[0]
+        kstar = self.p0
+        if self.b == 0:
+            f = np.zeros((m, self.ny))
+            sigma = np.full(m, kstar + self.s20)
+        else:
+            K = rbf(self.p0, self.p1, self.BV, Xs)        # b x m
+            f = (self.alpha.T @ K).T
+            sigma = self.s20 + kstar + np.einsum("im,ij,jm->m", K, self.C, K)
+        sigma = np.where(sigma < 0, 0.0, sigma)
+        if conf:
+            sigma = F(100.0) * (1.0 - sigma / (kstar + self.s20))
+        else:
+            sigma = np.sqrt(sigma)
+        return f, sigma
+
+
+def sattolo_like(n, rs):
+    """src/sparse_gp.hpp:43-56 driven by an explicit stream of rand() values."""
+    ind = list(range(n))
+    t = 0
+    for i in range(n - 1, 0, -1):
+        r = int(rs[t]) % i
+        t += 1
+        ind[i], ind[r] = ind[r], ind[i]
+    return np.array(ind, dtype=np.int32)
+
+
+def grid(res, sz):
+    """src/gp_compressor.cpp:317-332."""
+    xs = np.arange(sz, dtype=float)
+    g = res * ((xs + 0.5) / sz - 0.5)
+    X0 = np.tile(g, sz)          # x inner
+    X1 = np.repeat(g, sz)        # y outer
+    return X0, X1
