@@ -1,0 +1,281 @@
+"""ctypes binding of the C-ABI in include/gpc.h (gp_compressor_amd/libgpc_hip.so).
+
+This is exactly the binding a Python caller of the reference would add; the C++ host classes in
+gp_compressor_amd/host/ use the same entry points.  There is NO fallback: if the shared library has not been
+built (gp_compressor_amd.build.build() / __graft_entry__.build()) or no HIP device is present, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgpc_hip.so")
+
+GPC_OK, GPC_EINVAL, GPC_ENOMEM, GPC_ENODEV, GPC_EHIP, GPC_ERANGE = 0, -22, -12, -19, -5, -34
+STATUS_OK, STATUS_NOT_SPD, STATUS_NAN, STATUS_SIGMA_CLAMPED = 0, 1, 2, 3
+MAX_POINTS, MAX_BV = 1024, 256
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+
+
+class Params(C.Structure):
+    """struct gpc_params (include/gpc.h)."""
+    _fields_ = [("sigmaf_sq", C.c_double), ("l_sq", C.c_double), ("noise", C.c_double), ("eps_tol", C.c_double),
+                ("capacity", C.c_int32), ("noise_model", C.c_int32), ("ref_double_noise", C.c_int32),
+                ("ref_field_delete_bug", C.c_int32), ("want_variance", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GpcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gpc error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/gpc.h declares, with its prototype (the CPU test-suite checks the library exports all of them)
+_vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+PROTOTYPES = {
+    "gpc_version": (C.c_int, []),
+    "gpc_default_params_dense": (None, [C.POINTER(Params)]),
+    "gpc_default_params_sparse": (None, [C.POINTER(Params), _i]),
+    "gpc_ctx_create": (C.c_int, [C.POINTER(_vp), _i]),
+    "gpc_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "gpc_ctx_synchronize": (C.c_int, [_vp]),
+    "gpc_ctx_destroy": (None, [_vp]),
+    "gpc_last_error": (C.c_char_p, [_vp]),
+    "gpc_last_dense_kernel": (C.c_char_p, [_vp]),
+    "gpc_dense_fit_predict": (C.c_int, [_vp, C.POINTER(Params), _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gpc_dense_fit_predict_dev": (C.c_int, [_vp, C.POINTER(Params), _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp,
+                                            _vp, _vp, _vp, _vp]),
+    "gpc_dense_fit_predict_grid": (C.c_int, [_vp, C.POINTER(Params), _i, _vp, _vp, _vp, _vp, _i, _d, _i, _vp, _vp, _vp]),
+    "gpc_dense_fit_predict_grid_dev": (C.c_int, [_vp, C.POINTER(Params), _i, _vp, _i, _i, _vp, _vp, _vp, _i, _d, _i,
+                                                 _vp, _vp, _vp]),
+    "gpc_sparse_create": (C.c_int, [_vp, C.POINTER(Params), _i, _i, C.POINTER(_vp)]),
+    "gpc_sparse_destroy": (None, [_vp]),
+    "gpc_sparse_reset": (C.c_int, [_vp]),
+    "gpc_sparse_add": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gpc_sparse_add_dev": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gpc_sparse_predict": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "gpc_sparse_predict_dev": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "gpc_sparse_sizes": (C.c_int, [_vp, _vp]),
+    "gpc_sparse_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "gpc_sparse_ld": (C.c_int, [_vp]),
+    "gpc_partition_patches": (C.c_int, [_i, _vp, _i, _i, _vp]),
+    "gpc_test_exp_host": (None, [_vp, _vp, _i]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgpc_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GpcError(GPC_ENODEV, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                   "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    """Address of a numpy array (host), a torch tensor (host or device), an int, or None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"], "array must be contiguous"
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        assert a.is_contiguous(), "tensor must be contiguous"
+        return a.data_ptr()
+    raise TypeError(type(a))
+
+
+def default_params_dense(**kw):
+    p = Params()
+    load().gpc_default_params_dense(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def default_params_sparse(ny=1, **kw):
+    p = Params()
+    load().gpc_default_params_sparse(C.byref(p), ny)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    """gpc_ctx: one per process per GPU."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.gpc_ctx_create(C.byref(h), int(device))
+        if rc != GPC_OK:
+            raise GpcError(rc, "gpc_ctx_create failed (no HIP device?) -- there is no CPU fallback")
+        self.h = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gpc_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != GPC_OK:
+            raise GpcError(rc, self.lib.gpc_last_error(self.h).decode())
+
+    def set_stream(self, stream):
+        """stream: raw hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream) or None for the own stream."""
+        self._check(self.lib.gpc_ctx_set_stream(self.h, stream))
+
+    def synchronize(self):
+        self._check(self.lib.gpc_ctx_synchronize(self.h))
+
+    def last_dense_kernel(self):
+        return self.lib.gpc_last_dense_kernel(self.h).decode()
+
+    # ---- dense, host (numpy) buffers -----------------------------------------------------------------------
+    def dense_fit_predict(self, params, off, x0, x1, y, xs0, xs1, want_alpha=False):
+        """Host-pointer entry (gpc_dense_fit_predict).  y: (ny, N).  Returns f_star (P, ny, m), v_star|None, status, [alpha]."""
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.float64)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        xs0 = np.ascontiguousarray(xs0, dtype=np.float64)
+        xs1 = np.ascontiguousarray(xs1, dtype=np.float64)
+        P, ny, m = off.shape[0] - 1, y.shape[0], xs0.shape[0]
+        f = np.full((P, ny, m), np.nan)
+        v = np.full((P, m), np.nan) if params.want_variance else None
+        st = np.full(P, -1, dtype=np.int32)
+        al = np.full_like(y, np.nan) if want_alpha else None
+        self._check(self.lib.gpc_dense_fit_predict(self.h, C.byref(params), P, _ptr(off), _ptr(x0), _ptr(x1), _ptr(y), ny,
+                                                   m, _ptr(xs0), _ptr(xs1), _ptr(f), _ptr(v), _ptr(al), _ptr(st)))
+        return (f, v, st, al) if want_alpha else (f, v, st)
+
+    def dense_fit_predict_grid(self, params, off, x0, x1, y, res, sz, want_alpha=False):
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.float64)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        P, ny, m = off.shape[0] - 1, y.shape[0], sz * sz
+        f = np.full((P, ny, m), np.nan)
+        st = np.full(P, -1, dtype=np.int32)
+        al = np.full_like(y, np.nan) if want_alpha else None
+        self._check(self.lib.gpc_dense_fit_predict_grid(self.h, C.byref(params), P, _ptr(off), _ptr(x0), _ptr(x1), _ptr(y),
+                                                        ny, float(res), int(sz), _ptr(f), _ptr(al), _ptr(st)))
+        return (f, st, al) if want_alpha else (f, st)
+
+    # ---- dense, device buffers (torch tensors or raw addresses), asynchronous on the context's stream ---------
+    def dense_fit_predict_dev(self, params, P, off, n_max, n_total, x0, x1, y, ny, m, xs0, xs1, f_star,
+                              v_star=None, alpha_out=None, status=None):
+        self._check(self.lib.gpc_dense_fit_predict_dev(self.h, C.byref(params), P, _ptr(off), n_max, n_total, _ptr(x0),
+                                                       _ptr(x1), _ptr(y), ny, m, _ptr(xs0), _ptr(xs1), _ptr(f_star),
+                                                       _ptr(v_star), _ptr(alpha_out), _ptr(status)))
+
+    def dense_fit_predict_grid_dev(self, params, P, off, n_max, n_total, x0, x1, y, ny, res, sz, f_star,
+                                   alpha_out=None, status=None):
+        self._check(self.lib.gpc_dense_fit_predict_grid_dev(self.h, C.byref(params), P, _ptr(off), n_max, n_total,
+                                                            _ptr(x0), _ptr(x1), _ptr(y), ny, float(res), int(sz),
+                                                            _ptr(f_star), _ptr(alpha_out), _ptr(status)))
+
+
+class Sparse:
+    """gpc_sparse: P independent sparse_gp (ny=1) / sparse_gp_field (ny=3) states resident on the device."""
+
+    def __init__(self, ctx, params, P, ny=1):
+        self.ctx, self.lib, self.P, self.ny = ctx, ctx.lib, P, ny
+        h = _vp()
+        ctx._check(self.lib.gpc_sparse_create(ctx.h, C.byref(params), P, ny, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gpc_sparse_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        self.ctx._check(self.lib.gpc_sparse_reset(self.h))
+
+    def add(self, off, x0, x1, y, perm=None):
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.float64)
+        assert y.shape[0] == self.ny and off.shape[0] == self.P + 1
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+        st = np.full(self.P, -1, dtype=np.int32)
+        self.ctx._check(self.lib.gpc_sparse_add(self.h, _ptr(off), _ptr(x0), _ptr(x1), _ptr(y), _ptr(pm), _ptr(st)))
+        return st
+
+    def add_dev(self, off, n_max, n_total, x0, x1, y, perm=None, status=None):
+        self.ctx._check(self.lib.gpc_sparse_add_dev(self.h, _ptr(off), n_max, n_total, _ptr(x0), _ptr(x1), _ptr(y),
+                                                    _ptr(perm), _ptr(status)))
+
+    def predict(self, xs0, xs1, want_sigma=True, conf=False):
+        xs0 = np.ascontiguousarray(xs0, dtype=np.float64)
+        xs1 = np.ascontiguousarray(xs1, dtype=np.float64)
+        m = xs0.shape[0]
+        f = np.full((self.P, self.ny, m), np.nan)
+        s = np.full((self.P, m), np.nan) if want_sigma else None
+        st = np.full(self.P, -1, dtype=np.int32)
+        self.ctx._check(self.lib.gpc_sparse_predict(self.h, m, _ptr(xs0), _ptr(xs1), _ptr(f), _ptr(s), int(conf), _ptr(st)))
+        return f, s, st
+
+    def predict_dev(self, m, xs0, xs1, f_star, sigma=None, conf=False, status=None):
+        self.ctx._check(self.lib.gpc_sparse_predict_dev(self.h, m, _ptr(xs0), _ptr(xs1), _ptr(f_star), _ptr(sigma),
+                                                        int(conf), _ptr(status)))
+
+    def sizes(self):
+        b = np.zeros(self.P, dtype=np.int32)
+        self.ctx._check(self.lib.gpc_sparse_sizes(self.h, _ptr(b)))
+        return b
+
+    def ld(self):
+        return self.lib.gpc_sparse_ld(self.h)
+
+    def state(self):
+        ld = self.ld()
+        alpha = np.zeros((self.P, self.ny, ld))
+        Cc = np.zeros((self.P, ld, ld))
+        Q = np.zeros((self.P, ld, ld))
+        BV = np.zeros((self.P, ld, 2))
+        self.ctx._check(self.lib.gpc_sparse_get_state(self.h, _ptr(alpha), _ptr(Cc), _ptr(Q), _ptr(BV)))
+        # C, Q are column-major per patch: [p][j][i] = M(i, j)
+        return alpha, np.transpose(Cc, (0, 2, 1)).copy(), np.transpose(Q, (0, 2, 1)).copy(), BV
+
+
+def partition_patches(off, world, sparse_capacity=0):
+    """gpc_partition_patches: returns slot_patch (world, S) with patch ids (-1 = padding)."""
+    off = np.ascontiguousarray(off, dtype=np.int32)
+    P = off.shape[0] - 1
+    S = (P + world - 1) // world if world > 0 else 0
+    out = np.zeros(max(world * S, 1), dtype=np.int32)
+    rc = load().gpc_partition_patches(P, _ptr(off), world, sparse_capacity, _ptr(out))
+    if rc != GPC_OK:
+        raise GpcError(rc, "gpc_partition_patches")
+    return out[:world * S].reshape(world, S)
+
+
+def exp_host(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros_like(x)
+    load().gpc_test_exp_host(_ptr(x), _ptr(out), x.size)
+    return out

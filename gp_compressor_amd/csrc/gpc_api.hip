@@ -1,0 +1,316 @@
+// gpc_api.hip -- C-ABI entry points of libgpc_hip.so: context, parameter defaults, dense-path dispatch,
+// patch->rank partition.  See include/gpc.h for the contract and the reference call sites each one replaces.
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "gpc_device.h"
+#include "gpc_internal.h"
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(gpc_ctx* ctx, size_t bytes)
+    {
+        if (bytes == 0) bytes = 8;
+        GPC_HIP(ctx, hipMalloc(&p, bytes));
+        return GPC_OK;
+    }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+int host_n_max(gpc_ctx* ctx, int P, const int32_t* off, int* n_max, int* n_total)
+{
+    if (P > 0 && off[0] != 0) return gpc_fail(ctx, GPC_EINVAL, "off[0] must be 0");
+    int mx = 0;
+    for (int i = 0; i < P; ++i) {
+        int n = off[i + 1] - off[i];
+        if (n < 0) return gpc_fail(ctx, GPC_EINVAL, "off must be non-decreasing (patch %d)", i);
+        mx = std::max(mx, n);
+    }
+    *n_max = mx;
+    *n_total = P > 0 ? off[P] : 0;
+    return GPC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int gpc_version(void) { return GPC_VERSION; }
+
+// gaussian_process(double sigmaf = 0.05, double l = 3, double sigman = 0.04)  (/root/reference/src/gaussian_process.h:21),
+// squared by the constructor (/root/reference/src/gaussian_process.cpp:8-9)
+void gpc_default_params_dense(gpc_params* p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->sigmaf_sq = 0.05 * 0.05;
+    p->l_sq = 3.0 * 3.0;
+    p->noise = 0.04 * 0.04;
+    p->eps_tol = 0.0;
+    p->capacity = 0;
+    p->noise_model = 0;
+    p->ref_double_noise = 1;
+    p->ref_field_delete_bug = 1;
+    p->want_variance = 0;
+}
+
+// sparse_gp(int capacity = 100, double s0 = 1e-1f), eps_tol(1e-6f)       (/root/reference/src/sparse_gp.h:48, sparse_gp.hpp:30)
+// sparse_gp_field(int capacity = 100, double s0 = 1e2f), eps_tol(1e-4f)  (/root/reference/src/sparse_gp_field.h:43, .hpp:16)
+// rbf_kernel(double sigmaf_sq = 100e-0f, double l_sq = 1*1)              (/root/reference/src/rbf_kernel.h:24)
+void gpc_default_params_sparse(gpc_params* p, int ny)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->sigmaf_sq = (double)100e-0f;
+    p->l_sq = 1 * 1;
+    p->capacity = 100;
+    p->noise_model = 0;
+    p->ref_double_noise = 1;
+    p->ref_field_delete_bug = 1;
+    if (ny == 1) {
+        p->noise = (double)1e-1f;
+        p->eps_tol = (double)1e-6f;
+    } else {
+        p->noise = (double)1e2f;
+        p->eps_tol = (double)1e-4f;
+    }
+}
+
+int gpc_ctx_create(gpc_ctx** out, int device)
+{
+    if (!out) return GPC_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GPC_ENODEV;   // no CPU fallback
+    if (device < 0 || device >= count) return GPC_ENODEV;
+    if (hipSetDevice(device) != hipSuccess) return GPC_ENODEV;
+    gpc_ctx* ctx = new (std::nothrow) gpc_ctx();
+    if (!ctx) return GPC_ENOMEM;
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return GPC_EHIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return GPC_OK;
+}
+
+int gpc_ctx_set_stream(gpc_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return GPC_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return GPC_OK;
+}
+
+int gpc_ctx_synchronize(gpc_ctx* ctx)
+{
+    if (!ctx) return GPC_EINVAL;
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPC_OK;
+}
+
+void gpc_ctx_destroy(gpc_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* gpc_last_error(const gpc_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+const char* gpc_last_dense_kernel(const gpc_ctx* ctx) { return ctx ? ctx->last_dense_kernel : ""; }
+
+// ------------------------------------------------------------------------------------------------ dense path
+
+static int dense_check(gpc_ctx* ctx, const gpc_params* prm, int P, const void* off, int n_max, int n_total,
+                       const void* x0, const void* x1, const void* y, int ny, int m, const void* f_star)
+{
+    if (!ctx) return GPC_EINVAL;
+    if (!prm) return gpc_fail(ctx, GPC_EINVAL, "params is NULL");
+    if (P < 0 || m < 0 || n_total < 0 || n_max < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
+    if (ny != 1 && ny != 3) return gpc_fail(ctx, GPC_EINVAL, "ny must be 1 (depth) or 3 (RGB), got %d", ny);
+    if (P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    if (n_total > 0 && (!x0 || !x1 || !y)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/y is NULL");
+    if (P > 0 && m > 0 && !f_star) return gpc_fail(ctx, GPC_EINVAL, "f_star is NULL");
+    if (n_max > GPC_MAX_POINTS) return gpc_fail(ctx, GPC_ERANGE, "n_max %d > GPC_MAX_POINTS %d", n_max, GPC_MAX_POINTS);
+    if (!(prm->l_sq > 0.0) || !(prm->sigmaf_sq >= 0.0) || !(prm->noise >= 0.0))
+        return gpc_fail(ctx, GPC_EINVAL, "kernel/noise parameters out of range");
+    return GPC_OK;
+}
+
+static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
+{
+    if (a.P == 0 || (a.m == 0 && !a.alpha_out)) return GPC_OK;
+    if (a.n_max < 1) a.n_max = 1;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (!a.prm.want_variance) a.v_star = nullptr;
+    int grid = 0;
+    size_t bytes = dense_generic_ws_bytes(ctx, a, &grid);
+    int rc = gpc_ws_reserve(ctx, bytes);
+    if (rc != GPC_OK) return rc;
+    return dense_generic_launch(ctx, a, grid);
+}
+
+int gpc_dense_fit_predict_dev(gpc_ctx* ctx, const gpc_params* params, int P, const int32_t* off, int n_max, int n_total,
+                              const double* x0, const double* x1, const double* y, int ny,
+                              int m, const double* xs0, const double* xs1,
+                              double* f_star, double* v_star, double* alpha_out, int32_t* status)
+{
+    int rc = dense_check(ctx, params, P, off, n_max, n_total, x0, x1, y, ny, m, f_star);
+    if (rc != GPC_OK) return rc;
+    if (m > 0 && (!xs0 || !xs1)) return gpc_fail(ctx, GPC_EINVAL, "xs0/xs1 is NULL");
+    DenseArgs a{};
+    a.prm = *params;
+    a.P = P; a.n_max = n_max; a.n_total = n_total; a.ny = ny; a.m = m;
+    a.off = off; a.x0 = x0; a.x1 = x1; a.y = y; a.xs0 = xs0; a.xs1 = xs1;
+    a.grid_res = 0.0; a.grid_sz = 0;
+    a.f_star = f_star; a.v_star = v_star; a.alpha_out = alpha_out; a.status = status;
+    return dense_dispatch(ctx, a);
+}
+
+int gpc_dense_fit_predict_grid_dev(gpc_ctx* ctx, const gpc_params* params, int P, const int32_t* off, int n_max,
+                                   int n_total, const double* x0, const double* x1, const double* y, int ny,
+                                   double res, int sz, double* f_star, double* alpha_out, int32_t* status)
+{
+    if (ctx && (sz < 0 || sz > 1024)) return gpc_fail(ctx, GPC_EINVAL, "sz out of range");
+    int rc = dense_check(ctx, params, P, off, n_max, n_total, x0, x1, y, ny, sz * sz, f_star);
+    if (rc != GPC_OK) return rc;
+    DenseArgs a{};
+    a.prm = *params;
+    a.prm.want_variance = 0;
+    a.P = P; a.n_max = n_max; a.n_total = n_total; a.ny = ny; a.m = sz * sz;
+    a.off = off; a.x0 = x0; a.x1 = x1; a.y = y; a.xs0 = nullptr; a.xs1 = nullptr;
+    a.grid_res = res; a.grid_sz = sz;
+    a.f_star = f_star; a.v_star = nullptr; a.alpha_out = alpha_out; a.status = status;
+    return dense_dispatch(ctx, a);
+}
+
+// ---- host-pointer wrappers: H2D, launch, D2H, synchronous -------------------------------------------------
+
+
+static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32_t* off,
+                      const double* x0, const double* x1, const double* y, int ny,
+                      int m, const double* xs0, const double* xs1, double res, int sz, bool grid,
+                      double* f_star, double* v_star, double* alpha_out, int32_t* status)
+{
+    if (!ctx) return GPC_EINVAL;
+    if (P < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
+    if (P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    int n_max = 0, n_total = 0;
+    int rc = host_n_max(ctx, P, off, &n_max, &n_total);
+    if (rc != GPC_OK) return rc;
+    rc = dense_check(ctx, params, P, off, n_max, n_total, x0, x1, y, ny, m, f_star);
+    if (rc != GPC_OK) return rc;
+    if (!grid && m > 0 && (!xs0 || !xs1)) return gpc_fail(ctx, GPC_EINVAL, "xs0/xs1 is NULL");
+    if (P == 0) return GPC_OK;
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    const bool want_v = !grid && params->want_variance && v_star;
+    DevBuf d_off, d_x0, d_x1, d_y, d_xs0, d_xs1, d_f, d_v, d_al, d_st;
+    const size_t N = (size_t)n_total;
+    if ((rc = d_off.alloc(ctx, sizeof(int32_t) * (P + 1))) || (rc = d_x0.alloc(ctx, 8 * N)) || (rc = d_x1.alloc(ctx, 8 * N)) ||
+        (rc = d_y.alloc(ctx, 8 * N * ny)) || (rc = d_f.alloc(ctx, 8 * (size_t)P * ny * m)) ||
+        (rc = d_st.alloc(ctx, sizeof(int32_t) * P)))
+        return rc;
+    if (!grid && ((rc = d_xs0.alloc(ctx, 8 * (size_t)m)) || (rc = d_xs1.alloc(ctx, 8 * (size_t)m)))) return rc;
+    if (want_v && (rc = d_v.alloc(ctx, 8 * (size_t)P * m))) return rc;
+    if (alpha_out && (rc = d_al.alloc(ctx, 8 * N * ny))) return rc;
+    hipStream_t s = ctx->stream;
+    GPC_HIP(ctx, hipMemcpyAsync(d_off.p, off, sizeof(int32_t) * (P + 1), hipMemcpyHostToDevice, s));
+    if (N) {
+        GPC_HIP(ctx, hipMemcpyAsync(d_x0.p, x0, 8 * N, hipMemcpyHostToDevice, s));
+        GPC_HIP(ctx, hipMemcpyAsync(d_x1.p, x1, 8 * N, hipMemcpyHostToDevice, s));
+        GPC_HIP(ctx, hipMemcpyAsync(d_y.p, y, 8 * N * ny, hipMemcpyHostToDevice, s));
+    }
+    if (!grid && m) {
+        GPC_HIP(ctx, hipMemcpyAsync(d_xs0.p, xs0, 8 * (size_t)m, hipMemcpyHostToDevice, s));
+        GPC_HIP(ctx, hipMemcpyAsync(d_xs1.p, xs1, 8 * (size_t)m, hipMemcpyHostToDevice, s));
+    }
+    if (grid)
+        rc = gpc_dense_fit_predict_grid_dev(ctx, params, P, d_off.as<int32_t>(), n_max, n_total, d_x0.as<double>(),
+                                            d_x1.as<double>(), d_y.as<double>(), ny, res, sz, d_f.as<double>(),
+                                            alpha_out ? d_al.as<double>() : nullptr, d_st.as<int32_t>());
+    else
+        rc = gpc_dense_fit_predict_dev(ctx, params, P, d_off.as<int32_t>(), n_max, n_total, d_x0.as<double>(),
+                                       d_x1.as<double>(), d_y.as<double>(), ny, m, d_xs0.as<double>(), d_xs1.as<double>(),
+                                       d_f.as<double>(), want_v ? d_v.as<double>() : nullptr,
+                                       alpha_out ? d_al.as<double>() : nullptr, d_st.as<int32_t>());
+    if (rc != GPC_OK) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    if (m) GPC_HIP(ctx, hipMemcpyAsync(f_star, d_f.p, 8 * (size_t)P * ny * m, hipMemcpyDeviceToHost, s));
+    if (want_v && m) GPC_HIP(ctx, hipMemcpyAsync(v_star, d_v.p, 8 * (size_t)P * m, hipMemcpyDeviceToHost, s));
+    if (alpha_out && N) GPC_HIP(ctx, hipMemcpyAsync(alpha_out, d_al.p, 8 * N * ny, hipMemcpyDeviceToHost, s));
+    if (status) GPC_HIP(ctx, hipMemcpyAsync(status, d_st.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, s));
+    GPC_HIP(ctx, hipStreamSynchronize(s));
+    return GPC_OK;
+}
+
+int gpc_dense_fit_predict(gpc_ctx* ctx, const gpc_params* params, int P, const int32_t* off,
+                          const double* x0, const double* x1, const double* y, int ny,
+                          int m, const double* xs0, const double* xs1,
+                          double* f_star, double* v_star, double* alpha_out, int32_t* status)
+{
+    return dense_host(ctx, params, P, off, x0, x1, y, ny, m, xs0, xs1, 0.0, 0, false, f_star, v_star, alpha_out, status);
+}
+
+int gpc_dense_fit_predict_grid(gpc_ctx* ctx, const gpc_params* params, int P, const int32_t* off,
+                               const double* x0, const double* x1, const double* y, int ny,
+                               double res, int sz, double* f_star, double* alpha_out, int32_t* status)
+{
+    if (ctx && (sz < 0 || sz > 1024)) return gpc_fail(ctx, GPC_EINVAL, "sz out of range");
+    return dense_host(ctx, params, P, off, x0, x1, y, ny, sz * sz, nullptr, nullptr, res, sz, true, f_star, nullptr,
+                      alpha_out, status);
+}
+
+// ------------------------------------------------------------------------------------------------ partition
+
+// Patches are independent (/root/reference/src/gp_compressor.cpp:146-163), so one process per GPU takes a subset.
+// Longest-processing-time: sort by cost descending, give each to the least-loaded rank that still has a free slot.
+int gpc_partition_patches(int P, const int32_t* off, int world, int sparse_capacity, int32_t* slot_patch)
+{
+    if (P < 0 || world <= 0 || !slot_patch || (P > 0 && !off)) return GPC_EINVAL;
+    const int S = (P + world - 1) / world;
+    for (long i = 0; i < (long)S * world; ++i) slot_patch[i] = -1;
+    std::vector<int> order(P);
+    std::iota(order.begin(), order.end(), 0);
+    auto cost = [&](int p) -> double {
+        double n = (double)(off[p + 1] - off[p]);
+        if (sparse_capacity > 0) {
+            double b = std::min(n, (double)sparse_capacity);
+            return n * b * b;
+        }
+        return n * n * n;
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+    std::vector<double> load(world, 0.0);
+    std::vector<int> used(world, 0);
+    for (int p : order) {
+        int best = -1;
+        for (int r = 0; r < world; ++r)
+            if (used[r] < S && (best < 0 || load[r] < load[best])) best = r;
+        slot_patch[(long)best * S + used[best]] = p;
+        used[best]++;
+        load[best] += cost(p);
+    }
+    return GPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ test hooks
+// Host-side evaluation of the device exp() (same source, gpc_device.h) so that the CPU suite can bound its error.
+void gpc_test_exp_host(const double* x, double* out, int n)
+{
+    for (int i = 0; i < n; ++i) out[i] = gpc_exp_tbl(x[i], h_gpc_exp_table);
+}
+
+}  // extern "C"

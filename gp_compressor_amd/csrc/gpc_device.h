@@ -1,0 +1,90 @@
+// gpc_device.h -- device-side helpers shared by the dense and sparse kernels (gfx950, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#define GPC_WAVE 64
+
+// ---------------------------------------------------------------------------------------------------------
+// exp() for the RBF kernel.  Table-driven (Tang): x = (64 e + j) ln2/64 + r, |r| <= ln2/128,
+// exp(x) = 2^e * T[j] * (1 + p(r)), p of degree 5 (truncation r^6/720 < 3.5e-17).  Max error ~1 ulp, which is
+// the same class as glibc's exp the reference calls (src/rbf_kernel.cpp:17); parity is stated as a tolerance.
+// The table (64 doubles = 512 B) is staged into LDS once per workgroup by gpc_exp_table_init().
+// Compiles for host as well so that the CPU test-suite can check its accuracy without a GPU.
+// ---------------------------------------------------------------------------------------------------------
+#define GPC_EXP_TABLE_SIZE 64
+
+// one copy per translation unit (no -fgpu-rdc); 512 B
+static __constant__ double c_gpc_exp_table[GPC_EXP_TABLE_SIZE] = {
+#include "gpc_exp_table.inc"
+};
+static const double h_gpc_exp_table[GPC_EXP_TABLE_SIZE] = {
+#include "gpc_exp_table.inc"
+};
+
+__host__ __device__ static inline double gpc_exp_tbl(double x, const double* __restrict__ T)
+{
+    const double INV_LN2_64 = 92.332482616893656768;        // 64 / ln 2
+    const double LN2_64_HI = 0x1.62e42fef80000p-7;           // ln2/64 rounded to 34 bits: n * hi is exact for |n| < 2^19
+    const double LN2_64_LO = 0x1.1cf79abc9e3b4p-42;          // ln2/64 - hi
+    // clamp: outside [-760, 720] the result is 0 / inf anyway; keeps the int conversion in range. NaN falls through.
+    double xc = x < -760.0 ? -760.0 : (x > 720.0 ? 720.0 : x);
+    double nd = __builtin_rint(xc * INV_LN2_64);
+    int n = (int)nd;
+    double r = __builtin_fma(-nd, LN2_64_HI, xc);
+    r = __builtin_fma(-nd, LN2_64_LO, r);
+    int j = n & (GPC_EXP_TABLE_SIZE - 1);
+    int e = n >> 6;
+    double p = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    p = __builtin_fma(r, p, 1.0 / 6.0);
+    p = __builtin_fma(r, p, 0.5);
+    double r2 = r * r;
+    p = __builtin_fma(r2, p, r);          // r + r^2 (1/2 + r/6 + r^2/24 + r^3/120)
+    double t = T[j];
+    double v = __builtin_fma(t, p, t);
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = __builtin_amdgcn_ldexp(v, e);     // v_ldexp_f64: correct gradual underflow / overflow to inf
+#else
+    v = __builtin_ldexp(v, e);
+#endif
+    return (x != x) ? x : v;
+}
+
+__device__ static inline void gpc_exp_table_init(double* T_lds)
+{
+    for (int i = threadIdx.x; i < GPC_EXP_TABLE_SIZE; i += blockDim.x) T_lds[i] = c_gpc_exp_table[i];
+}
+
+// RBF / squared-exponential kernel.  c = (double)(-0.5f) / l_sq is formed on the host exactly like the reference
+// evaluates `-0.5f / p(1)` (src/rbf_kernel.cpp:17, src/gaussian_process.cpp:49); sf = sigma_f^2.
+__device__ static inline double gpc_rbf(double sf, double c, double xi0, double xi1, double xj0, double xj1, const double* T)
+{
+    double d0 = xi0 - xj0, d1 = xi1 - xj1;
+    double sq = d0 * d0 + d1 * d1;
+    return sf * gpc_exp_tbl(c * sq, T);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// wave / block reductions
+// ---------------------------------------------------------------------------------------------------------
+__device__ static inline double gpc_wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum through LDS scratch (>= blockDim.x/64 doubles); every thread gets the result
+__device__ static inline double gpc_block_sum(double v, double* scratch)
+{
+    v = gpc_wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; ++i) s += scratch[i];
+    return s;
+}

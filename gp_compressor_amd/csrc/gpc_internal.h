@@ -1,0 +1,83 @@
+// gpc_internal.h -- shared host-side definitions of libgpc_hip.so (not part of the C-ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/gpc.h"
+
+struct gpc_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;  // created with the context
+    hipStream_t stream = nullptr;      // stream in use (own_stream or the caller's)
+    int num_cus = 256;
+    // grow-only device workspace (K / L factors of the generic dense kernel, variance scratch, grid tables)
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    std::mutex mu;
+    char err[512] = {0};
+    const char* last_dense_kernel = "";
+};
+
+static inline int gpc_fail(gpc_ctx* ctx, int code, const char* fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define GPC_HIP(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return gpc_fail((ctx), e_ == hipErrorOutOfMemory ? GPC_ENOMEM : GPC_EHIP, "%s failed: %s",  \
+                            #call, hipGetErrorString(e_));                                              \
+    } while (0)
+
+// grow-only workspace; returns nullptr + sets error on failure.  Caller holds ctx->mu.
+static inline int gpc_ws_reserve(gpc_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->ws_bytes) return GPC_OK;
+    if (ctx->ws) {
+        // the previous workspace may still be in use by work enqueued on the stream
+        GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GPC_HIP(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    GPC_HIP(ctx, hipMalloc(&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return GPC_OK;
+}
+
+// ---- launchers implemented in the kernel translation units -------------------------------------------------
+
+struct DenseArgs {
+    gpc_params prm;
+    int P, n_max, n_total, ny, m;
+    const int32_t* off;
+    const double *x0, *x1, *y;
+    const double *xs0, *xs1;   // point-wise X* (m entries) or nullptr when the grid form is used
+    double grid_res;           // grid form: res, sz (m = sz*sz)
+    int grid_sz;
+    double *f_star, *v_star, *alpha_out;
+    int32_t* status;
+};
+
+// generic kernel: any n <= GPC_MAX_POINTS, K/L in a global-memory workspace slot per workgroup
+size_t dense_generic_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out);
+int dense_generic_launch(gpc_ctx* ctx, const DenseArgs& a, int grid);
+
+// register-tile MFMA kernel: n <= 256, trailing matrix resident in VGPRs (see dense_mfma.hip)
+bool dense_mfma_supported(const DenseArgs& a);
+int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a);

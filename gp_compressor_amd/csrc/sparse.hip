@@ -1,0 +1,706 @@
+// sparse.hip -- batched online sparse GP (Csato-Opper) : sparse_gp<rbf_kernel, gaussian_noise> and
+// sparse_gp_field<rbf_kernel, gaussian_noise_3d> of the reference, one patch per workgroup.
+//
+// Follows /root/reference/src/sparse_gp.hpp:89-249 (add), :252-295 (delete_bv), :299-351 (predict) and the
+// field variant /root/reference/src/sparse_gp_field.hpp:59-215, 219-263, 268-320.  The recursion is strictly
+// sequential in the points of one patch and data-dependent (sparse vs full update, capacity / geometric
+// deletions), so the parallelism is: patches across workgroups, and inside a patch the O(b) kernel vector, the
+// two O(b^2) mat-vecs (C k, Q k) and the O(b^2) rank-1 updates across the 256 threads of the workgroup.  All
+// branch decisions are taken from values every thread computes identically (LDS-reduced), so control flow is
+// workgroup-uniform.
+//
+// State layout in HBM (persistent across calls, /root/reference/src/gp_mapping.cpp:338-339 keeps adding to
+// trained GPs):  alpha [P][ny][ld], C [P][ld][ld], Q [P][ld][ld] column-major like Eigen, BV [P][ld][2] (AoS,
+// = Eigen 2 x b column-major), b [P], total_count [P];  ld = capacity + 1 (a full update may hold capacity+1
+// basis vectors until the deletion that follows it), or GPC_MAX_BV when capacity == -1.
+#include <vector>
+
+#include "gpc_device.h"
+#include "gpc_internal.h"
+
+#define SP_THREADS 256
+
+struct gpc_sparse {
+    gpc_ctx* ctx;
+    gpc_params prm;
+    int P, ny, ld;
+    double *alpha, *C, *Q, *BV;
+    int32_t *b, *count, *stat;
+};
+
+struct SpState {
+    double *alpha, *C, *Q, *BV;   // this patch
+    int ld, ny;
+};
+
+// ---- block-wide helpers (all SP_THREADS threads call) -------------------------------------------------------
+
+// dot products of up to 4 pairs at once; results broadcast to every thread
+__device__ static inline void sp_block_sum4(double (&v)[4], double* scratch /*4*4 doubles*/)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = gpc_wave_sum(v[q]);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) scratch[w * 4 + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = scratch[q] + scratch[4 + q] + scratch[8 + q] + scratch[12 + q];
+}
+
+// argmin with first-index tie break (the reference scans i ascending with a strict '<')
+__device__ static inline void sp_block_argmin(double& val, int& idx, double* sval, int* sidx)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_xor(val, o, 64);
+        int oi = __shfl_xor(idx, o, 64);
+        if (ov < val || (ov == val && oi < idx) || (val != val && ov == ov)) { val = ov; idx = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sval[w] = val; sidx[w] = idx; }
+    __syncthreads();
+    val = sval[0];
+    idx = sidx[0];
+    for (int q = 1; q < SP_THREADS / 64; ++q) {
+        double ov = sval[q];
+        int oi = sidx[q];
+        if (ov < val || (ov == val && oi < idx) || (val != val && ov == ov)) { val = ov; idx = oi; }
+    }
+}
+
+// delete_bv(loc): sparse_gp.hpp:252-295 / sparse_gp_field.hpp:219-263.  b is workgroup-uniform; returns b-1.
+__device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_bug, double* Cstar, double* Qstar,
+                                   double* Crep, double* Qrep)
+{
+    const int tid = threadIdx.x, ld = S.ld, last = b - 1, ny = S.ny;
+    double alphastar[3];
+    for (int c = 0; c < ny; ++c) alphastar[c] = S.alpha[c * ld + loc];
+    const double cstar = S.C[loc + (size_t)loc * ld];
+    const double qstar = S.Q[loc + (size_t)loc * ld];
+    for (int i = tid; i < b; i += SP_THREADS) {
+        Cstar[i] = S.C[i + (size_t)loc * ld];
+        Qstar[i] = S.Q[i + (size_t)loc * ld];
+        Crep[i] = S.C[i + (size_t)last * ld];
+        Qrep[i] = S.Q[i + (size_t)last * ld];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Cstar[loc] = Cstar[last];   // Cstar(loc) = Cstar(last)  (:263)
+        Qstar[loc] = Qstar[last];   // (:275)
+        Crep[loc] = Crep[last];     // (:267)
+        Qrep[loc] = Qrep[last];     // (:278)
+    }
+    __syncthreads();
+    for (int i = tid; i < b; i += SP_THREADS) {
+        const double cr = Crep[i], qr = Qrep[i];
+        S.C[loc + (size_t)i * ld] = cr;   // C.row(loc) = Crep^T
+        S.C[i + (size_t)loc * ld] = cr;   // C.col(loc) = Crep
+        S.Q[loc + (size_t)i * ld] = qr;
+        S.Q[i + (size_t)loc * ld] = qr;
+    }
+    if (tid < ny) S.alpha[tid * ld + loc] = S.alpha[tid * ld + last];     // alpha(loc) = alpha(last)  (:257)
+    if (tid == 32) {
+        S.BV[2 * loc] = S.BV[2 * last];                                     // BV.col(loc) = BV.col(last) (:291)
+        S.BV[2 * loc + 1] = S.BV[2 * last + 1];
+    }
+    __syncthreads();
+    const int nb = b - 1;
+    const double qc_den = qstar + cstar;
+    // alpha update (:285) / field variant (:250-253, multiplies when bug-compatible)
+    for (int i = tid; i < nb; i += SP_THREADS) {
+        const double qc = Qstar[i] + Cstar[i];
+        for (int c = 0; c < ny; ++c) {
+            if (ny == 1) S.alpha[i] -= alphastar[0] / qc_den * qc;
+            else S.alpha[c * ld + i] -= alphastar[c] * (field_bug ? qc_den * qc : qc / qc_den);
+        }
+    }
+    // C += Qs Qs^T / qstar - (Qs+Cs)(Qs+Cs)^T / (qstar+cstar);  Q -= Qs Qs^T / qstar   (:286-288)
+    for (int e = tid; e < nb * nb; e += SP_THREADS) {
+        const int i = e % nb, j = e / nb;
+        const double qq = (Qstar[i] * Qstar[j]) / qstar;
+        const double cc = ((Qstar[i] + Cstar[i]) * (Qstar[j] + Cstar[j])) / qc_den;
+        S.C[i + (size_t)j * ld] += qq - cc;
+        S.Q[i + (size_t)j * ld] -= qq;
+    }
+    __syncthreads();
+    return nb;
+}
+
+struct SpAddParams {
+    gpc_params prm;
+    double c_exp;
+    int P, ny, ld, n_total;
+    const int32_t* off;
+    const double *x0, *x1, *y;
+    const int32_t* perm;
+    double *alpha, *C, *Q, *BV;
+    int32_t *b, *count, *stat, *status_out;
+};
+
+__global__ __launch_bounds__(SP_THREADS) void sparse_add_kernel(SpAddParams A)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ld = A.ld, ny = A.ny;
+    double* T = reinterpret_cast<double*>(smem);   // 64
+    double* red = T + 64;                          // 16
+    double* sval = red + 16;                       // 4
+    int* sidx = reinterpret_cast<int*>(sval + 4);  // 4 ints (2 doubles)
+    double* kv = sval + 6;                         // k        [ld]
+    double* ck = kv + ld;                          // C k      [ld]
+    double* eh = ck + ld;                          // e_hat    [ld+1]
+    double* sv = eh + ld + 1;                      // s / s_hat[ld+1]
+    double* part = sv + ld + 1;                    // partial mat-vec sums [4][2][ld]
+    double* Cstar = part;                          // delete_bv scratch aliases the mat-vec partials
+    double* Qstar = part + ld;
+    double* Crep = part + 2 * ld;
+    double* Qrep = part + 3 * ld;
+    gpc_exp_table_init(T);
+
+    const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, eps_tol = A.prm.eps_tol;
+    const int capacity = A.prm.capacity;
+
+    for (int patch = blockIdx.x; patch < A.P; patch += gridDim.x) {
+        const int o = A.off[patch], n = A.off[patch + 1] - o;
+        SpState S;
+        S.ld = ld; S.ny = ny;
+        S.alpha = A.alpha + (size_t)patch * ny * ld;
+        S.C = A.C + (size_t)patch * ld * ld;
+        S.Q = A.Q + (size_t)patch * ld * ld;
+        S.BV = A.BV + (size_t)patch * ld * 2;
+        int b = A.b[patch];
+        int st = A.stat[patch];
+        __syncthreads();
+
+        for (int it = 0; it < n; ++it) {
+            const int r = A.perm ? A.perm[o + it] : it;
+            const double px0 = A.x0[o + r], px1 = A.x1[o + r];
+            double yv[3];
+            for (int c = 0; c < ny; ++c) yv[c] = A.y[(size_t)c * A.n_total + o + r];
+            const double kstar = sf;   // kernel_function(X, X) = p(0)*exp(0)  (:98)
+
+            if (b == 0) {
+                // First point (:100-114)
+                if (tid == 0) {
+                    for (int c = 0; c < ny; ++c) S.alpha[c * ld] = yv[c] / (kstar + s20);
+                    S.C[0] = (double)(-1.0f) / (kstar + s20);
+                    S.Q[0] = (double)(1.0f) / kstar;
+                    S.BV[0] = px0;
+                    S.BV[1] = px1;
+                }
+                b = 1;
+                __syncthreads();
+                continue;
+            }
+
+            // k = construct_covariance(X, BV)  (:119, :523-530)
+            for (int i = tid; i < b; i += SP_THREADS) kv[i] = gpc_rbf(sf, A.c_exp, px0, px1, S.BV[2 * i], S.BV[2 * i + 1], T);
+            __syncthreads();
+
+            // C k and e_hat = Q k (:140,:160,:171): wave w covers columns j in its quarter, lanes cover rows
+            {
+                const int jlo = (b * wave) >> 2, jhi = (b * (wave + 1)) >> 2;
+                for (int i = lane; i < b; i += 64) {
+                    double ac = 0.0, aq = 0.0;
+                    for (int j = jlo; j < jhi; ++j) {
+                        const double kj = kv[j];
+                        ac += S.C[i + (size_t)j * ld] * kj;
+                        aq += S.Q[i + (size_t)j * ld] * kj;
+                    }
+                    part[(wave * 2 + 0) * ld + i] = ac;
+                    part[(wave * 2 + 1) * ld + i] = aq;
+                }
+            }
+            __syncthreads();
+            double sums[4] = {0.0, 0.0, 0.0, 0.0};   // m[0..2] partial, (kCk, ke) handled in a second pass
+            double dots[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i = tid; i < b; i += SP_THREADS) {
+                const double c_ = part[0 * ld + i] + part[2 * ld + i] + part[4 * ld + i] + part[6 * ld + i];
+                const double q_ = part[1 * ld + i] + part[3 * ld + i] + part[5 * ld + i] + part[7 * ld + i];
+                ck[i] = c_;
+                eh[i] = q_;
+                const double ki = kv[i];
+                dots[0] += ki * c_;                        // k^T C k   (:122)
+                dots[1] += ki * q_;                        // k^T e_hat (:144)
+                for (int c = 0; c < ny; ++c) sums[c] += S.alpha[c * ld + i] * ki;   // m = alpha^T k (:121)
+            }
+            sp_block_sum4(dots, red);
+            sp_block_sum4(sums, red);
+            const double s2 = kstar + dots[0];
+            double gamma = kstar - dots[1];
+            if (gamma < (double)1e-12f) gamma = 0;          // :146-151
+
+            // r = noise.dx2_ln, q = noise.dx_ln  (/root/reference/src/gaussian_noise.cpp:9-18, gaussian_noise_3d.cpp:11-20,
+            // probit_noise.cpp:11-31)
+            double rr, qv[3];
+            if (A.prm.noise_model == 1 && ny == 1) {
+                const double sigma2 = s20 + s2, sigma = sqrt(sigma2);
+                const double z = yv[0] * sums[0] / sigma;
+                const double two_sqrt2 = (double)(2.0f * 1.41421354f);   // float product, see oracle/gpc_oracle.c
+                const double ef = erf(z) / two_sqrt2;
+                const double efprim = exp(-z * z / 2.0) / sqrt(2.0 * M_PI);
+                qv[0] = yv[0] / sigma * efprim / ef;
+                const double first = efprim / ef;
+                rr = ((-z * efprim) / ef - first * first) / sigma2;
+            } else {
+                rr = (double)(-1.0f) / (s20 + s2);
+                for (int c = 0; c < ny; ++c) qv[c] = (yv[c] - sums[c]) / (s20 + s2);
+            }
+
+            if (gamma < eps_tol && capacity != -1) {
+                // sparse update (:155-163)
+                const double eta = 1 / (1 + gamma * rr);
+                for (int i = tid; i < b; i += SP_THREADS) {
+                    const double sh = ck[i] + eh[i];        // s_hat = C*k + e_hat
+                    sv[i] = sh;
+                    for (int c = 0; c < ny; ++c) S.alpha[c * ld + i] += sh * (qv[c] * eta);
+                }
+                __syncthreads();
+                const double re = rr * eta;
+                for (int e = tid; e < b * b; e += SP_THREADS) {
+                    const int i = e % b, j = e / b;
+                    S.C[i + (size_t)j * ld] += (re * sv[i]) * sv[j];
+                }
+                __syncthreads();
+            } else if (b >= ld) {
+                st = GPC_STATUS_OVERFLOW;                   // capacity == -1 and GPC_MAX_BV reached: skip the point
+            } else {
+                // full update (:164-203)
+                for (int i = tid; i <= b; i += SP_THREADS) {
+                    const double si = (i < b) ? ck[i] : (double)1.0f;
+                    sv[i] = si;
+                    if (i == b) eh[b] = (double)(-1.0f);
+                    for (int c = 0; c < ny; ++c) {
+                        const double a0 = (i < b) ? S.alpha[c * ld + i] : 0.0;
+                        S.alpha[c * ld + i] = a0 + qv[c] * si;
+                    }
+                }
+                if (tid == 64) {
+                    S.BV[2 * b] = px0;
+                    S.BV[2 * b + 1] = px1;
+                }
+                __syncthreads();
+                const double ig = (double)1.0f / gamma;
+                const int nb = b + 1;
+                for (int e = tid; e < nb * nb; e += SP_THREADS) {
+                    const int i = e % nb, j = e / nb;
+                    const bool old = (i < b) && (j < b);
+                    const double c0 = old ? S.C[i + (size_t)j * ld] : 0.0;
+                    const double q0 = old ? S.Q[i + (size_t)j * ld] : 0.0;
+                    S.C[i + (size_t)j * ld] = c0 + (rr * sv[i]) * sv[j];
+                    S.Q[i + (size_t)j * ld] = q0 + (ig * eh[i]) * eh[j];
+                }
+                b = nb;
+                __syncthreads();
+            }
+
+            // Delete BVs if necessary (:206-223)
+            while (b > capacity && capacity > 0) {
+                double best = 0.0;
+                int loc = 0x7fffffff;
+                bool have = false;
+                for (int i = tid; i < b; i += SP_THREADS) {
+                    double a2 = 0.0;
+                    for (int c = 0; c < ny; ++c) { const double a = S.alpha[c * ld + i]; a2 += a * a; }
+                    const double score = a2 / (S.Q[i + (size_t)i * ld] + S.C[i + (size_t)i * ld]);
+                    if (!have || score < best) { best = score; loc = i; have = true; }
+                }
+                if (!have) best = __builtin_inf();
+                sp_block_argmin(best, loc, sval, sidx);
+                if (loc < 0 || loc >= b) loc = 0;          // all-NaN scores: the reference keeps minloc = 0
+                b = sp_delete_bv(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
+            }
+            // Delete for geometric reasons (:226-242)
+            {
+                double minscore = 0.0;
+                while (minscore < (double)1e-9f && b > 1) {
+                    double best = 0.0;
+                    int loc = 0x7fffffff;
+                    bool have = false;
+                    for (int i = tid; i < b; i += SP_THREADS) {
+                        const double score = (double)1.0f / S.Q[i + (size_t)i * ld];
+                        if (!have || score < best) { best = score; loc = i; have = true; }
+                    }
+                    if (!have) best = __builtin_inf();
+                    sp_block_argmin(best, loc, sval, sidx);
+                    if (loc < 0 || loc >= b) loc = 0;
+                    minscore = best;
+                    if (minscore < (double)1e-9f) b = sp_delete_bv(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
+                    else if (!(minscore >= (double)1e-9f)) break;   // NaN: `minscore < 1e-9f` is false in the reference too
+                }
+            }
+            // isnan(C(0,0)) -> "sparse_gp::C has become Nan" (:245)
+            {
+                const double c00 = S.C[0];
+                if (c00 != c00 && st == GPC_STATUS_OK) st = GPC_STATUS_NAN;
+            }
+        }
+        if (tid == 0) {
+            A.b[patch] = b;
+            A.count[patch] += n;
+            A.stat[patch] = st;
+            if (A.status_out) A.status_out[patch] = st;
+        }
+    }
+}
+
+struct SpPredParams {
+    gpc_params prm;
+    double c_exp;
+    int P, ny, ld, m, conf;
+    const double *xs0, *xs1;
+    const double *alpha, *C, *BV;
+    const int32_t* b;
+    double *f_star, *sigma;
+    int32_t* status_out;
+    const int32_t* stat;
+};
+
+#define SP_PC 32   // grid points per chunk of the sigma path
+
+__global__ __launch_bounds__(SP_THREADS) void sparse_predict_kernel(SpPredParams A)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int ld = A.ld, ny = A.ny, m = A.m;
+    double* T = reinterpret_cast<double*>(smem);   // 64
+    double* bv = T + 64;                           // 2*ld
+    double* al = bv + 2 * ld;                      // ny*ld
+    int* clamp = reinterpret_cast<int*>(al + 3 * ld);   // 2 doubles of room
+    double* racc = al + 3 * ld + 2;                // [8][SP_PC]
+    double* Kc = racc + 8 * SP_PC;                 // [ld][SP_PC]   (sigma path only; LDS is sized for it only then)
+    gpc_exp_table_init(T);
+    const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise;
+
+    for (int patch = blockIdx.x; patch < A.P; patch += gridDim.x) {
+        const int b = A.b[patch];
+        const double* Cg = A.C + (size_t)patch * ld * ld;
+        __syncthreads();
+        for (int i = tid; i < b; i += SP_THREADS) {
+            bv[2 * i] = A.BV[(size_t)patch * ld * 2 + 2 * i];
+            bv[2 * i + 1] = A.BV[(size_t)patch * ld * 2 + 2 * i + 1];
+            for (int c = 0; c < ny; ++c) al[c * ld + i] = A.alpha[((size_t)patch * ny + c) * ld + i];
+        }
+        if (tid == 0) *clamp = 0;
+        __syncthreads();
+        double* fs = A.f_star + (size_t)patch * ny * m;
+        // mean: f = alpha^T k (:329); b == 0 -> 0 (:321-327)
+        for (int p = tid; p < m; p += SP_THREADS) {
+            const double q0 = A.xs0[p], q1 = A.xs1[p];
+            double s[3] = {0.0, 0.0, 0.0};
+            for (int i = 0; i < b; ++i) {
+                const double k = gpc_rbf(sf, A.c_exp, q0, q1, bv[2 * i], bv[2 * i + 1], T);
+                for (int c = 0; c < ny; ++c) s[c] += al[c * ld + i] * k;
+            }
+            for (int c = 0; c < ny; ++c) fs[(size_t)c * m + p] = s[c];
+        }
+        if (A.sigma) {
+            double* sg = A.sigma + (size_t)patch * m;
+            const double kstar = sf;
+            for (int p0 = 0; p0 < m; p0 += SP_PC) {
+                const int pc = min(SP_PC, m - p0);
+                __syncthreads();
+                for (int e = tid; e < b * SP_PC; e += SP_THREADS) {
+                    const int pp = e & (SP_PC - 1), i = e / SP_PC;
+                    Kc[i * SP_PC + pp] = (pp < pc) ? gpc_rbf(sf, A.c_exp, A.xs0[p0 + pp], A.xs1[p0 + pp], bv[2 * i], bv[2 * i + 1], T) : 0.0;
+                }
+                __syncthreads();
+                const int pp = tid & (SP_PC - 1), ig = tid / SP_PC;   // 8 row groups
+                double acc = 0.0;
+                for (int j = ig; j < b; j += SP_THREADS / SP_PC) {
+                    // (k^T C)_j = sum_i k_i C(i,j)   (:330, evaluated as (k^T C) k)
+                    double t = 0.0;
+                    for (int i = 0; i < b; ++i) t += Kc[i * SP_PC + pp] * Cg[i + (size_t)j * ld];
+                    acc += t * Kc[j * SP_PC + pp];
+                }
+                racc[ig * SP_PC + pp] = acc;
+                __syncthreads();
+                if (tid < pc) {
+                    double kCk = 0.0;
+                    for (int q = 0; q < SP_THREADS / SP_PC; ++q) kCk += racc[q * SP_PC + tid];
+                    double sigma = (b == 0) ? kstar + s20 : s20 + kstar + kCk;
+                    if (sigma < 0) { sigma = 0; *clamp = 1; }                 // :334-337
+                    if (A.conf) {
+                        sigma /= kstar + s20;
+                        sigma = (double)100.0f * ((double)1.0f - sigma);    // :340-345
+                    } else {
+                        sigma = sqrt(sigma);
+                    }
+                    sg[p0 + tid] = sigma;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && A.status_out) {
+            int st = A.stat[patch];
+            if (st == GPC_STATUS_OK && *clamp) st = GPC_STATUS_SIGMA_CLAMPED;
+            A.status_out[patch] = st;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+static size_t sp_add_lds(int ld) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (ld + 1) + 8 * ld); }
+static size_t sp_pred_lds(int ld, bool sigma)
+{
+    return sizeof(double) * (size_t)(64 + 5 * ld + (sigma ? (size_t)ld * SP_PC : 0) + 8 * SP_PC + 2);
+}
+
+extern "C" {
+
+int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc_sparse** out)
+{
+    if (!ctx) return GPC_EINVAL;
+    if (!out) return gpc_fail(ctx, GPC_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!params) return gpc_fail(ctx, GPC_EINVAL, "params is NULL");
+    if (P < 0) return gpc_fail(ctx, GPC_EINVAL, "negative P");
+    if (ny != 1 && ny != 3) return gpc_fail(ctx, GPC_EINVAL, "ny must be 1 (sparse_gp) or 3 (sparse_gp_field), got %d", ny);
+    if (params->capacity == 0 || params->capacity < -1) return gpc_fail(ctx, GPC_EINVAL, "capacity must be > 0 or -1");
+    if (params->capacity > GPC_MAX_BV - 1) return gpc_fail(ctx, GPC_ERANGE, "capacity %d > %d", params->capacity, GPC_MAX_BV - 1);
+    if (params->noise_model == 1 && ny != 1) return gpc_fail(ctx, GPC_EINVAL, "probit noise needs ny == 1");
+    if (!(params->l_sq > 0.0) || !(params->sigmaf_sq > 0.0)) return gpc_fail(ctx, GPC_EINVAL, "kernel parameters out of range");
+    gpc_sparse* g = new (std::nothrow) gpc_sparse();
+    if (!g) return GPC_ENOMEM;
+    g->ctx = ctx; g->prm = *params; g->P = P; g->ny = ny;
+    g->ld = params->capacity == -1 ? GPC_MAX_BV : params->capacity + 1;
+    g->alpha = g->C = g->Q = g->BV = nullptr;
+    g->b = g->count = g->stat = nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const size_t ld = (size_t)g->ld, Pn = (size_t)(P > 0 ? P : 1);
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc(&g->alpha, 8 * Pn * ny * ld);
+    if (e == hipSuccess) e = hipMalloc(&g->C, 8 * Pn * ld * ld);
+    if (e == hipSuccess) e = hipMalloc(&g->Q, 8 * Pn * ld * ld);
+    if (e == hipSuccess) e = hipMalloc(&g->BV, 8 * Pn * ld * 2);
+    if (e == hipSuccess) e = hipMalloc(&g->b, 4 * Pn);
+    if (e == hipSuccess) e = hipMalloc(&g->count, 4 * Pn);
+    if (e == hipSuccess) e = hipMalloc(&g->stat, 4 * Pn);
+    if (e == hipSuccess) e = hipMemsetAsync(g->b, 0, 4 * Pn, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(g->count, 0, 4 * Pn, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(g->stat, 0, 4 * Pn, ctx->stream);
+    if (e != hipSuccess) {
+        int rc = gpc_fail(ctx, e == hipErrorOutOfMemory ? GPC_ENOMEM : GPC_EHIP, "gpc_sparse_create: %s", hipGetErrorString(e));
+        for (void* p : {(void*)g->alpha, (void*)g->C, (void*)g->Q, (void*)g->BV, (void*)g->b, (void*)g->count, (void*)g->stat})
+            if (p) (void)hipFree(p);
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return GPC_OK;
+}
+
+void gpc_sparse_destroy(gpc_sparse* g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    for (void* p : {(void*)g->alpha, (void*)g->C, (void*)g->Q, (void*)g->BV, (void*)g->b, (void*)g->count, (void*)g->stat})
+        if (p) (void)hipFree(p);
+    delete g;
+}
+
+int gpc_sparse_ld(const gpc_sparse* g) { return g ? g->ld : GPC_EINVAL; }
+
+int gpc_sparse_reset(gpc_sparse* g)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t Pn = (size_t)(g->P > 0 ? g->P : 1);
+    GPC_HIP(ctx, hipMemsetAsync(g->b, 0, 4 * Pn, ctx->stream));
+    GPC_HIP(ctx, hipMemsetAsync(g->count, 0, 4 * Pn, ctx->stream));
+    GPC_HIP(ctx, hipMemsetAsync(g->stat, 0, 4 * Pn, ctx->stream));
+    return GPC_OK;
+}
+
+int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total, const double* x0, const double* x1,
+                       const double* y, const int32_t* perm, int32_t* status)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    if (g->P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    if (n_total < 0 || n_max < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
+    if (n_total > 0 && (!x0 || !x1 || !y)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/y is NULL");
+    if (g->P == 0) return GPC_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    SpAddParams A;
+    A.prm = g->prm;
+    A.c_exp = (double)(-0.5f) / g->prm.l_sq;
+    A.P = g->P; A.ny = g->ny; A.ld = g->ld; A.n_total = n_total;
+    A.off = off; A.x0 = x0; A.x1 = x1; A.y = y; A.perm = perm;
+    A.alpha = g->alpha; A.C = g->C; A.Q = g->Q; A.BV = g->BV;
+    A.b = g->b; A.count = g->count; A.stat = g->stat; A.status_out = status;
+    const size_t lds = sp_add_lds(g->ld);
+    int per_cu = (int)((160u * 1024u) / lds);
+    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    int grid = std::min(g->P, ctx->num_cus * per_cu);
+    hipLaunchKernelGGL(sparse_add_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
+    GPC_HIP(ctx, hipGetLastError());
+    return GPC_OK;
+}
+
+int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double* xs1, double* f_star, double* sigma,
+                           int conf, int32_t* status)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    if (m < 0) return gpc_fail(ctx, GPC_EINVAL, "negative m");
+    if (m > 0 && (!xs0 || !xs1 || !f_star)) return gpc_fail(ctx, GPC_EINVAL, "xs0/xs1/f_star is NULL");
+    if (g->P == 0 || m == 0) return GPC_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    SpPredParams A;
+    A.prm = g->prm;
+    A.c_exp = (double)(-0.5f) / g->prm.l_sq;
+    A.P = g->P; A.ny = g->ny; A.ld = g->ld; A.m = m; A.conf = conf;
+    A.xs0 = xs0; A.xs1 = xs1; A.alpha = g->alpha; A.C = g->C; A.BV = g->BV; A.b = g->b;
+    A.f_star = f_star; A.sigma = sigma; A.status_out = status; A.stat = g->stat;
+    const size_t lds = sp_pred_lds(g->ld, sigma != nullptr);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_predict_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int per_cu = (int)((160u * 1024u) / lds);
+    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    int grid = std::min(g->P, ctx->num_cus * per_cu);
+    hipLaunchKernelGGL(sparse_predict_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
+    GPC_HIP(ctx, hipGetLastError());
+    return GPC_OK;
+}
+
+int gpc_sparse_add(gpc_sparse* g, const int32_t* off, const double* x0, const double* x1, const double* y,
+                   const int32_t* perm, int32_t* status)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    const int P = g->P;
+    if (P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    if (P == 0) return GPC_OK;
+    if (off[0] != 0) return gpc_fail(ctx, GPC_EINVAL, "off[0] must be 0");
+    int n_max = 0;
+    for (int i = 0; i < P; ++i) {
+        const int n = off[i + 1] - off[i];
+        if (n < 0) return gpc_fail(ctx, GPC_EINVAL, "off must be non-decreasing (patch %d)", i);
+        n_max = std::max(n_max, n);
+    }
+    const size_t N = (size_t)off[P];
+    if (N > 0 && (!x0 || !x1 || !y)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/y is NULL");
+    if (perm)
+        for (int i = 0; i < P; ++i)
+            for (int k = off[i]; k < off[i + 1]; ++k)
+                if (perm[k] < 0 || perm[k] >= off[i + 1] - off[i])
+                    return gpc_fail(ctx, GPC_EINVAL, "perm[%d] = %d outside patch %d", k, perm[k], i);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    void *d_off = nullptr, *d_x0 = nullptr, *d_x1 = nullptr, *d_y = nullptr, *d_perm = nullptr, *d_st = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {d_off, d_x0, d_x1, d_y, d_perm, d_st})
+            if (p) (void)hipFree(p);
+    };
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMalloc(&d_off, 4 * (size_t)(P + 1));
+    if (e == hipSuccess) e = hipMalloc(&d_x0, 8 * std::max<size_t>(N, 1));
+    if (e == hipSuccess) e = hipMalloc(&d_x1, 8 * std::max<size_t>(N, 1));
+    if (e == hipSuccess) e = hipMalloc(&d_y, 8 * std::max<size_t>(N, 1) * g->ny);
+    if (e == hipSuccess && perm) e = hipMalloc(&d_perm, 4 * std::max<size_t>(N, 1));
+    if (e == hipSuccess) e = hipMalloc(&d_st, 4 * (size_t)P);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off, 4 * (size_t)(P + 1), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && N) e = hipMemcpyAsync(d_x0, x0, 8 * N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && N) e = hipMemcpyAsync(d_x1, x1, 8 * N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && N) e = hipMemcpyAsync(d_y, y, 8 * N * g->ny, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && N && perm) e = hipMemcpyAsync(d_perm, perm, 4 * N, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+        cleanup();
+        return gpc_fail(ctx, e == hipErrorOutOfMemory ? GPC_ENOMEM : GPC_EHIP, "gpc_sparse_add: %s", hipGetErrorString(e));
+    }
+    int rc = gpc_sparse_add_dev(g, (const int32_t*)d_off, n_max, (int)N, (const double*)d_x0, (const double*)d_x1,
+                                (const double*)d_y, (const int32_t*)d_perm, (int32_t*)d_st);
+    if (rc == GPC_OK && status) e = hipMemcpyAsync(status, d_st, 4 * (size_t)P, hipMemcpyDeviceToHost, s);
+    hipError_t e2 = hipStreamSynchronize(s);
+    cleanup();
+    if (rc != GPC_OK) return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return gpc_fail(ctx, GPC_EHIP, "gpc_sparse_add: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return GPC_OK;
+}
+
+int gpc_sparse_predict(gpc_sparse* g, int m, const double* xs0, const double* xs1, double* f_star, double* sigma,
+                       int conf, int32_t* status)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    if (m < 0) return gpc_fail(ctx, GPC_EINVAL, "negative m");
+    if (m > 0 && (!xs0 || !xs1 || !f_star)) return gpc_fail(ctx, GPC_EINVAL, "xs0/xs1/f_star is NULL");
+    const int P = g->P;
+    if (P == 0 || m == 0) return GPC_OK;
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    void *d_xs0 = nullptr, *d_xs1 = nullptr, *d_f = nullptr, *d_s = nullptr, *d_st = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {d_xs0, d_xs1, d_f, d_s, d_st})
+            if (p) (void)hipFree(p);
+    };
+    hipStream_t s = ctx->stream;
+    const size_t fbytes = 8 * (size_t)P * g->ny * m, sbytes = 8 * (size_t)P * m;
+    hipError_t e = hipMalloc(&d_xs0, 8 * (size_t)m);
+    if (e == hipSuccess) e = hipMalloc(&d_xs1, 8 * (size_t)m);
+    if (e == hipSuccess) e = hipMalloc(&d_f, fbytes);
+    if (e == hipSuccess && sigma) e = hipMalloc(&d_s, sbytes);
+    if (e == hipSuccess) e = hipMalloc(&d_st, 4 * (size_t)P);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_xs0, xs0, 8 * (size_t)m, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_xs1, xs1, 8 * (size_t)m, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+        cleanup();
+        return gpc_fail(ctx, e == hipErrorOutOfMemory ? GPC_ENOMEM : GPC_EHIP, "gpc_sparse_predict: %s", hipGetErrorString(e));
+    }
+    int rc = gpc_sparse_predict_dev(g, m, (const double*)d_xs0, (const double*)d_xs1, (double*)d_f, (double*)d_s, conf,
+                                    (int32_t*)d_st);
+    if (rc == GPC_OK) e = hipMemcpyAsync(f_star, d_f, fbytes, hipMemcpyDeviceToHost, s);
+    if (rc == GPC_OK && e == hipSuccess && sigma) e = hipMemcpyAsync(sigma, d_s, sbytes, hipMemcpyDeviceToHost, s);
+    if (rc == GPC_OK && e == hipSuccess && status) e = hipMemcpyAsync(status, d_st, 4 * (size_t)P, hipMemcpyDeviceToHost, s);
+    hipError_t e2 = hipStreamSynchronize(s);
+    cleanup();
+    if (rc != GPC_OK) return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return gpc_fail(ctx, GPC_EHIP, "gpc_sparse_predict: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return GPC_OK;
+}
+
+int gpc_sparse_sizes(gpc_sparse* g, int32_t* bv_count)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    if (!bv_count) return gpc_fail(ctx, GPC_EINVAL, "bv_count is NULL");
+    if (g->P == 0) return GPC_OK;
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    GPC_HIP(ctx, hipMemcpyAsync(bv_count, g->b, 4 * (size_t)g->P, hipMemcpyDeviceToHost, ctx->stream));
+    GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPC_OK;
+}
+
+int gpc_sparse_get_state(gpc_sparse* g, double* alpha, double* C, double* Q, double* BV)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    if (g->P == 0) return GPC_OK;
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ld = (size_t)g->ld, P = (size_t)g->P;
+    hipStream_t s = ctx->stream;
+    if (alpha) GPC_HIP(ctx, hipMemcpyAsync(alpha, g->alpha, 8 * P * g->ny * ld, hipMemcpyDeviceToHost, s));
+    if (C) GPC_HIP(ctx, hipMemcpyAsync(C, g->C, 8 * P * ld * ld, hipMemcpyDeviceToHost, s));
+    if (Q) GPC_HIP(ctx, hipMemcpyAsync(Q, g->Q, 8 * P * ld * ld, hipMemcpyDeviceToHost, s));
+    if (BV) GPC_HIP(ctx, hipMemcpyAsync(BV, g->BV, 8 * P * ld * 2, hipMemcpyDeviceToHost, s));
+    GPC_HIP(ctx, hipStreamSynchronize(s));
+    return GPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+/*
+ * gpc.h -- C-ABI of the MI355X-native per-patch Gaussian-process hot path of gp_compressor.
+ *
+ * The reference (nilsbore/gp_compressor) has no FFI: its seam is the duck-typed contract that
+ * gp_compressor uses on every element of `gps` / `RGB_gps` (src/gp_compressor.h:55-56):
+ *
+ *     add_measurements(X, y)                      src/sparse_gp.h:40, src/sparse_gp_field.h:37, src/gaussian_process.h:20
+ *     predict_measurements(f_star, X_star, sig)   src/sparse_gp.h:41-42, src/sparse_gp_field.h:38-39, src/gaussian_process.h:19
+ *     size(), reset()                             src/sparse_gp.h:36,39
+ *
+ * called once per octree-leaf patch from gp_compressor::train_processes (src/gp_compressor.cpp:121-175) and
+ * gp_compressor::load_compressed (src/gp_compressor.cpp:298-380).  A per-object call per patch would serialise
+ * the GPU, so the entry points below are the same calls BATCHED over patches: plain pointers and sizes, a ragged
+ * CSR batch, no C++ / torch types.  All paths are relative to /root/reference.
+ *
+ * Layout conventions
+ *   - patch i owns rows off[i] .. off[i+1]-1 of x0, x1, y   (off has P+1 entries, off[0] == 0)
+ *   - X is SoA: x0[N], x1[N]  == Eigen column-major n x 2 (src/gp_compressor.cpp:146-155)
+ *   - y is `ny` planes of N doubles (plane c at y + c*N): ny = 1 depth (VectorXd y), ny = 3 RGB (MatrixXd C n x 3,
+ *     column-major), which is what sparse_gp_field::add_measurements takes (src/sparse_gp_field.hpp:46-57)
+ *   - f_star is [P][ny][m]; v_star / sigma is [P][m]
+ *   - every function returns 0 or a negative errno-style code and NEVER aborts (the reference exit(0)s,
+ *     src/gp_compressor.cpp:138,215); per-patch conditions are reported in status[P]
+ *   - *_dev entry points take DEVICE pointers and enqueue on the context's HIP stream without synchronising;
+ *     the plain entry points take HOST pointers and are synchronous (H2D, launch, D2H).
+ *
+ * There is no CPU fallback: without a HIP device gpc_ctx_create() fails with GPC_ENODEV.
+ */
+#ifndef GPC_H
+#define GPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPC_VERSION 100 /* 0.1.0 */
+
+/* return codes */
+#define GPC_OK 0
+#define GPC_EINVAL (-22)  /* bad argument (NULL pointer, negative size, ny not in {1,3}, ...) */
+#define GPC_ENOMEM (-12)  /* device or host allocation failed */
+#define GPC_ENODEV (-19)  /* no HIP device / device index out of range */
+#define GPC_EHIP (-5)     /* a HIP runtime call failed; see gpc_last_error() */
+#define GPC_ERANGE (-34)  /* a size exceeds what the kernels support (n > GPC_MAX_POINTS, capacity > GPC_MAX_BV) */
+
+/* per-patch status values */
+#define GPC_STATUS_OK 0
+#define GPC_STATUS_NOT_SPD 1      /* Cholesky pivot <= 0 (Eigen::LLT would report NumericalIssue); outputs are NaN */
+#define GPC_STATUS_NAN 2          /* state became NaN ("sparse_gp::C has become Nan", src/sparse_gp.hpp:245) */
+#define GPC_STATUS_SIGMA_CLAMPED 3 /* predictive sigma^2 < 0 was clamped to 0 (src/sparse_gp.hpp:334-337) */
+#define GPC_STATUS_OVERFLOW 4     /* sparse, capacity == -1 only: basis set would exceed GPC_MAX_BV; point skipped */
+
+#define GPC_MAX_POINTS 1024 /* largest n per patch of the dense path (BASELINE config 5) */
+#define GPC_MAX_BV 256      /* largest sparse capacity (BASELINE config 4 uses 200) */
+
+/* Hyper-parameters: exactly the constants the reference hard-codes per object. */
+typedef struct gpc_params {
+    double sigmaf_sq;             /* kernel amplitude: rbf_kernel p(0) (src/rbf_kernel.h:24) / gaussian_process sigmaf^2 */
+    double l_sq;                  /* squared length scale: rbf_kernel p(1) / gaussian_process l^2 */
+    double noise;                 /* dense: sigman_sq (src/gaussian_process.h:21);  sparse: s20 (src/sparse_gp.h:48) */
+    double eps_tol;               /* sparse only: src/sparse_gp.hpp:30 (1e-6f), src/sparse_gp_field.hpp:16 (1e-4f) */
+    int32_t capacity;             /* sparse only: max basis vectors; -1 = exact GP (src/sparse_gp.hpp:155,206) */
+    int32_t noise_model;          /* 0 gaussian_noise(_3d), 1 probit_noise (ny == 1 only; never instantiated upstream) */
+    int32_t ref_double_noise;     /* dense: 1 = add sigman_sq twice like src/gaussian_process.cpp:19-22,59-61 */
+    int32_t ref_field_delete_bug; /* sparse ny==3: 1 = multiply like src/sparse_gp_field.hpp:250-253, 0 = divide */
+    int32_t want_variance;        /* dense: also compute V_star (src/gaussian_process.cpp:35-43) */
+    int32_t reserved;
+} gpc_params;
+
+/* gaussian_process(double sigmaf = 0.05, double l = 3, double sigman = 0.04), squared (src/gaussian_process.h:21, .cpp:8-9) */
+void gpc_default_params_dense(gpc_params* p);
+/* sparse_gp(capacity=100, s0=1e-1f), eps_tol 1e-6f (ny==1)  |  sparse_gp_field(capacity=100, s0=1e2f), eps_tol 1e-4f (ny==3);
+ * rbf_kernel(sigmaf_sq = 100e-0f, l_sq = 1) */
+void gpc_default_params_sparse(gpc_params* p, int ny);
+
+int gpc_version(void);
+
+/* ---- context: one per process per GPU (owns the device workspace; thread-safe per context) ---------------- */
+typedef struct gpc_ctx gpc_ctx;
+int gpc_ctx_create(gpc_ctx** out, int device);
+/* hip_stream: a hipStream_t passed as void* (NULL = the context's own stream).  Not owned. */
+int gpc_ctx_set_stream(gpc_ctx* ctx, void* hip_stream);
+int gpc_ctx_synchronize(gpc_ctx* ctx);
+void gpc_ctx_destroy(gpc_ctx* ctx);
+/* text of the last failure on this context ("" if none); valid until the next call on the context */
+const char* gpc_last_error(const gpc_ctx* ctx);
+/* name of the kernel variant the last dense call dispatched to (for tests and profiles) */
+const char* gpc_last_dense_kernel(const gpc_ctx* ctx);
+
+/* ---- dense exact GP: gaussian_process::add_measurements + predict_measurements, batched ------------------- */
+/* Replaces, per patch:  gp.add_measurements(X, y); gp.predict_measurements(f_star, X_star, V_star);
+ * (src/gaussian_process.cpp:15-45).  Computes K (+noise), its Cholesky factor, alpha, f_star = K*^T alpha and,
+ * when params->want_variance and v_star != NULL, V_star.  alpha_out (ny planes of N) may be NULL. */
+int gpc_dense_fit_predict(gpc_ctx* ctx, const gpc_params* params, int P, const int32_t* off,
+                          const double* x0, const double* x1, const double* y, int ny,
+                          int m, const double* xs0, const double* xs1,
+                          double* f_star, double* v_star, double* alpha_out, int32_t* status);
+/* Same with device pointers.  n_max >= max_i(off[i+1]-off[i]) and n_total == off[P] are passed by value because
+ * `off` lives on the device. */
+int gpc_dense_fit_predict_dev(gpc_ctx* ctx, const gpc_params* params, int P, const int32_t* off, int n_max, int n_total,
+                              const double* x0, const double* x1, const double* y, int ny,
+                              int m, const double* xs0, const double* xs1,
+                              double* f_star, double* v_star, double* alpha_out, int32_t* status);
+/* The decompression grid of gp_compressor::load_compressed is the same for every patch and separable:
+ * X*(p,0) = res*((x+.5)/sz-.5), X*(p,1) = res*((y+.5)/sz-.5), p = y*sz + x, m = sz*sz
+ * (src/gp_compressor.cpp:317-332).  These entry points build it internally and evaluate K* as an outer product
+ * of two sz x n factor tables (rounding differs from the point-wise kernel by O(1 ulp) per entry). */
+int gpc_dense_fit_predict_grid(gpc_ctx* ctx, const gpc_params* params, int P, const int32_t* off,
+                               const double* x0, const double* x1, const double* y, int ny,
+                               double res, int sz, double* f_star, double* alpha_out, int32_t* status);
+int gpc_dense_fit_predict_grid_dev(gpc_ctx* ctx, const gpc_params* params, int P, const int32_t* off, int n_max,
+                                   int n_total, const double* x0, const double* x1, const double* y, int ny,
+                                   double res, int sz, double* f_star, double* alpha_out, int32_t* status);
+
+/* ---- sparse online GP: sparse_gp<rbf_kernel, gaussian_noise> / sparse_gp_field<rbf_kernel, gaussian_noise_3d> */
+/* One handle holds the persistent state (alpha, C, Q, BV, current_size) of P independent patch GPs on the
+ * device: the batched equivalent of `std::vector<sparse_gp<...>> gps` (src/gp_compressor.h:55-56). */
+typedef struct gpc_sparse gpc_sparse;
+int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc_sparse** out);
+void gpc_sparse_destroy(gpc_sparse* g);
+/* reset(): src/sparse_gp.hpp:573-582, for all patches */
+int gpc_sparse_reset(gpc_sparse* g);
+/* add_measurements(X, y) for every patch (src/sparse_gp.hpp:59-86); may be called repeatedly (online growth,
+ * src/gp_mapping.cpp:338-339).  perm holds, per patch, the insertion order as patch-local row indices
+ * (the reference draws it from libc rand(), src/sparse_gp.hpp:43-56; here it is an explicit input, NULL = identity). */
+int gpc_sparse_add(gpc_sparse* g, const int32_t* off, const double* x0, const double* x1, const double* y,
+                   const int32_t* perm, int32_t* status);
+int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total, const double* x0, const double* x1,
+                       const double* y, const int32_t* perm, int32_t* status);
+/* predict_measurements(f_star, X_star, sigconf, conf) for every patch on one shared X_star (src/sparse_gp.hpp:299-351).
+ * sigma may be NULL (the caller in src/gp_compressor.cpp:333-334 discards it); conf selects the 0-100 confidence form. */
+int gpc_sparse_predict(gpc_sparse* g, int m, const double* xs0, const double* xs1, double* f_star, double* sigma,
+                       int conf, int32_t* status);
+int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double* xs1, double* f_star, double* sigma,
+                           int conf, int32_t* status);
+/* size() of every patch GP (src/sparse_gp.hpp:35-39) -- host pointer */
+int gpc_sparse_sizes(gpc_sparse* g, int32_t* bv_count);
+/* state read-back for tests (host pointers; each may be NULL): alpha [P][ny][cap1], C,Q [P][cap1][cap1] column-major,
+ * BV [P][cap1][2], with cap1 = gpc_sparse_ld(g) */
+int gpc_sparse_get_state(gpc_sparse* g, double* alpha, double* C, double* Q, double* BV);
+int gpc_sparse_ld(const gpc_sparse* g);
+
+/* ---- patch -> rank partition for one process per GPU (src/gp_compressor.cpp:146-163: patches are independent) ----- */
+/* Longest-processing-time assignment of P patches with per-patch cost n_i^3 (dense) or n_i*cap^2 (sparse) onto
+ * `world` ranks, every rank padded to ceil(P/world) slots so that the single all-gather of f_star is fixed-size.
+ * slot_patch has world*ceil(P/world) entries (patch id or -1 for padding), rank r owns slots [r*S, (r+1)*S). */
+int gpc_partition_patches(int P, const int32_t* off, int world, int sparse_capacity, int32_t* slot_patch);
+
+/* ---- diagnostics ------------------------------------------------------------------------------------------------ */
+/* Host-side evaluation of the table-driven exp() the kernels use for the RBF kernel (same source, csrc/gpc_device.h),
+ * so that its error against libm -- which the reference calls, src/rbf_kernel.cpp:17 -- can be bounded without a GPU. */
+void gpc_test_exp_host(const double* x, double* out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPC_H */

@@ -1,0 +1,201 @@
+"""GPU parity tests of the dense path (gaussian_process fit + predict) through the C-ABI.
+
+Oracle: oracle/gpc_oracle.c (and the NumPy/LAPACK golden fixtures).  Stated tolerance: the HIP path and the CPU
+oracle are two fp64 evaluations of the same well-conditioned system (kappa(K + 2 sn^2 I) <= 1 + n sf^2 / (2 sn^2),
+~200 at n = 256, ~800 at n = 1024) that differ in summation order, FMA contraction and exp() (<= 2 ulp):
+    |f*_gpu - f*_cpu| <= 1e-9 * max|f*|      |alpha_gpu - alpha_cpu| <= 1e-8 * max|alpha|     |V*_gpu - V*_cpu| <= 1e-11
+"""
+import os
+
+import numpy as np
+import pytest
+
+from gp_compressor_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FTOL, ATOL, VTOL = 1e-9, 1e-8, 1e-11
+
+
+@pytest.fixture(scope="module")
+def gp():
+    from gp_compressor_amd import capi
+    capi.load()          # raises if the HIP library is missing: no fallback
+    ctx = capi.Context(0)
+    yield capi, ctx
+    ctx.close()
+
+
+def _close(f, want, tol):
+    scale = max(float(np.max(np.abs(want))), 1e-300)
+    err = float(np.max(np.abs(f - want)))
+    assert err <= tol * scale, (err, scale)
+
+
+def _dense_case(name):
+    z = np.load(os.path.join(GOLD, "dense_cases.npz"))
+    return {k.split(".", 1)[1]: z[k] for k in z.files if k.startswith(name + ".")}
+
+
+@pytest.mark.parametrize("name", ["tiny", "c1", "rgb", "n256"])
+def test_dense_golden(gp, name):
+    capi, ctx = gp
+    d = _dense_case(name)
+    p = capi.default_params_dense(want_variance=1)
+    f, v, st, al = ctx.dense_fit_predict(p, d["off"], d["x0"], d["x1"], d["y"], d["xs0"], d["xs1"], want_alpha=True)
+    assert np.all(st == 0)
+    _close(f, d["f_star"], FTOL)
+    _close(al, d["alpha"], ATOL)
+    assert np.max(np.abs(v - d["v_star"])) <= VTOL
+
+
+@pytest.mark.parametrize("P,n,ny,ragged,seed", [(37, 64, 1, True, 1), (9, 200, 3, True, 2), (5, 256, 1, False, 3),
+                                                (3, 300, 1, True, 4), (2, 515, 3, True, 5), (40, 17, 1, True, 6)])
+def test_dense_vs_oracle(gp, oracle, P, n, ny, ragged, seed):
+    capi, ctx = gp
+    off, x0, x1, y = synth.make_patches(P, n, seed=seed, ragged=ragged, ny=ny)
+    xs0, xs1 = synth.grid(0.15, 12)
+    for dbl in (1, 0):
+        p = capi.default_params_dense(want_variance=1, ref_double_noise=dbl)
+        f, v, st, al = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
+        fo, vo, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(ref_double_noise=dbl), off, x0, x1, y, xs0, xs1,
+                                                        variance=True, want_alpha=True)
+        assert np.array_equal(st, so)
+        _close(f, fo, FTOL)
+        _close(al, ao, ATOL)
+        assert np.max(np.abs(v - vo)) <= VTOL
+
+
+def test_dense_other_hyperparameters(gp, oracle):
+    capi, ctx = gp
+    off, x0, x1, y = synth.make_patches(6, 90, seed=12, ragged=True)
+    xs0, xs1 = synth.grid(0.15, 9)
+    kw = dict(sigmaf_sq=1.0, l_sq=0.05 ** 2, noise=1e-3)
+    p = capi.default_params_dense(want_variance=1, **kw)
+    f, v, st = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1)
+    fo, vo, so = oracle.dense_fit_predict_batch(oracle.dense_params(kw["sigmaf_sq"], kw["l_sq"], kw["noise"]), off, x0, x1, y,
+                                                xs0, xs1, variance=True)
+    assert np.all(st == 0)
+    _close(f, fo, 1e-8)           # kappa ~ 1 + n/(2e-3) ~ 5e4 here
+    assert np.max(np.abs(v - vo)) <= 1e-9
+
+
+def test_dense_edge_cases(gp, oracle):
+    capi, ctx = gp
+    xs0, xs1 = synth.grid(0.15, 5)
+    p = capi.default_params_dense(want_variance=1)
+    # P == 0
+    f, v, st = ctx.dense_fit_predict(p, np.zeros(1, np.int32), np.zeros(0), np.zeros(0), np.zeros((1, 0)), xs0, xs1)
+    assert f.shape == (0, 1, 25)
+    # empty patches (n == 0) between real ones, and a single-point patch
+    off = np.array([0, 0, 1, 1, 8, 8], dtype=np.int32)
+    rng = np.random.default_rng(0)
+    x0, x1 = rng.uniform(-0.07, 0.07, 8), rng.uniform(-0.07, 0.07, 8)
+    y = rng.normal(0, 0.01, (1, 8))
+    f, v, st = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1)
+    fo, vo, so = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, variance=True)
+    assert np.array_equal(st, so) and np.all(st == 0)
+    assert np.all(f[[0, 2, 4]] == 0) and np.all(v[[0, 2, 4]] == 0.0025)   # prior mean / prior variance
+    _close(f, fo, FTOL)
+    assert np.max(np.abs(v - vo)) <= VTOL
+    # not SPD: duplicated point, zero noise -> status 1, NaN outputs (the oracle does the same)
+    p0 = capi.default_params_dense(noise=0.0)
+    off = np.array([0, 3, 6], dtype=np.int32)
+    x0 = np.array([0.01, 0.01, 0.02, 0.0, 0.03, -0.02])
+    x1 = np.array([0.0, 0.0, 0.03, 0.01, -0.01, 0.02])
+    y = np.array([[1.0, 2.0, 3.0, 0.1, 0.2, 0.3]])
+    f, v, st, al = ctx.dense_fit_predict(p0, off, x0, x1, y, xs0, xs1, want_alpha=True)
+    fo, vo, so = oracle.dense_fit_predict_batch(oracle.dense_params(sigman_sq=0.0), off, x0, x1, y, xs0, xs1)
+    assert st.tolist() == so.tolist() == [1, 0]
+    assert np.all(np.isnan(f[0])) and np.all(np.isnan(al[0, :3])) and np.all(np.isfinite(f[1]))
+
+
+def test_dense_argument_errors(gp):
+    capi, ctx = gp
+    xs0, xs1 = synth.grid(0.15, 4)
+    off, x0, x1, y = synth.make_patches(2, 8, seed=1)
+    p = capi.default_params_dense()
+    with pytest.raises(capi.GpcError) as e:
+        ctx.dense_fit_predict(p, off, x0, x1, np.concatenate([y, y]), xs0, xs1)      # ny == 2
+    assert e.value.code == capi.GPC_EINVAL
+    with pytest.raises(capi.GpcError) as e:
+        ctx.dense_fit_predict(p, np.array([0, 5, 3], np.int32), x0, x1, y, xs0, xs1)  # decreasing offsets
+    assert e.value.code == capi.GPC_EINVAL
+    big = synth.make_patches(1, 1100, seed=1)
+    with pytest.raises(capi.GpcError) as e:
+        ctx.dense_fit_predict(p, big[0], big[1], big[2], big[3], xs0, xs1)
+    assert e.value.code == capi.GPC_ERANGE
+    with pytest.raises(capi.GpcError) as e:
+        ctx.dense_fit_predict(capi.default_params_dense(l_sq=0.0), off, x0, x1, y, xs0, xs1)
+    assert e.value.code == capi.GPC_EINVAL
+
+
+@pytest.mark.parametrize("n,ny", [(100, 1), (256, 1), (256, 3), (300, 1)])
+def test_dense_grid_entry_matches_pointwise(gp, oracle, n, ny):
+    """gpc_dense_fit_predict_grid builds the grid of gp_compressor.cpp:317-332 itself; results equal the point-wise entry."""
+    capi, ctx = gp
+    off, x0, x1, y = synth.make_patches(7, n, seed=21, ragged=True, ny=ny)
+    res, sz = 0.15, 20
+    xs0, xs1 = oracle.grid(res, sz)
+    p = capi.default_params_dense()
+    f1, _, st1 = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1)
+    f2, st2 = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz)
+    fo, _, so = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1)
+    assert np.array_equal(st1, st2) and np.all(st1 == 0)
+    _close(f2, f1, 1e-11)
+    _close(f2, fo, FTOL)
+
+
+def test_dense_device_pointers_on_torch_stream(gp, oracle):
+    import torch
+    capi, ctx = gp
+    dev = torch.device("cuda:0")
+    off, x0, x1, y = synth.make_patches(33, 128, seed=8, ragged=True)
+    xs0, xs1 = synth.grid(0.15, 20)
+    P, N, m = 33, int(off[-1]), 400
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_off, d_x0, d_x1, d_y, d_xs0, d_xs1 = t(off), t(x0), t(x1), t(y), t(xs0), t(xs1)
+    f = torch.full((P, 1, m), float("nan"), dtype=torch.float64, device=dev)
+    st = torch.full((P,), -1, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ctx.set_stream(side.cuda_stream)
+        ctx.dense_fit_predict_dev(capi.default_params_dense(), P, d_off, 128, N, d_x0, d_x1, d_y, 1, m, d_xs0, d_xs1, f,
+                                  status=st)
+    side.synchronize()
+    ctx.set_stream(None)
+    fo, _, so = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1)
+    assert np.all(st.cpu().numpy() == 0)
+    _close(f.cpu().numpy(), fo, FTOL)
+
+
+def test_dense_full_size_c2_properties(gp, oracle):
+    """BASELINE config 2 (8192 patches x 256 points, m = 400) at full size: size-independent properties
+    (linearity in y, interpolation residual through alpha) plus the oracle on a random sample of patches."""
+    capi, ctx = gp
+    P, n, res, sz = 8192, 256, 0.15, 20
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=2)
+    rng = np.random.default_rng(99)
+    y2 = rng.normal(0, 0.01, size=y.shape)
+    p = capi.default_params_dense()
+    fa, sta, ala = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz, want_alpha=True)
+    fb, stb = ctx.dense_fit_predict_grid(p, off, x0, x1, y2, res, sz)
+    fc, stc = ctx.dense_fit_predict_grid(p, off, x0, x1, y + 2.0 * y2, res, sz)
+    assert np.all(sta == 0) and np.all(stb == 0) and np.all(stc == 0)
+    assert np.all(np.isfinite(fa))
+    # linearity of the posterior mean in the targets
+    _close(fc, fa + 2.0 * fb, 1e-10)
+    # (K + 2 sn^2 I) alpha = y, checked per patch with an independent NumPy Gram matrix on a sample
+    xs0, xs1 = oracle.grid(res, sz)
+    sample = rng.choice(P, size=24, replace=False)
+    for i in sample:
+        sl = slice(off[i], off[i + 1])
+        X = np.stack([x0[sl], x1[sl]], 1)
+        d = X[:, None, :] - X[None, :, :]
+        K = 0.0025 * np.exp(-0.5 / 9.0 * (d[..., 0] ** 2 + d[..., 1] ** 2)) + 2 * 0.0016 * np.eye(n)
+        assert np.max(np.abs(K @ ala[0, sl] - y[0, sl])) <= 1e-12 * max(1.0, np.max(np.abs(ala[0, sl])))
+    sub_off = np.concatenate([[0], np.cumsum([n] * len(sample))]).astype(np.int32)
+    idx = np.concatenate([np.arange(off[i], off[i + 1]) for i in sample])
+    fo, _, so = oracle.dense_fit_predict_batch(oracle.dense_params(), sub_off, x0[idx], x1[idx], y[:, idx], xs0, xs1)
+    _close(fa[sample], fo, FTOL)
