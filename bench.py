@@ -35,6 +35,19 @@ def algorithmic_flops(n, m):
     return 3.5 * n * n + n ** 3 / 3.0 + 2.0 * n * n + 9.0 * n * m
 
 
+def host_cores():
+    """Threads to use for the CPU baseline: the cgroup CPU quota if there is one (a 1-GPU box gets a 16-CPU share of
+    the host), else the affinity mask, capped at 64."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("GPC_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(off, x0, x1, y, res, sz, f_gpu, budget_s=12.0):
     """Times the CPU oracle (oracle/gpc_oracle.c, -O3 -march=native build; kind "port": the reference's own Eigen code
     cannot be built here) on a bounded sample of the same workload, one thread per host core, and returns
@@ -58,7 +71,7 @@ def cpu_baseline(off, x0, x1, y, res, sz, f_gpu, budget_s=12.0):
     t0 = time.perf_counter()
     run(0, 4)
     per_patch = (time.perf_counter() - t0) / 4
-    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+    cores = host_cores()
     per_thread = max(2, min(P // cores, int(budget_s / per_patch)))
     chunks = [(i * per_thread, (i + 1) * per_thread) for i in range(cores)]
     t0 = time.perf_counter()

@@ -141,8 +141,9 @@ class Context:
             raise GpcError(rc, self.lib.gpc_last_error(self.h).decode())
 
     def set_stream(self, stream):
-        """stream: raw hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream) or None for the own stream."""
-        self._check(self.lib.gpc_ctx_set_stream(self.h, stream))
+        """stream: raw hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream; 0 is HIP's default stream),
+        or None for the context's own non-blocking stream (GPC_STREAM_OWN)."""
+        self._check(self.lib.gpc_ctx_set_stream(self.h, C.c_void_p(-1) if stream is None else C.c_void_p(int(stream))))
 
     def synchronize(self):
         self._check(self.lib.gpc_ctx_synchronize(self.h))

@@ -104,7 +104,7 @@ int gpc_ctx_set_stream(gpc_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return GPC_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = (hip_stream == GPC_STREAM_OWN) ? ctx->own_stream : static_cast<hipStream_t>(hip_stream);
     return GPC_OK;
 }
 

@@ -80,7 +80,9 @@ int gpc_version(void);
 /* ---- context: one per process per GPU (owns the device workspace; thread-safe per context) ---------------- */
 typedef struct gpc_ctx gpc_ctx;
 int gpc_ctx_create(gpc_ctx** out, int device);
-/* hip_stream: a hipStream_t passed as void* (NULL = the context's own stream).  Not owned. */
+/* hip_stream: a hipStream_t passed as void*, used as is (NULL is HIP's default stream); GPC_STREAM_OWN selects the
+ * non-blocking stream the context created for itself (the initial setting).  Not owned. */
+#define GPC_STREAM_OWN ((void*)(intptr_t)-1)
 int gpc_ctx_set_stream(gpc_ctx* ctx, void* hip_stream);
 int gpc_ctx_synchronize(gpc_ctx* ctx);
 void gpc_ctx_destroy(gpc_ctx* ctx);

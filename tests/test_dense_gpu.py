@@ -96,7 +96,7 @@ def test_dense_edge_cases(gp, oracle):
     f, v, st = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1)
     fo, vo, so = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, variance=True)
     assert np.array_equal(st, so) and np.all(st == 0)
-    assert np.all(f[[0, 2, 4]] == 0) and np.all(v[[0, 2, 4]] == 0.0025)   # prior mean / prior variance
+    assert np.all(f[[0, 2, 4]] == 0) and np.all(v[[0, 2, 4]] == p.sigmaf_sq)   # prior mean / prior variance
     _close(f, fo, FTOL)
     assert np.max(np.abs(v - vo)) <= VTOL
     # not SPD: duplicated point, zero noise -> status 1, NaN outputs (the oracle does the same)

@@ -75,6 +75,7 @@ static double time_ms(F f, int reps = 5)
 
 int main()
 {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s, CUs %d, clock %d kHz, LDS/block %zu, regs/block %d, L2 %d\n", prop.name, prop.multiProcessorCount,
            prop.clockRate, prop.sharedMemPerBlock, prop.regsPerBlock, prop.l2CacheSize);
@@ -96,7 +97,7 @@ int main()
     }
     // ---- rates
     const int blocks = prop.multiProcessorCount * 2, iters = 20000;
-    double* out; CK(hipMalloc(&out, (size_t)blocks * 256 * 8));
+    double* out; CK(hipMalloc(&out, (size_t)blocks * 2 * 256 * 8));   // largest launch below is blocks*2
     {
         double ms = time_ms([&] { hipLaunchKernelGGL(mfma_rate_kernel<4>, dim3(blocks), dim3(256), 0, 0, out, iters); });
         double fl = (double)blocks * 4 * iters * 4 * 2048.0;
