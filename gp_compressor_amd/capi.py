@@ -73,6 +73,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Whichever copy is mapped first
+        # serves the whole process, and torch refuses to see the GPU when the system copy won: load torch's first.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise GpcError(GPC_ENODEV, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                    "(hipcc --offload-arch=gfx950); there is no CPU fallback")

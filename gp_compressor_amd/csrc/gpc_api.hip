@@ -1,6 +1,7 @@
 // gpc_api.hip -- C-ABI entry points of libgpc_hip.so: context, parameter defaults, dense-path dispatch,
 // patch->rank partition.  See include/gpc.h for the contract and the reference call sites each one replaces.
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -154,6 +155,7 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
     std::lock_guard<std::mutex> lk(ctx->mu);
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     if (!a.prm.want_variance) a.v_star = nullptr;
+    if (dense_mfma_supported(a) && !getenv("GPC_FORCE_GENERIC")) return dense_mfma_launch(ctx, a);
     int grid = 0;
     size_t bytes = dense_generic_ws_bytes(ctx, a, &grid);
     int rc = gpc_ws_reserve(ctx, bytes);

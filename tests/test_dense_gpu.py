@@ -50,9 +50,21 @@ def test_dense_golden(gp, name):
     assert np.max(np.abs(v - d["v_star"])) <= VTOL
 
 
+@pytest.fixture(params=["dispatch", "generic"])
+def kernel_choice(request, monkeypatch):
+    """Run a test once with the normal dispatch (register-tile MFMA kernel for n <= 256) and once with the generic
+    global-workspace kernel forced (GPC_FORCE_GENERIC is read at every call)."""
+    if request.param == "generic":
+        monkeypatch.setenv("GPC_FORCE_GENERIC", "1")
+    else:
+        monkeypatch.delenv("GPC_FORCE_GENERIC", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("P,n,ny,ragged,seed", [(37, 64, 1, True, 1), (9, 200, 3, True, 2), (5, 256, 1, False, 3),
-                                                (3, 300, 1, True, 4), (2, 515, 3, True, 5), (40, 17, 1, True, 6)])
-def test_dense_vs_oracle(gp, oracle, P, n, ny, ragged, seed):
+                                                (3, 300, 1, True, 4), (2, 515, 3, True, 5), (40, 17, 1, True, 6),
+                                                (11, 128, 1, True, 7), (6, 192, 1, True, 8), (300, 256, 1, True, 9)])
+def test_dense_vs_oracle(gp, oracle, kernel_choice, P, n, ny, ragged, seed):
     capi, ctx = gp
     off, x0, x1, y = synth.make_patches(P, n, seed=seed, ragged=ragged, ny=ny)
     xs0, xs1 = synth.grid(0.15, 12)
@@ -65,6 +77,15 @@ def test_dense_vs_oracle(gp, oracle, P, n, ny, ragged, seed):
         _close(f, fo, FTOL)
         _close(al, ao, ATOL)
         assert np.max(np.abs(v - vo)) <= VTOL
+    # mean-only call: this is what dispatches to the register-tile kernel when n <= 256
+    p = capi.default_params_dense()
+    f, _, st, al = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
+    fo, _, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, want_alpha=True)
+    want_kernel = "dense_generic" if (kernel_choice == "generic" or n > 256) else "dense_mfma"
+    assert ctx.last_dense_kernel().startswith(want_kernel), ctx.last_dense_kernel()
+    assert np.array_equal(st, so)
+    _close(f, fo, FTOL)
+    _close(al, ao, ATOL)
 
 
 def test_dense_other_hyperparameters(gp, oracle):

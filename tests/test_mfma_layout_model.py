@@ -1,0 +1,230 @@
+"""CPU model of the index algebra of csrc/dense_mfma.hip (-m "not gpu").
+
+The register-tile kernel never materialises K in memory: tiles live in the v_mfma_f64_16x16x4_f64 accumulator layout,
+stored transposed, and move between roles (accumulator -> B operand -> LDS operand image) without any cross-lane
+shuffle.  That only works if a handful of lane maps line up; this test replays the kernel's data flow lane by lane in
+NumPy -- with the MFMA lane maps measured by tools/probe_mfma_f64.hip on MI355X -- and checks the result against a
+plain Cholesky solve.  It is the host-side proof that the kernel's formulas compute (K + 2 sn^2 I)^-1 y and K*^T alpha.
+
+Lane maps (lane l, 64 lanes):  A operand: A[l & 15][l >> 4]   B operand: B[l >> 4][l & 15]
+                               C/D register r: D[(l >> 4) + 4 r][l & 15]
+"""
+import numpy as np
+
+import np_restatement as R
+from gp_compressor_amd import synth
+
+L = np.arange(64)
+LR, LG = L & 15, L >> 4
+
+
+def mfma(a, b, c, neg_a=False):
+    """v_mfma_f64_16x16x4_f64: a, b (64,), c (64, 4) -> d (64, 4)."""
+    A = np.zeros((16, 4))
+    B = np.zeros((4, 16))
+    A[LR, LG] = a
+    B[LG, LR] = b
+    P = A @ B
+    if neg_a:
+        P = -P
+    d = c.copy()
+    for r in range(4):
+        d[:, r] += P[LG + 4 * r, LR]
+    return d
+
+
+def tiles_of_wave(NT, wave, waves=8):
+    """column-major enumeration of the lower triangle dealt round-robin (the tij[] table of the kernel)."""
+    out = []
+    ntiles = NT * (NT + 1) // 2
+    for t in range((ntiles + waves - 1) // waves):
+        idx = t * waves + wave
+        if idx >= ntiles:
+            continue
+        jj = 0
+        for j in range(1, NT):
+            if idx >= j * NT - (j * (j - 1)) // 2:
+                jj = j
+        ii = jj + idx - (jj * NT - (jj * (jj - 1)) // 2)
+        out.append((ii, jj))
+    return out
+
+
+def test_tile_enumeration_covers_lower_triangle_once():
+    for NT in (4, 8, 12, 16):
+        seen = [tl for w in range(8) for tl in tiles_of_wave(NT, w)]
+        assert sorted(seen) == sorted((i, j) for j in range(NT) for i in range(j, NT))
+        # per step k the active tiles (j > k) are spread within +-1 over the waves... of column-major suffixes
+        for k in range(NT - 1):
+            cnt = [sum(1 for (i, j) in tiles_of_wave(NT, w) if j > k) for w in range(8)]
+            assert max(cnt) - min(cnt) <= 1
+
+
+def diag_factor(S):
+    """mf_diag_factor: forward elimination on [A | I] -> [L^T | L^-1], lane = column; returns the operand image."""
+    reg = np.zeros((16, 32))            # reg[i][lane]
+    for lane in range(32):
+        j = lane & 15
+        reg[:, lane] = (np.arange(16) == j) if lane & 16 else S[np.arange(16) * 17 + j]
+    ok = True
+    for c in range(16):
+        d = reg[c, c]
+        ok = ok and d > 0
+        rs = 1.0 / np.sqrt(d)
+        reg[c, :] *= rs
+        for i in range(c + 1, 16):
+            mlt = reg[i, c] * rs
+            reg[i, :] -= mlt * reg[c, :]
+    out = np.zeros(256)
+    for j in range(16):
+        for i in range(16):
+            out[(i + 16 * (j & 3)) * 4 + (j >> 2)] = reg[i, 16 + j]
+    return out, ok
+
+
+def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
+    sf, lsq, sn = 0.0025, 9.0, 0.0016
+    cexp = -0.5 / lsq
+    off, x0, x1, y = synth.make_patches(1, n, seed=seed, ny=ny)
+    NT = NT or (n + 15) // 16
+    npad = 16 * NT
+    nt = (n + 15) // 16
+    px0 = np.zeros(npad); px1 = np.zeros(npad)
+    px0[:n], px1[:n] = x0, x1
+    yc = np.zeros((ny, npad)); yc[:, :n] = y
+    zv = np.zeros((ny, npad)); wv = np.zeros((ny, npad)); av = np.zeros((ny, npad))
+    # Gram tiles (transposed storage)
+    acc = {}
+    for j in range(NT):
+        for i in range(j, NT):
+            if i >= nt:
+                continue
+            a = np.zeros((64, 4))
+            pi = 16 * i + LR
+            for r in range(4):
+                pj = 16 * j + LG + 4 * r
+                d0, d1 = px0[pi] - px0[pj], px1[pi] - px1[pj]
+                v = sf * np.exp(cexp * (d0 * d0 + d1 * d1))
+                v = np.where(pi == pj, v + sn + sn, v)
+                v = np.where((pi >= n) | (pj >= n), (pi == pj).astype(float), v)
+                a[:, r] = v
+            acc[(i, j)] = a
+    Linv = np.zeros((NT, 256))
+    pan = np.zeros((NT, 256))
+    DS = np.zeros(16 * 17)
+    for k in range(-1, nt):
+        if k >= 0:
+            lv = Linv[k].reshape(64, 4)
+            zq = np.zeros((ny, 64, 4))
+            for c in range(ny):
+                part = sum(lv[:, s] * yc[c, 16 * k + LG + 4 * s] for s in range(4))
+                zk = np.array([part[(L & 15) == (l & 15)].sum() for l in L])     # sum over lane groups
+                zv[c, 16 * k + LR[:16]] = zk[:16]
+                for s in range(4):
+                    zq[c, :, s] = zk[LG + 4 * s]
+            for i in range(k + 1, nt):
+                D = np.zeros((64, 4))
+                for s in range(4):
+                    D = mfma(lv[:, s], acc[(i, k)][:, s], D)
+                acc[(i, k)] = D
+                pan[i] = D.reshape(256)
+                for c in range(ny):
+                    part = sum(D[:, s] * zq[c, :, s] for s in range(4))
+                    tot = np.array([part[(L & 15) == r].sum() for r in range(16)])
+                    yc[c, 16 * i + np.arange(16)] -= tot
+        if k + 1 < nt:
+            a_ = acc[(k + 1, k + 1)]
+            if k >= 0:
+                p = pan[k + 1].reshape(64, 4)
+                for s in range(4):
+                    a_ = mfma(p[:, s], p[:, s], a_, neg_a=True)
+                acc[(k + 1, k + 1)] = a_
+            for r in range(4):
+                DS[(LG + 4 * r) * 17 + LR] = a_[:, r]
+            Linv[k + 1], ok = diag_factor(DS)
+            assert ok
+        if k >= 0:
+            for j in range(k + 1, nt):
+                for i in range(j, nt):
+                    if (i, j) == (k + 1, k + 1):
+                        continue
+                    a = pan[j].reshape(64, 4)
+                    b = pan[i].reshape(64, 4)
+                    t = acc[(i, j)]
+                    for s in range(4):
+                        t = mfma(a[:, s], b[:, s], t, neg_a=True)
+                    acc[(i, j)] = t
+    # backward solve
+    for k in range(nt - 1, -1, -1):
+        lv = Linv[k].reshape(64, 4)
+        for c in range(ny):
+            u = zv[c, 16 * k + LR] - wv[c, 16 * k + LR]
+            for s in range(4):
+                prod = lv[:, s] * u
+                for g in range(4):
+                    av[c, 16 * k + g + 4 * s] = prod[LG == g].sum()
+        for j in range(k):
+            t = acc[(k, j)]
+            for c in range(ny):
+                ar = av[c, 16 * k + LR]
+                for s in range(4):
+                    prod = t[:, s] * ar
+                    for g in range(4):
+                        wv[c, 16 * j + g + 4 * s] += prod[LG == g].sum()
+    # separable predictive mean on the sz x sz grid, wave w takes points [32 w, 32 w + 32)
+    f = np.zeros((ny, sz * sz))
+    for c in range(ny):
+        red = np.zeros((8, 4, 64, 4))
+        for w in range(8):
+            ibase = 32 * w
+            if ibase >= n:
+                continue
+            P = [[np.zeros((64, 4)) for _ in range(2)] for _ in range(2)]
+            for s in range(8):
+                i = ibase + 4 * s + LG
+                al = sf * av[c, np.minimum(i, npad - 1)]
+                ea, eb = [], []
+                for h in range(2):
+                    pq = 16 * h + LR
+                    gq = res * ((pq + 0.5) / sz - 0.5)
+                    on = (pq < sz) & (i < n)
+                    ii = np.minimum(i, npad - 1)
+                    ea.append(np.where(on, np.exp(cexp * (gq - px1[ii]) ** 2), 0.0))
+                    eb.append(np.where(on, np.exp(cexp * (gq - px0[ii]) ** 2), 0.0))
+                for nl in range(2):
+                    bop = eb[nl] * al
+                    for mt in range(2):
+                        P[mt][nl] = mfma(ea[mt], bop, P[mt][nl])
+            for mt in range(2):
+                for nl in range(2):
+                    red[w, mt * 2 + nl] = P[mt][nl]
+        for oo in range(1024):
+            tile, e = oo >> 8, oo & 255
+            l2, r = e >> 2, e & 3
+            py, pxx = 16 * (tile >> 1) + (l2 >> 4) + 4 * r, 16 * (tile & 1) + (l2 & 15)
+            if py < sz and pxx < sz:
+                f[c, py * sz + pxx] = red[:, tile, l2, r].sum()
+    return (x0, x1, y), av[:, :n], f, acc, nt
+
+
+def _reference(x0, x1, y, sz=20, res=0.15):
+    X = np.stack([x0, x1], 1)
+    Lc, alpha = R.dense_fit(X, y)
+    xs0, xs1 = R.grid(res, sz)
+    f, _ = R.dense_predict(X, Lc, alpha, np.stack([xs0, xs1], 1))
+    return Lc, alpha, f
+
+
+def test_register_tile_data_flow_matches_cholesky_solve():
+    for n, ny, seed, NT in ((64, 1, 1, 4), (100, 3, 2, 8), (37, 1, 3, 4), (256, 1, 4, 16), (129, 1, 5, 12)):
+        (x0, x1, y), alpha, f, acc, nt = run_model(n, ny, seed, NT=NT)
+        Lc, want_alpha, want_f = _reference(x0, x1, y)
+        assert np.max(np.abs(alpha - want_alpha)) <= 1e-9 * np.max(np.abs(want_alpha))
+        assert np.max(np.abs(f - want_f)) <= 1e-10 * np.max(np.abs(want_f))
+        # the finished panel tile (i, k) is the operand image of L_ik: register r of lane l = L[16 i + (l&15)][16 k + (l>>4) + 4 r]
+        Lp = np.eye(16 * nt)
+        Lp[:n, :n] = Lc
+        for (i, k), t in acc.items():
+            if i > k:
+                for r in range(4):
+                    assert np.allclose(t[:, r], Lp[16 * i + LR, 16 * k + LG + 4 * r], rtol=0, atol=1e-13)
