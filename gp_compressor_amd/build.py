@@ -25,8 +25,17 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source for gfx950 into gp_compressor_amd/libgpc_hip.so (cross-compiles without a GPU)."""
+def build(force=False, verbose=False, extra_flags=(), lib=None):
+    """Compile every HIP source for gfx950 into gp_compressor_amd/libgpc_hip.so (cross-compiles without a GPU).
+    `lib` + `extra_flags` build a diagnostic variant next to it (e.g. -DMF_STAMPS -> libgpc_hip_stamps.so)."""
+    global LIB
+    if lib is not None:
+        saved = LIB
+        LIB = lib
+        try:
+            return build(force=True, verbose=verbose, extra_flags=extra_flags)
+        finally:
+            LIB = saved
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -34,7 +43,7 @@ def build(force=False, verbose=False, extra_flags=()):
         raise RuntimeError("hipcc not found: cannot build libgpc_hip.so (and there is no CPU fallback)")
     objs = []
     for src in sources():
-        obj = os.path.splitext(src)[0] + ".o"
+        obj = os.path.splitext(src)[0] + (".o" if not extra_flags else ".diag.o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-c", src, "-o", obj, *extra_flags]
         if verbose:

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgpc_hip.so")
+LIB_PATH = os.environ.get("GPC_LIB_PATH", os.path.join(HERE, "libgpc_hip.so"))   # override: diagnostic builds only
 
 GPC_OK, GPC_EINVAL, GPC_ENOMEM, GPC_ENODEV, GPC_EHIP, GPC_ERANGE = 0, -22, -12, -19, -5, -34
 STATUS_OK, STATUS_NOT_SPD, STATUS_NAN, STATUS_SIGMA_CLAMPED = 0, 1, 2, 3

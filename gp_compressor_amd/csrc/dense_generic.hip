@@ -23,6 +23,7 @@
 struct GenParams {
     DenseArgs a;
     double c_exp;      // (double)(-0.5f) / l_sq
+    double pivot_tol;  // GPC_PIVOT_RTOL * (sigmaf_sq + noise)
     double* ws;        // workspace base
     size_t slot;       // doubles per workgroup slot
     int ld;            // leading dimension of the K/L slot (>= n_max + ny)
@@ -31,14 +32,14 @@ struct GenParams {
 
 // In-register Cholesky of a w x w diagonal block held one row per lane (lanes 0..w-1 of wave 0, a[jj] = row
 // entries).  All 64 lanes of the wave execute it (shuffles).  Returns false in every lane if a pivot is <= 0.
-__device__ static inline bool diag_chol_wave(double (&a)[GEN_NB], int w, int lane)
+__device__ static inline bool diag_chol_wave(double (&a)[GEN_NB], int w, int lane, double pivot_tol)
 {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < GEN_NB; ++j) {
         if (j < w) {
             double dj = __shfl(a[j], j, 64);
-            if (!(dj > 0.0)) ok = false;
+            if (!(dj > pivot_tol)) ok = false;
             double piv = sqrt(dj);
             double lij = a[j] / piv;                 // lane i: L[i][j] (valid for i >= j)
             if (lane == j) lij = piv;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(GEN_THREADS) void dense_generic_kernel(GenParams g)
                 if (rbase == c0) {
                     // rows c0..c0+w-1 are lanes 0..w-1 of wave 0: factor the diagonal block in registers
                     if (wave == 0) {
-                        bool ok = diag_chol_wave(acc, w, lane);
+                        bool ok = diag_chol_wave(acc, w, lane, g.pivot_tol);
                         if (!ok && lane == 0) *flag = 1;
                         if (lane < w) {
 #pragma unroll
@@ -359,6 +360,7 @@ int dense_generic_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
     GenParams g;
     g.a = a;
     g.c_exp = (double)(-0.5f) / a.prm.l_sq;
+    g.pivot_tol = GPC_PIVOT_RTOL * (a.prm.sigmaf_sq + a.prm.noise);
     g.ws = static_cast<double*>(ctx->ws);
     g.ld = a.n_max + a.ny;
     g.mpad = (a.m + 63) & ~63;

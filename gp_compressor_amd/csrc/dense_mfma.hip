@@ -21,6 +21,8 @@
 //
 // Lane maps (verified by tools/probe_mfma_f64.hip): A operand lane l = A[l&15][l>>4], B operand lane l =
 // B[l>>4][l&15], C/D register r of lane l = D[(l>>4) + 4r][l&15].
+#include <vector>
+
 #include "gpc_device.h"
 #include "gpc_internal.h"
 
@@ -34,7 +36,34 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 struct MfmaParams {
     DenseArgs a;
     double c_exp;
+    double pivot_tol;               // a pivot <= pivot_tol is reported as GPC_STATUS_NOT_SPD
+    unsigned long long* stamps;     // diagnostic build (-DMF_STAMPS) only: [block][wave][MF_NPH] cycle sums
 };
+
+// Diagnostic phase timing (cdna_hip_programming.md section 7, "In-kernel stamps"): compiled in only with -DMF_STAMPS
+// (tools/stamp_mfma.py builds a separate library); the shipped kernel executes no stamp.
+#define MF_NPH 12
+#ifdef MF_STAMPS
+#define MF_STAMP_DECL unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); unsigned long long t_acc_[MF_NPH] = {};
+#define MF_STAMP(ph)                                              \
+    do {                                                          \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                       \
+        t_acc_[ph] += t_now_ - t_prev_;                           \
+        t_prev_ = t_now_;                                         \
+        __builtin_amdgcn_sched_barrier(0);                        \
+    } while (0)
+#define MF_STAMP_FLUSH()                                                                                         \
+    do {                                                                                                         \
+        if (g.stamps && lane == 0)                                                                               \
+            for (int q_ = 0; q_ < MF_NPH; ++q_) g.stamps[((size_t)blockIdx.x * MF_WAVES + wave) * MF_NPH + q_] = t_acc_[q_]; \
+    } while (0)
+#else
+#define MF_STAMP_DECL
+#define MF_STAMP(ph) do { } while (0)
+#define MF_STAMP_FLUSH() do { } while (0)
+#endif
 
 // ---- LDS carve (doubles) ----------------------------------------------------------------------------------
 #define L_EXP 0                          // 64    exp table
@@ -83,7 +112,7 @@ __device__ static inline double mf_rsqrt(double d)
 // Inverse Cholesky factor of the 16 x 16 SPD tile in S (row stride 17): forward elimination on [A | I] gives
 // [L^T | L^-1].  One wave; lane j < 16 holds column j of A, lane 16 + j column j of I (lanes 32..63 mirror them).
 // Writes L^-1 in operand layout (element (r, c) at (r + 16 (c & 3)) * 4 + (c >> 2)) and raises *flag on a pivot <= 0.
-__device__ __forceinline__ static void mf_diag_factor(const double* S, double* Linv_out, int* flag)
+__device__ __forceinline__ static void mf_diag_factor(const double* S, double* Linv_out, int* flag, double pivot_tol)
 {
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
@@ -95,7 +124,7 @@ __device__ __forceinline__ static void mf_diag_factor(const double* S, double* L
 #pragma unroll
     for (int c = 0; c < MF_TS; ++c) {
         const double d = mf_readlane(reg[c], c);
-        ok = ok && (d > 0.0);
+        ok = ok && (d > pivot_tol);
         const double rs = mf_rsqrt(d);
         reg[c] *= rs;
 #pragma unroll
@@ -170,6 +199,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     }
 
     gpc_exp_table_init(T);
+    MF_STAMP_DECL
 
     // one workgroup per patch (no persistent loop: keeps every live range inside one pass; the ~1-2 us block hand-over
     // is < 4 % of a patch's run time and nothing else can share the CU's registers anyway)
@@ -219,6 +249,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 }
             }
         }
+        MF_STAMP(0);
         // ---- right-looking tiled Cholesky with the forward solve riding along ----
         // Iteration k: [B1] TRSM of tile column k (+ z_k, y update) [B2] trailing update with panel k.  In the update
         // the tile (k+1, k+1) goes first and its owner factors it at once (the only inlined copy of mf_diag_factor),
@@ -228,6 +259,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         for (int k = -1; k < nt; ++k) {
             if (k >= 0) {
                 __syncthreads();   // B1: L_kk^-1 published, step k-1 updates finished (panel free to overwrite)
+                MF_STAMP(1);
                 if (*flag) { bad = true; break; }
                 const d4 lv = *reinterpret_cast<const d4*>(Linv + k * 256 + lane * 4);
                 // z_k = L_kk^-1 y_k  (y_k already carries -sum_{j<k} L_kj z_j)
@@ -260,7 +292,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         }
                     }
                 }
+                MF_STAMP(2);
                 __syncthreads();   // B2: panel k complete
+                MF_STAMP(3);
             }
             // pass 1: the next diagonal tile: T_(k+1)(k+1) -= L_(k+1)k L_(k+1)k^T, then straight to the factor scratch
             bool mine = false;
@@ -279,10 +313,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     mine = true;
                 }
             }
+            MF_STAMP(4);
             if (mine) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                mf_diag_factor(DS, Linv + (k + 1) * 256, flag);
+                mf_diag_factor(DS, Linv + (k + 1) * 256, flag, g.pivot_tol);
             }
+            MF_STAMP(5);
             // pass 2: the rest of the trailing matrix, T_ij -= L_jk L_ik^T
             if (k >= 0) {
 #pragma unroll
@@ -296,6 +332,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     }
                 }
             }
+            MF_STAMP(6);
         }
         if (bad) {
             __syncthreads();
@@ -308,6 +345,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         }
         __syncthreads();
 
+        MF_STAMP(7);
         // ---- backward solve L^T alpha = z, tile rows from the last to the first ----
         for (int k = nt - 1; k >= 0; --k) {
             if (wave == (k & 7)) {
@@ -346,6 +384,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             for (int i = tid; i < n; i += MF_THREADS)
                 for (int c = 0; c < ny; ++c) A.alpha_out[(size_t)c * A.n_total + o + i] = av[c * MF_NPAD + i];
 
+        MF_STAMP(8);
         // ---- predictive mean ----
         if (A.xs0 == nullptr && A.grid_sz <= 32) {
             // separable grid: f[py][px] = sum_i Ey[py][i] * (sf alpha_i Ex[px][i]); wave w takes i in [32 w, 32 w + 32)
@@ -428,6 +467,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 for (int c = 0; c < ny; ++c) fs[(size_t)c * m + p] = s_[c];
             }
         }
+        MF_STAMP(9);
+        MF_STAMP_FLUSH();
         if (tid == 0 && A.status) A.status[patch] = GPC_STATUS_OK;
     } while (0);
 }
@@ -458,7 +499,43 @@ int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a)
     MfmaParams g;
     g.a = a;
     g.c_exp = (double)(-0.5f) / a.prm.l_sq;
+    g.pivot_tol = GPC_PIVOT_RTOL * (a.prm.sigmaf_sq + a.prm.noise);
+    g.stamps = nullptr;
     const int grid = a.P;         // one workgroup per patch
+#ifdef MF_STAMPS
+    GPC_HIP(ctx, hipMalloc(&g.stamps, sizeof(unsigned long long) * (size_t)grid * MF_WAVES * MF_NPH));
+    GPC_HIP(ctx, hipMemsetAsync(g.stamps, 0, sizeof(unsigned long long) * (size_t)grid * MF_WAVES * MF_NPH, ctx->stream));
+    struct StampDump {
+        gpc_ctx* ctx; unsigned long long* d; int grid;
+        ~StampDump()
+        {
+            std::vector<unsigned long long> h((size_t)grid * MF_WAVES * MF_NPH);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            (void)hipFree(d);
+            static const char* names[MF_NPH] = {"load+gram", "wait_B1", "z+trsm", "wait_B2", "pass1(diag tile upd)", "diag_factor",
+                                                "pass2(update)", "post-loop sync", "backward", "predict", "-", "-"};
+            fprintf(stderr, "[MF_STAMPS] mean cycles per patch, by wave (s_memtime ticks):\n%-22s", "phase");
+            for (int w = 0; w < MF_WAVES; ++w) fprintf(stderr, "   wave%d", w);
+            fprintf(stderr, "     mean\n");
+            double tot = 0;
+            for (int q = 0; q < 10; ++q) {
+                fprintf(stderr, "%-22s", names[q]);
+                double rowsum = 0;
+                for (int w = 0; w < MF_WAVES; ++w) {
+                    double s_ = 0;
+                    for (int b = 0; b < grid; ++b) s_ += (double)h[((size_t)b * MF_WAVES + w) * MF_NPH + q];
+                    s_ /= grid;
+                    rowsum += s_;
+                    fprintf(stderr, " %7.0f", s_);
+                }
+                fprintf(stderr, "  %7.0f\n", rowsum / MF_WAVES);
+                tot += rowsum / MF_WAVES;
+            }
+            fprintf(stderr, "%-22s total %.0f ticks per patch\n", "", tot);
+        }
+    } dump{ctx, g.stamps, grid};
+#endif
     if (a.n_max <= 64) return launch_nt<4>(ctx, g, grid, "dense_mfma_nt4");
     if (a.n_max <= 128) return launch_nt<8>(ctx, g, grid, "dense_mfma_nt8");
     if (a.n_max <= 192) return launch_nt<12>(ctx, g, grid, "dense_mfma_nt12");

@@ -47,7 +47,8 @@ extern "C" {
 
 /* per-patch status values */
 #define GPC_STATUS_OK 0
-#define GPC_STATUS_NOT_SPD 1      /* Cholesky pivot <= 0 (Eigen::LLT would report NumericalIssue); outputs are NaN */
+#define GPC_STATUS_NOT_SPD 1      /* Cholesky pivot <= 1e-14 (sigmaf_sq + noise): numerically singular (Eigen::LLT would
+                                     report NumericalIssue on a pivot <= 0); outputs are NaN */
 #define GPC_STATUS_NAN 2          /* state became NaN ("sparse_gp::C has become Nan", src/sparse_gp.hpp:245) */
 #define GPC_STATUS_SIGMA_CLAMPED 3 /* predictive sigma^2 < 0 was clamped to 0 (src/sparse_gp.hpp:334-337) */
 #define GPC_STATUS_OVERFLOW 4     /* sparse, capacity == -1 only: basis set would exceed GPC_MAX_BV; point skipped */

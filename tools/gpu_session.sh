@@ -21,8 +21,12 @@ if [ "${RUN_PROBE:-1}" = "1" ]; then
   step 120 $OUT/probe_$TAG.log /tmp/probe_mfma
 fi
 if [ "${RUN_TESTS:-1}" = "1" ]; then
-  step ${TEST_LIMIT:-900} $OUT/pytest_$TAG.log python -m pytest tests -x -q -m gpu ${PYTEST_ARGS:-}
+  step ${TEST_LIMIT:-900} $OUT/pytest_$TAG.log python -m pytest tests -q -m gpu ${PYTEST_ARGS:-}
   tail -5 $OUT/pytest_$TAG.log
+fi
+if [ "${RUN_STAMP:-0}" = "1" ]; then
+  step 300 $OUT/stamp_$TAG.log python tools/stamp_mfma.py
+  tail -16 $OUT/stamp_$TAG.log
 fi
 if [ "${RUN_BENCH:-1}" = "1" ]; then
   step 600 $OUT/bench_$TAG.log python bench.py --steps ${BENCH_STEPS:-10} --warmup 2
