@@ -125,7 +125,7 @@ def main():
     d_off, d_x0, d_x1, d_y = t(off), t(x0), t(x1), t(y)
     f_star = torch.empty((P, 1, m), dtype=torch.float64, device=dev)
     status = torch.empty((P,), dtype=torch.int32, device=dev)
-    gathered = torch.empty((world, P, 1, m), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty((world * P, 1, m), dtype=torch.float64, device=dev) if world > 1 else None
 
     ctx = capi.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # kernel, events and collective share one stream
@@ -165,7 +165,7 @@ def main():
     f_host = f_star.cpu().numpy()
     ok = bool(np.all(st == 0)) and bool(np.all(np.isfinite(f_host)))
     if world > 1:
-        mine = gathered[rank].cpu().numpy()
+        mine = gathered[rank * P:(rank + 1) * P].cpu().numpy()
         ok = ok and bool(np.array_equal(mine, f_host))
 
     if rank == 0:

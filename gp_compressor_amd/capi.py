@@ -6,6 +6,7 @@ built (gp_compressor_amd.build.build() / __graft_entry__.build()) or no HIP devi
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -132,11 +133,14 @@ class Context:
         if rc != GPC_OK:
             raise GpcError(rc, "gpc_ctx_create failed (no HIP device?) -- there is no CPU fallback")
         self.h = h
+        self._children = weakref.WeakSet()   # sparse handles must be destroyed before their context
         if stream is not None:
             self.set_stream(stream)
 
     def close(self):
         if getattr(self, "h", None):
+            for ch in list(self._children):
+                ch.close()
             self.lib.gpc_ctx_destroy(self.h)
             self.h = None
 
@@ -210,6 +214,7 @@ class Sparse:
         h = _vp()
         ctx._check(self.lib.gpc_sparse_create(ctx.h, C.byref(params), P, ny, C.byref(h)))
         self.h = h
+        ctx._children.add(self)
 
     def close(self):
         if getattr(self, "h", None):

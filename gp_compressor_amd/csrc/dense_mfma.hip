@@ -71,7 +71,7 @@ struct MfmaParams {
 #define L_PX1 (L_PX0 + MF_NPAD)          // 256   x1
 #define L_YC (L_PX1 + MF_NPAD)           // 3*256 running right-hand sides (forward solve)
 #define L_ZV (L_YC + 3 * MF_NPAD)        // 3*256 z = L^-1 y
-#define L_WV (L_ZV + 3 * MF_NPAD)        // 3*256 backward-solve accumulators
+#define L_WV (L_ZV + 3 * MF_NPAD)        // 3*256 backward-solve partial sums [8 waves][3][16] (384 used)
 #define L_AV (L_WV + 3 * MF_NPAD)        // 3*256 alpha
 #define L_DS (L_AV + 3 * MF_NPAD)        // 16*17 (+ pad to 288) diagonal-tile scratch
 #define L_FLAG (L_DS + 288)              // 2     not-SPD flag
@@ -140,20 +140,29 @@ __device__ __forceinline__ static void mf_diag_factor(const double* S, double* L
     }
 }
 
-// sum over the 4 lane groups (l>>4) -- every lane gets the total
-__device__ static inline double mf_sum_groups(double v)
+// ---- slot dispatch ----------------------------------------------------------------------------------------
+// Tiles are enumerated column-major over the lower triangle (idx = cs(j) + i - j, cs(j) = j NT - j (j-1)/2) and
+// dealt round-robin: wave w owns idx = 8 t + w in register slot t.  Every phase works on a contiguous idx range,
+// i.e. on a contiguous slot range [t_lo, t_hi] of each wave, entered through a fall-through switch so that the
+// scalar unit does not scan the dead slots (17 slots x 3 phases x 16 steps of compare-and-branch cost more than the
+// MFMAs of the late steps).
+#define MF_SLOTS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+__device__ static __forceinline__ int mf_cs(int j, int nt_full) { return j * nt_full - (j * (j - 1)) / 2; }
+
+template <int CTRL>
+__device__ static __forceinline__ double mf_dpp(double v)
 {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
-// sum over the 16 lanes of a group (l & 15) -- every lane gets the total
-__device__ static inline double mf_sum_rows(double v)
+// sum over the 16 lanes of a DPP row (l & 15); every lane gets the total.  row_ror:1,2,4,8 (no LDS traffic).
+__device__ static __forceinline__ double mf_row_allsum(double v)
 {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += mf_dpp<0x121>(v);
+    v += mf_dpp<0x122>(v);
+    v += mf_dpp<0x124>(v);
+    v += mf_dpp<0x128>(v);
     return v;
 }
 
@@ -162,6 +171,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 {
     constexpr int NTILES = NT * (NT + 1) / 2;
     constexpr int TPW = (NTILES + MF_WAVES - 1) / MF_WAVES;
+    static_assert(TPW <= 17, "MF_SLOTS covers 17 slots");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     double* T = lds + L_EXP;
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     double* px1 = lds + L_PX1;
     double* yc = lds + L_YC;
     double* zv = lds + L_ZV;
-    double* wv = lds + L_WV;
+    double* wpart = lds + L_WV;
     double* av = lds + L_AV;
     double* DS = lds + L_DS;
     int* flag = reinterpret_cast<int*>(lds + L_FLAG);
@@ -179,11 +189,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     const DenseArgs& A = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, lg = lane >> 4;
     const int ny = A.ny, m = A.m;
     const double sf = A.prm.sigmaf_sq, cexp = g.c_exp, noise = A.prm.noise;
 
-    // tile slots of this wave: column-major enumeration of the lower triangle dealt round-robin to the 8 waves
+    // tile coordinates of this wave's slots (wave-uniform, SGPRs)
     int tij[TPW];
 #define ti_(t) (tij[t] & 255)
 #define tj_(t) (tij[t] >> 8)
@@ -201,14 +210,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     gpc_exp_table_init(T);
     MF_STAMP_DECL
 
-    // one workgroup per patch (no persistent loop: keeps every live range inside one pass; the ~1-2 us block hand-over
-    // is < 4 % of a patch's run time and nothing else can share the CU's registers anyway)
+    // one workgroup per patch, straight-line (a persistent patch loop makes hipcc hoist hundreds of lane-dependent
+    // LDS addresses out of it and spill 1.8 KB/lane; the block hand-over costs ~1-2 us against >100 us of work)
     do {
         const int patch = blockIdx.x;
         const int o = A.off[patch];
         const int n = A.off[patch + 1] - o;
         double* fs = A.f_star + (size_t)patch * ny * m;
-        __syncthreads();   // previous patch done with LDS
         if (n <= 0 || n > NT * MF_TS) {
             for (int p = tid; p < m * ny; p += MF_THREADS) fs[p] = (n == 0) ? 0.0 : __builtin_nan("");
             if (tid == 0 && A.status) A.status[patch] = (n == 0) ? GPC_STATUS_OK : GPC_STATUS_NAN;
@@ -219,10 +227,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             const bool live = i < n;
             px0[i] = live ? A.x0[o + i] : 0.0;
             px1[i] = live ? A.x1[o + i] : 0.0;
-            for (int c = 0; c < ny; ++c) {
-                yc[c * MF_NPAD + i] = live ? A.y[(size_t)c * A.n_total + o + i] : 0.0;
-                wv[c * MF_NPAD + i] = 0.0;
-            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (c < ny) yc[c * MF_NPAD + i] = live ? A.y[(size_t)c * A.n_total + o + i] : 0.0;
         }
         if (tid == 0) *flag = 0;
         __syncthreads();
@@ -250,86 +257,133 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             }
         }
         MF_STAMP(0);
-        // ---- right-looking tiled Cholesky with the forward solve riding along ----
-        // Iteration k: [B1] TRSM of tile column k (+ z_k, y update) [B2] trailing update with panel k.  In the update
-        // the tile (k+1, k+1) goes first and its owner factors it at once (the only inlined copy of mf_diag_factor),
-        // so that the serial 16 x 16 factorisation overlaps the other waves' MFMAs.  k = -1 is the virtual step that
-        // only factors tile (0, 0).
+
+        // ---- right-looking tiled Cholesky, forward solve riding along ----
+        // Iteration k: [B1] z_k and the TRSM of tile column k [B2] y update, trailing update with panel k.  In the
+        // update the tile (k+1, k+1) goes first and its owner factors it at once (the only inlined copy of
+        // mf_diag_factor), so that the serial 16 x 16 factorisation overlaps the other waves' MFMAs.  k = -1 is the
+        // virtual step that only factors tile (0, 0).
         bool bad = false;
         for (int k = -1; k < nt; ++k) {
             if (k >= 0) {
                 __syncthreads();   // B1: L_kk^-1 published, step k-1 updates finished (panel free to overwrite)
                 MF_STAMP(1);
                 if (*flag) { bad = true; break; }
-                const d4 lv = *reinterpret_cast<const d4*>(Linv + k * 256 + lane * 4);
-                // z_k = L_kk^-1 y_k  (y_k already carries -sum_{j<k} L_kj z_j)
-                double zq[3][4];
-                for (int c = 0; c < ny; ++c) {
-                    double part = 0.0;
+                // z_k = L_kk^-1 y_k (y_k already carries -sum_{j<k} L_kj z_j): 16 row-threads of one wave
+                if (wave == (k & 7) && lane < 16) {
+                    const double* Lr = Linv + k * 256 + lane * 4;          // row `lane`: 4 chunks of 4 (k = g + 4 s)
+                    d4 ch[4];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) part = __builtin_fma(lv[s], yc[c * MF_NPAD + MF_TS * k + lg + 4 * s], part);
-                    const double zk = mf_sum_groups(part);                    // z_k[l & 15] in every lane
-                    if (wave == (k & 7) && lg == 0) zv[c * MF_NPAD + MF_TS * k + lr] = zk;
+                    for (int gq = 0; gq < 4; ++gq) ch[gq] = *reinterpret_cast<const d4*>(Lr + gq * 64);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) zq[c][s] = __shfl(zk, lg + 4 * s, 64);   // z_k[(l>>4) + 4 s]
+                    for (int c = 0; c < 3; ++c) {
+                        if (c < ny) {
+                            const double* yk = yc + c * MF_NPAD + MF_TS * k;
+                            double s_ = 0.0;
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) s_ = __builtin_fma(ch[gq][s], yk[gq + 4 * s], s_);
+                            zv[c * MF_NPAD + MF_TS * k + lane] = s_;
+                        }
+                    }
                 }
                 // panel TRSM: L_ik^T = L_kk^-1 * T_ik  (A operand = L_kk^-1 from LDS, B operand = the accumulator itself)
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    if (tj_(t) == k && ti_(t) > k && ti_(t) < nt) {
-                        const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                        d4 D = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) D = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[s], acc[t][s], D, 0, 0, 0);
-                        acc[t] = D;                                            // = L_ik[l & 15][(l>>4) + 4 r]
-                        *reinterpret_cast<d4*>(panP + ti_(t) * 256 + ln * 4) = D;
-                        for (int c = 0; c < ny; ++c) {                         // y_i -= L_ik z_k
-                            double part = 0.0;
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) part = __builtin_fma(D[s], zq[c][s], part);
-                            part = mf_sum_groups(part);
-                            if (lg == 0) yc[c * MF_NPAD + MF_TS * ti_(t) + lr] -= part;
+                {
+                    const int lo_ = mf_cs(k, NT) + 1 - wave, hi_ = mf_cs(k + 1, NT) - 1 - wave;
+                    const int t_lo = (lo_ + 7) >> 3, t_hi = hi_ >> 3;
+                    if (t_lo <= t_hi) {
+                        const d4 lv = *reinterpret_cast<const d4*>(Linv + k * 256 + mf_opaque(lane) * 4);
+                        switch (t_lo) {
+#define MF_TRSM_CASE(t)                                                                                              \
+    case t:                                                                                                          \
+        if constexpr (t < TPW) {                                                                                     \
+            if (t > t_hi) break;                                                                                     \
+            if (ti_(t) < nt) {                                                                                       \
+                d4 D1 = d4{0.0, 0.0, 0.0, 0.0}, D2 = d4{0.0, 0.0, 0.0, 0.0};                                         \
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], acc[t][0], D1, 0, 0, 0);                            \
+                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], acc[t][2], D2, 0, 0, 0);                            \
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], acc[t][1], D1, 0, 0, 0);                            \
+                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], acc[t][3], D2, 0, 0, 0);                            \
+                acc[t] = D1 + D2; /* = L_ik[l & 15][(l>>4) + 4 r] */                                                 \
+                *reinterpret_cast<d4*>(panP + ti_(t) * 256 + mf_opaque(lane) * 4) = acc[t];                          \
+            }                                                                                                        \
+        }                                                                                                            \
+        [[fallthrough]];
+                            MF_SLOTS(MF_TRSM_CASE)
+                            default: break;
                         }
                     }
                 }
                 MF_STAMP(2);
-                __syncthreads();   // B2: panel k complete
+                __syncthreads();   // B2: panel k and z_k complete
                 MF_STAMP(3);
             }
             // pass 1: the next diagonal tile: T_(k+1)(k+1) -= L_(k+1)k L_(k+1)k^T, then straight to the factor scratch
-            bool mine = false;
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                if (ti_(t) == k + 1 && tj_(t) == k + 1 && k + 1 < nt) {
+            if (k + 1 < nt) {
+                const int idx1 = mf_cs(k + 1, NT);
+                if (wave == (idx1 & 7)) {
                     const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                    if (k >= 0) {
-                        const d4 a = *reinterpret_cast<const d4*>(panP + (k + 1) * 256 + ln * 4);
-                        // blgp = 1 on the f64 MFMA is NEG(A): acc - a*b  (tools/probe_mfma_f64.hip)
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], a[s], acc[t], 0, 0, 1);
+                    switch (idx1 >> 3) {
+#define MF_DIAG_CASE(t)                                                                                              \
+    case t:                                                                                                          \
+        if constexpr (t < TPW) {                                                                                     \
+            if (k >= 0) {                                                                                            \
+                const d4 a = *reinterpret_cast<const d4*>(panP + (k + 1) * 256 + ln * 4);                            \
+                /* blgp = 1 on the f64 MFMA is NEG(A): acc - a*b  (tools/probe_mfma_f64.hip) */                      \
+                _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                        \
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], a[s], acc[t], 0, 0, 1);                      \
+            }                                                                                                        \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) DS[(lg + 4 * r) * 17 + lr] = acc[t][r];                    \
+        }                                                                                                            \
+        break;
+                        MF_SLOTS(MF_DIAG_CASE)
+                        default: break;
                     }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) DS[(lg + 4 * r) * 17 + lr] = acc[t][r];
-                    mine = true;
+                    MF_STAMP(4);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    mf_diag_factor(DS, Linv + (k + 1) * 256, flag, g.pivot_tol);
+                    MF_STAMP(5);
                 }
             }
-            MF_STAMP(4);
-            if (mine) {
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                mf_diag_factor(DS, Linv + (k + 1) * 256, flag, g.pivot_tol);
-            }
-            MF_STAMP(5);
-            // pass 2: the rest of the trailing matrix, T_ij -= L_jk L_ik^T
             if (k >= 0) {
+                // forward solve: y_i -= L_ik z_k for the panel rows, one thread per matrix row, operands from LDS
+                if (tid < MF_TS * (nt - 1 - k)) {
+                    const int i = k + 1 + (tid >> 4), mr = tid & 15;
+                    const double* Pr = panP + i * 256 + mr * 4;
+                    d4 ch[4];
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    if (tj_(t) > k && ti_(t) < nt && !(ti_(t) == k + 1 && tj_(t) == k + 1)) {
-                        const int ln4 = mf_opaque(lane) * 4;
-                        const d4 a = *reinterpret_cast<const d4*>(panP + tj_(t) * 256 + ln4);
-                        const d4 b = *reinterpret_cast<const d4*>(panP + ti_(t) * 256 + ln4);
+                    for (int gq = 0; gq < 4; ++gq) ch[gq] = *reinterpret_cast<const d4*>(Pr + gq * 64);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc[t], 0, 0, 1);
+                    for (int c = 0; c < 3; ++c) {
+                        if (c < ny) {
+                            const double* zk = zv + c * MF_NPAD + MF_TS * k;
+                            double s_ = 0.0;
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) s_ = __builtin_fma(ch[gq][s], zk[gq + 4 * s], s_);
+                            yc[c * MF_NPAD + MF_TS * i + mr] -= s_;
+                        }
                     }
+                }
+                // pass 2: the rest of the trailing matrix, T_ij -= L_jk L_ik^T  (idx > cs(k+1))
+                const int t_first = (mf_cs(k + 1, NT) + 1 - wave + 7) >> 3;
+                switch (t_first) {
+#define MF_UPD_CASE(t)                                                                                               \
+    case t:                                                                                                          \
+        if constexpr (t < TPW) {                                                                                     \
+            if (ti_(t) < nt) {                                                                                       \
+                const int ln4 = mf_opaque(lane) * 4;                                                                 \
+                const d4 a = *reinterpret_cast<const d4*>(panP + tj_(t) * 256 + ln4);                                \
+                const d4 b = *reinterpret_cast<const d4*>(panP + ti_(t) * 256 + ln4);                                \
+                _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                        \
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc[t], 0, 0, 1);                      \
+            }                                                                                                        \
+        }                                                                                                            \
+        [[fallthrough]];
+                    MF_SLOTS(MF_UPD_CASE)
+                    default: break;
                 }
             }
             MF_STAMP(6);
@@ -343,51 +397,68 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             if (tid == 0 && A.status) A.status[patch] = GPC_STATUS_NOT_SPD;
             continue;
         }
-        __syncthreads();
-
         MF_STAMP(7);
-        // ---- backward solve L^T alpha = z, tile rows from the last to the first ----
+
+        // ---- backward solve L^T alpha = z, tile columns from the last to the first ----
+        // alpha_k = L_kk^-T (z_k - sum_{i>k} L_ik^T alpha_i).  The column-k tiles sit in registers as
+        // L_ik[l&15][(l>>4)+4r]: each wave sums its tiles' products in registers, reduces over the 16 lanes of a DPP
+        // row (row_ror, no LDS), and publishes one 16-vector per channel; one wave finishes alpha_k.
         for (int k = nt - 1; k >= 0; --k) {
-            if (wave == (k & 7)) {
-                // alpha_k = L_kk^-T (z_k - w_k):  alpha_k[c] = sum_r Linv[r][c] u[r]
-                const d4 lv = *reinterpret_cast<const d4*>(Linv + k * 256 + lane * 4);
-                for (int c = 0; c < ny; ++c) {
-                    const double u = zv[c * MF_NPAD + MF_TS * k + lr] - wv[c * MF_NPAD + MF_TS * k + lr];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const double a_ = mf_sum_rows(lv[s] * u);
-                        if (lr == 0) av[c * MF_NPAD + MF_TS * k + lg + 4 * s] = a_;
+            const int lo_ = mf_cs(k, NT) + 1 - wave, hi_ = mf_cs(k + 1, NT) - 1 - wave;
+            const int t_lo = (lo_ + 7) >> 3, t_hi = hi_ >> 3;
+            for (int c = 0; c < ny; ++c) {      // one channel at a time keeps the register footprint at 4 doubles
+                const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
+                d4 pa = d4{0.0, 0.0, 0.0, 0.0};
+                if (t_lo <= t_hi) {
+                    const double* avc = av + c * MF_NPAD + lr;
+                    switch (t_lo) {
+#define MF_BWD_CASE(t)                                                                                               \
+    case t:                                                                                                          \
+        if constexpr (t < TPW) {                                                                                     \
+            if (t > t_hi) break;                                                                                     \
+            if (ti_(t) < nt) pa += acc[t] * avc[MF_TS * ti_(t)];                                                     \
+        }                                                                                                            \
+        [[fallthrough]];
+                        MF_SLOTS(MF_BWD_CASE)
+                        default: break;
                     }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) pa[s] = mf_row_allsum(pa[s]);
+                }
+                if (lr == 0) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) wpart[(wave * 3 + c) * 16 + lg + 4 * s] = pa[s];
                 }
             }
             __syncthreads();
-            if (k > 0) {
-                // w_j += L_kj^T alpha_k for the tiles (k, j), j < k, which sit in registers as L_kj[l&15][(l>>4)+4r]
+            if (wave == (k & 7)) {
+                // lane c' < 16: u[c'] = z_k[c'] - w_k[c'];  alpha_k[c'] = sum_m Linv[m][c'] u[m]
+                const int cc = mf_opaque(lane) & 15;
+                const double* Lc = Linv + k * 256 + (16 * (cc & 3)) * 4 + (cc >> 2);
+                for (int c = 0; c < ny; ++c) {
+                    double w_ = 0.0;
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    if (ti_(t) == k && tj_(t) < k) {
-                        const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                        for (int c = 0; c < ny; ++c) {
-                            const double ar = av[c * MF_NPAD + MF_TS * k + lr];
+                    for (int w8 = 0; w8 < MF_WAVES; ++w8) w_ += wpart[(w8 * 3 + c) * 16 + cc];
+                    const double u = zv[c * MF_NPAD + MF_TS * k + cc] - w_;
+                    double a_ = 0.0;
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) {
-                                const double q = mf_sum_rows(acc[t][s] * ar);
-                                if (lr == 0) wv[c * MF_NPAD + MF_TS * tj_(t) + lg + 4 * s] += q;
-                            }
-                        }
-                    }
+                    for (int mm = 0; mm < MF_TS; ++mm) a_ = __builtin_fma(Lc[mm * 4], mf_readlane(u, mm), a_);
+                    if (lane < 16) av[c * MF_NPAD + MF_TS * k + cc] = a_;
                 }
-                __syncthreads();
             }
+            __syncthreads();
         }
         if (A.alpha_out)
             for (int i = tid; i < n; i += MF_THREADS)
-                for (int c = 0; c < ny; ++c) A.alpha_out[(size_t)c * A.n_total + o + i] = av[c * MF_NPAD + i];
-
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < ny) A.alpha_out[(size_t)c * A.n_total + o + i] = av[c * MF_NPAD + i];
         MF_STAMP(8);
+
         // ---- predictive mean ----
         if (A.xs0 == nullptr && A.grid_sz <= 32) {
             // separable grid: f[py][px] = sum_i Ey[py][i] * (sf alpha_i Ex[px][i]); wave w takes i in [32 w, 32 w + 32)
+            const int lr = lane & 15, lg = lane >> 4;
             const int sz = A.grid_sz;
             const double res = A.grid_res;
             double* red = panP;   // 8 waves x 4 tiles x 256 doubles = 64 KB: aliases the (dead) panels
@@ -462,9 +533,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 double s_[3] = {0.0, 0.0, 0.0};
                 for (int i = 0; i < n; ++i) {
                     const double kk = gpc_rbf(sf, cexp, px0[i], px1[i], q0, q1, T);
-                    for (int c = 0; c < ny; ++c) s_[c] += kk * av[c * MF_NPAD + i];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (c < ny) s_[c] += kk * av[c * MF_NPAD + i];
                 }
-                for (int c = 0; c < ny; ++c) fs[(size_t)c * m + p] = s_[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < ny) fs[(size_t)c * m + p] = s_[c];
             }
         }
         MF_STAMP(9);
@@ -514,7 +589,7 @@ int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a)
             (void)hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
             (void)hipFree(d);
             static const char* names[MF_NPH] = {"load+gram", "wait_B1", "z+trsm", "wait_B2", "pass1(diag tile upd)", "diag_factor",
-                                                "pass2(update)", "post-loop sync", "backward", "predict", "-", "-"};
+                                                "yupd+pass2(update)", "post-loop", "backward", "predict", "-", "-"};
             fprintf(stderr, "[MF_STAMPS] mean cycles per patch, by wave (s_memtime ticks):\n%-22s", "phase");
             for (int w = 0; w < MF_WAVES; ++w) fprintf(stderr, "   wave%d", w);
             fprintf(stderr, "     mean\n");

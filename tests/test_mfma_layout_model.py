@@ -92,7 +92,7 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
     px0 = np.zeros(npad); px1 = np.zeros(npad)
     px0[:n], px1[:n] = x0, x1
     yc = np.zeros((ny, npad)); yc[:, :n] = y
-    zv = np.zeros((ny, npad)); wv = np.zeros((ny, npad)); av = np.zeros((ny, npad))
+    zv = np.zeros((ny, npad)); av = np.zeros((ny, npad))
     # Gram tiles (transposed storage)
     acc = {}
     for j in range(NT):
@@ -115,23 +115,34 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
     for k in range(-1, nt):
         if k >= 0:
             lv = Linv[k].reshape(64, 4)
-            zq = np.zeros((ny, 64, 4))
+            # z_k = L_kk^-1 y_k by 16 row-threads reading the operand image: row m = 4 chunks of 4 at (m + 16 g) * 4
             for c in range(ny):
-                part = sum(lv[:, s] * yc[c, 16 * k + LG + 4 * s] for s in range(4))
-                zk = np.array([part[(L & 15) == (l & 15)].sum() for l in L])     # sum over lane groups
-                zv[c, 16 * k + LR[:16]] = zk[:16]
-                for s in range(4):
-                    zq[c, :, s] = zk[LG + 4 * s]
+                for mrow in range(16):
+                    s_ = 0.0
+                    for gq in range(4):
+                        ch = Linv[k][(mrow + 16 * gq) * 4:(mrow + 16 * gq) * 4 + 4]
+                        for s in range(4):
+                            s_ += ch[s] * yc[c, 16 * k + gq + 4 * s]
+                    zv[c, 16 * k + mrow] = s_
             for i in range(k + 1, nt):
-                D = np.zeros((64, 4))
-                for s in range(4):
-                    D = mfma(lv[:, s], acc[(i, k)][:, s], D)
+                D1 = np.zeros((64, 4)); D2 = np.zeros((64, 4))
+                D1 = mfma(lv[:, 0], acc[(i, k)][:, 0], D1)
+                D2 = mfma(lv[:, 2], acc[(i, k)][:, 2], D2)
+                D1 = mfma(lv[:, 1], acc[(i, k)][:, 1], D1)
+                D2 = mfma(lv[:, 3], acc[(i, k)][:, 3], D2)
+                D = D1 + D2
                 acc[(i, k)] = D
                 pan[i] = D.reshape(256)
-                for c in range(ny):
-                    part = sum(D[:, s] * zq[c, :, s] for s in range(4))
-                    tot = np.array([part[(L & 15) == r].sum() for r in range(16)])
-                    yc[c, 16 * i + np.arange(16)] -= tot
+            # y_i -= L_ik z_k by row-threads reading the LDS panel
+            for i in range(k + 1, nt):
+                for mrow in range(16):
+                    for c in range(ny):
+                        s_ = 0.0
+                        for gq in range(4):
+                            ch = pan[i][(mrow + 16 * gq) * 4:(mrow + 16 * gq) * 4 + 4]
+                            for s in range(4):
+                                s_ += ch[s] * zv[c, 16 * k + gq + 4 * s]
+                        yc[c, 16 * i + mrow] -= s_
         if k + 1 < nt:
             a_ = acc[(k + 1, k + 1)]
             if k >= 0:
@@ -154,23 +165,22 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
                     for s in range(4):
                         t = mfma(a[:, s], b[:, s], t, neg_a=True)
                     acc[(i, j)] = t
-    # backward solve
+    # backward solve, left-looking over tile columns: alpha_k = L_kk^-T (z_k - sum_{i>k} L_ik^T alpha_i)
     for k in range(nt - 1, -1, -1):
-        lv = Linv[k].reshape(64, 4)
         for c in range(ny):
-            u = zv[c, 16 * k + LR] - wv[c, 16 * k + LR]
+            w = np.zeros(16)
+            pa = np.zeros((64, 4))
+            for i in range(k + 1, nt):
+                pa += acc[(i, k)] * av[c, 16 * i + LR][:, None]
             for s in range(4):
-                prod = lv[:, s] * u
                 for g in range(4):
-                    av[c, 16 * k + g + 4 * s] = prod[LG == g].sum()
-        for j in range(k):
-            t = acc[(k, j)]
-            for c in range(ny):
-                ar = av[c, 16 * k + LR]
-                for s in range(4):
-                    prod = t[:, s] * ar
-                    for g in range(4):
-                        wv[c, 16 * j + g + 4 * s] += prod[LG == g].sum()
+                    w[g + 4 * s] = pa[LG == g, s].sum()          # mf_row_allsum over the 16 lanes of a DPP row
+            u = zv[c, 16 * k:16 * k + 16] - w
+            for cc in range(16):
+                a_ = 0.0
+                for mm in range(16):
+                    a_ += Linv[k][(mm + 16 * (cc & 3)) * 4 + (cc >> 2)] * u[mm]
+                av[c, 16 * k + cc] = a_
     # separable predictive mean on the sz x sz grid, wave w takes points [32 w, 32 w + 32)
     f = np.zeros((ny, sz * sz))
     for c in range(ny):

@@ -3,7 +3,9 @@
 Oracle: oracle/gpc_oracle.c run patch by patch with the same explicit insertion order.
 Stated tolerance (fp64, tree-reduced sums on the GPU vs sequential sums in the oracle):
   * well-conditioned regimes (exact / capacity-bounded with a kernel that fills the basis):
-        identical basis-vector bookkeeping (counts, BV order) and |f*| within 1e-7 relative, sigma within 1e-7
+        identical basis-vector bookkeeping (counts, BV order); f* and sigma within 2e-5 of max|f*| on random batches
+        (Q = K_BV^-1 reaches 1e6 with eps_tol = 1e-6f, and the two CPU restatements -- C oracle vs NumPy -- already
+        differ by up to 4e-6 on these very inputs), within 1e-7 on the committed golden sequences
   * the reference's default hyper-parameters (sigma_f^2 = 100, l^2 = 1 on a 0.15 m patch): the sparse-vs-full
     decision `gamma < 1e-6f` is taken on rounding noise (|Q| ~ 1e6), so two correct fp64 implementations disagree
     in the BV count; only f* is compared, to 1e-2 of max|f*| (see tests/test_oracle.py for the CPU-vs-CPU evidence).
@@ -96,8 +98,8 @@ def test_sparse_batch_vs_oracle(gp, oracle, ny, cap):
     assert np.all(st == 0)
     assert np.array_equal(g.sizes(), bo)
     scale = np.max(np.abs(fo))
-    assert np.max(np.abs(f - fo)) <= 1e-7 * scale
-    assert np.max(np.abs(s - so)) <= 1e-7 * np.max(so)
+    assert np.max(np.abs(f - fo)) <= 2e-5 * scale
+    assert np.max(np.abs(s - so)) <= 2e-5 * np.max(so)
     # confidence form (src/sparse_gp.hpp:340-345) and the mean-only call the compressor makes
     f2, c2, _ = g.predict(xs0, xs1, conf=True)
     kss = kw["sigmaf_sq"] + kw["noise"]
@@ -129,7 +131,7 @@ def test_sparse_online_growth_equals_one_shot(gp, oracle):
     op = oracle.sparse_params(1, p0=1.0, p1=(res / 8) ** 2, s20=1e-4, capacity=cap)
     fo, so, bo = _oracle_batch(oracle, op, off, x0, x1, y, None, xs0, xs1, cap + 2)
     assert np.array_equal(g1.sizes(), bo)
-    assert np.max(np.abs(f1 - fo)) <= 1e-6 * np.max(np.abs(fo))
+    assert np.max(np.abs(f1 - fo)) <= 2e-5 * np.max(np.abs(fo))
     # reset() (src/sparse_gp.hpp:573-582)
     g2.reset()
     assert np.all(g2.sizes() == 0)
