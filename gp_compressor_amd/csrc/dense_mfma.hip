@@ -3,24 +3,30 @@
 // Same computation as dense_generic.hip (gaussian_process::add_measurements + predict_measurements,
 // /root/reference/src/gaussian_process.cpp:15-45), restructured for CDNA4:
 //
-//   * one 512-thread workgroup (8 waves, 2 per SIMD) per patch; the whole lower triangle of K -- 136 tiles of
-//     16 x 16 doubles = 272 KB, more than the 160 KB of LDS -- lives in the VGPR file as
-//     v_mfma_f64_16x16x4_f64 accumulators (17 tiles = 136 VGPRs per wave).  K never touches HBM or L2.
-//   * right-looking tiled Cholesky: per tile column k the owner of the diagonal tile inverts its Cholesky factor
-//     in registers ([A | I] -> [L^T | L^-1] with cross-lane v_readlane broadcasts), the panel TRSM is
-//     L_ik^T = L_kk^-1 * A_ik^T as 4 MFMAs per tile, the trailing update A_ij -= L_ik L_jk^T is 4 MFMAs per tile
-//     with both operands read from a 32 KB LDS panel in "operand layout" (lane l holds row l&15, k = (l>>4)+4s:
-//     one conflict-free 32-byte read per operand).
+//   * one 512-thread workgroup per patch: 7 WORKER waves + 1 FACTOR wave (wave specialisation).  The whole lower
+//     triangle of K -- 136 tiles of 16 x 16 doubles = 272 KB, more than the 160 KB of LDS -- lives in the VGPR
+//     file of the workers as v_mfma_f64_16x16x4_f64 accumulators (20 tile slots = 160 VGPRs per wave).  K never
+//     touches HBM or L2.
+//   * right-looking tiled Cholesky.  Per tile column k the panel TRSM is L_ik^T = L_kk^-1 * A_ik^T (4 MFMAs per
+//     tile) and the trailing update A_ij -= L_ik L_jk^T is 4 MFMAs per tile, both operands read from a 32 KB LDS
+//     panel in "operand layout" (lane l holds row l&15, k = (l>>4)+4s: one conflict-free 32-byte read per operand).
 //   * tiles are stored TRANSPOSED (T_ij = A_ij^T in the MFMA C/D layout), which makes the accumulator registers of
 //     a panel tile directly the B operand of its TRSM and the TRSM result directly the operand-layout image of
 //     L_ik: no cross-lane movement anywhere in the O(n^3) part.
-//   * the diagonal factorisation of column k+1 is issued by its owner right after that tile's step-k update, so it
-//     overlaps the other waves' MFMA work; the forward solve rides along with the TRSM, the backward solve walks
-//     the register-resident factor, and the predictive mean on the sz x sz decompression grid is evaluated
-//     separably (K* = Ex o Ey, /root/reference/src/gp_compressor.cpp:317-332) as 4 more MFMA tiles per wave.
+//   * the serial part -- inverting the Cholesky factor of the next 16 x 16 diagonal tile (square-root-free
+//     elimination on [A | I] in registers, lane = column, wave-uniform multipliers through v_readlane) and the
+//     16-wide pieces of the forward solve -- runs on the factor wave, which holds no accumulators: it overlaps the
+//     workers' MFMAs instead of stalling them, and its 32-register working set does not collide with the 160
+//     accumulator registers.  Workers and factor wave hand over through two LDS words (tile_ready / ready) and one
+//     workgroup barrier per tile column; the panel is double-buffered so that the next TRSM may start while slow
+//     workers still read the previous panel.
+//   * the backward solve walks the register-resident factor (DPP row reductions, ds_add_f64), and the predictive
+//     mean on the sz x sz decompression grid is evaluated separably (K* = Ex o Ey,
+//     /root/reference/src/gp_compressor.cpp:317-332) as 4 more MFMA tiles per wave.
 //
 // Lane maps (verified by tools/probe_mfma_f64.hip): A operand lane l = A[l&15][l>>4], B operand lane l =
-// B[l>>4][l&15], C/D register r of lane l = D[(l>>4) + 4r][l&15].
+// B[l>>4][l&15], C/D register r of lane l = D[(l>>4) + 4r][l&15]; blgp = 1 negates A.  The whole data flow is
+// replayed lane by lane in tests/test_mfma_layout_model.py.
 #include <vector>
 
 #include "gpc_device.h"
@@ -30,6 +36,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define MF_THREADS 512
 #define MF_WAVES 8
+#define MF_WORKERS 7
+#define MF_FACTOR_WAVE 7
 #define MF_TS 16
 #define MF_NPAD 256
 
@@ -71,48 +79,84 @@ struct MfmaParams {
 #define L_PX1 (L_PX0 + MF_NPAD)          // 256   x1
 #define L_YC (L_PX1 + MF_NPAD)           // 3*256 running right-hand sides (forward solve)
 #define L_ZV (L_YC + 3 * MF_NPAD)        // 3*256 z = L^-1 y
-#define L_WV (L_ZV + 3 * MF_NPAD)        // 3*256 backward-solve partial sums [8 waves][3][16] (384 used)
+#define L_WV (L_ZV + 3 * MF_NPAD)        // 3*256 backward-solve accumulators w_k[c][16 k + .] (ds_add_f64 targets)
 #define L_AV (L_WV + 3 * MF_NPAD)        // 3*256 alpha
-#define L_DS (L_AV + 3 * MF_NPAD)        // 16*17 (+ pad to 288) diagonal-tile scratch
-#define L_FLAG (L_DS + 288)              // 2     not-SPD flag
+#define L_DS (L_AV + 3 * MF_NPAD)        // 16*17 (+ pad to 288) diagonal-tile hand-over scratch
+#define L_FLAG (L_DS + 288)              // 2     ints: [0] not-SPD, [1] ready, [2] tile_ready
 #define L_LINV (L_FLAG + 2)              // 16*256 L_kk^-1, operand layout
-#define L_PANP (L_LINV + 16 * 256)       // 16*256 panel L_ik, operand layout (also the predict reduction buffer: 8*4*256)
-#define L_TOTAL (L_PANP + 32 * 256)      // doubles
+#define L_LINVT (L_LINV + 16 * 256)      // 16*256 L_kk^-T, operand layout (backward solve)
+#define L_PANP (L_LINVT + 16 * 256)      // 2 x 16*256 panel L_ik, operand layout, double-buffered by k & 1 (also the
+                                         // predict reduction buffer: 8*4*256)
+#define L_TOTAL (L_PANP + 32 * 256)      // doubles  (158.8 KB)
 
 // The kernel is fully unrolled over tile slots, and every slot has its own lane-dependent LDS addresses.  hipcc
-// hoists all of that loop-invariant address arithmetic out of the patch loop and keeps it in registers (hundreds
-// of VGPRs, hence scratch spills).  Passing the lane id through an empty asm inside each slot body makes the
-// addresses cheap-to-recompute values the compiler cannot hoist: one or two extra VALU ops per use, no spills.
+// hoists such loop-invariant address arithmetic out of the surrounding loops and keeps it in registers.  Passing the
+// lane id through an empty asm inside each slot body makes the addresses cheap-to-recompute values the compiler
+// cannot hoist: one or two extra VALU ops per use instead of a register each.
 __device__ static __forceinline__ int mf_opaque(int v)
 {
     asm volatile("" : "+v"(v));
     return v;
 }
 
-__device__ static inline double mf_readlane(double v, int lane_const)
+// Spin until *word >= k (an LDS word published with release semantics by another wave of the workgroup).
+// Written as ONE asm statement on purpose: as a C loop it puts a cycle into the CFG of the fully unrolled step body
+// and hipcc's register allocator answers with ~100 spilled accumulator registers.  All lanes read the same word.
+__device__ static __forceinline__ void mf_wait_ge(const int* word, int k)
+{
+    int v;
+    asm volatile(
+        "1:\n\t"
+        "flat_load_dword %0, %1 sc0\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        "v_cmp_gt_i32 vcc, %2, %0\n\t"
+        "s_cbranch_vccz 2f\n\t"
+        "s_sleep 1\n\t"
+        "s_branch 1b\n\t"
+        "2:\n\t"
+        : "=&v"(v)
+        : "v"(word), "v"(k)
+        : "vcc", "memory");
+}
+__device__ static __forceinline__ void mf_publish(int* word, int k)
+{
+    __hip_atomic_store(word, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ static __forceinline__ double mf_readlane(double v, int lane_const)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane_const);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane_const);
     return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(d) to fp64 accuracy: v_rsq_f64 seed + two Newton steps
-__device__ static inline double mf_rsqrt(double d)
+// 1/sqrt(d) and 1/d to fp64 accuracy: hardware seed + two Newton steps
+__device__ static __forceinline__ double mf_rsqrt(double d)
 {
     double y = __builtin_amdgcn_rsq(d);
     double e = __builtin_fma(-d * y, y, 1.0);
     y = __builtin_fma(y * 0.5, e, y);
     e = __builtin_fma(-d * y, y, 1.0);
     y = __builtin_fma(y * 0.5, e, y);
-    e = __builtin_fma(-d * y, y, 1.0);
-    y = __builtin_fma(y * 0.5, e, y);
+    return y;
+}
+__device__ static __forceinline__ double mf_rcp(double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
     return y;
 }
 
-// Inverse Cholesky factor of the 16 x 16 SPD tile in S (row stride 17): forward elimination on [A | I] gives
-// [L^T | L^-1].  One wave; lane j < 16 holds column j of A, lane 16 + j column j of I (lanes 32..63 mirror them).
-// Writes L^-1 in operand layout (element (r, c) at (r + 16 (c & 3)) * 4 + (c >> 2)) and raises *flag on a pivot <= 0.
-__device__ __forceinline__ static void mf_diag_factor(const double* S, double* Linv_out, int* flag, double pivot_tol)
+// Inverse Cholesky factor of the 16 x 16 SPD tile in S (row stride 17).  Square-root-free forward elimination on
+// [A | I] gives [D Lu^T | Lu^-1] with Lu unit lower triangular; L^-1 = D^-1/2 Lu^-1.  Only the reciprocal of the
+// pivot sits on the dependency chain, the 16 reciprocal square roots are independent of each other.
+// One wave; lane j < 16 holds column j of A, lane 16 + j column j of I (lanes 32..63 mirror them); the multipliers
+// are wave-uniform (v_readlane).  Writes L^-1 and L^-T in operand layout (element (r, c) of the stored matrix at
+// (r + 16 (c & 3)) * 4 + (c >> 2)) and returns false when a pivot is <= pivot_tol.
+__device__ __forceinline__ static bool mf_diag_factor(const double* S, double* Linv_out, double* LinvT_out, double pivot_tol)
 {
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
@@ -125,28 +169,43 @@ __device__ __forceinline__ static void mf_diag_factor(const double* S, double* L
     for (int c = 0; c < MF_TS; ++c) {
         const double d = mf_readlane(reg[c], c);
         ok = ok && (d > pivot_tol);
-        const double rs = mf_rsqrt(d);
-        reg[c] *= rs;
-#pragma unroll
-        for (int i = c + 1; i < MF_TS; ++i) {
-            const double mlt = mf_readlane(reg[i], c) * rs;
-            reg[i] = __builtin_fma(-mlt, reg[c], reg[i]);
-        }
+        const double prow = reg[c] * mf_rcp(d);       // pivot row / pivot
+        reg[c] *= mf_rsqrt(d);                         // row c is final: row c of L^-1 = row c of Lu^-1 / sqrt(d_c)
+#pragma unroll                                         // (off the dependency chain: nothing below reads reg[c])
+        for (int i = c + 1; i < MF_TS; ++i) reg[i] = __builtin_fma(-mf_readlane(reg[i], c), prow, reg[i]);
     }
-    if (!ok && lane == 0) *flag = 1;
     if ((lane >> 4) == 1) {
 #pragma unroll
-        for (int i = 0; i < MF_TS; ++i) Linv_out[(i + 16 * (j & 3)) * 4 + (j >> 2)] = reg[i];
+        for (int i = 0; i < MF_TS; ++i) Linv_out[(i + 16 * (j & 3)) * 4 + (j >> 2)] = reg[i];   // (r = i, c = j)
+        // L^-T: element (r = j, c = i) = Linv[i][j]: for fixed j the four i = g, g+4, g+8, g+12 are contiguous
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<d4*>(LinvT_out + (j + 16 * gq) * 4) = d4{reg[gq], reg[gq + 4], reg[gq + 8], reg[gq + 12]};
     }
+    return ok;
+}
+
+// out[mr] = sum_kk M[mr][kk] * v[kk] for a 16 x 16 matrix stored as an operand image (row mr = 4 chunks of 4 doubles
+// at (mr + 16 g) * 4, holding k = g, g+4, g+8, g+12), one thread per row.
+__device__ static __forceinline__ double mf_row_dot(const double* img, int mr, const double* v)
+{
+    const double* Pr = img + mr * 4;
+    double s_ = 0.0;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const d4 ch = *reinterpret_cast<const d4*>(Pr + gq * 64);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) s_ = __builtin_fma(ch[s], v[gq + 4 * s], s_);
+    }
+    return s_;
 }
 
 // ---- slot dispatch ----------------------------------------------------------------------------------------
 // Tiles are enumerated column-major over the lower triangle (idx = cs(j) + i - j, cs(j) = j NT - j (j-1)/2) and
-// dealt round-robin: wave w owns idx = 8 t + w in register slot t.  Every phase works on a contiguous idx range,
-// i.e. on a contiguous slot range [t_lo, t_hi] of each wave, entered through a fall-through switch so that the
-// scalar unit does not scan the dead slots (17 slots x 3 phases x 16 steps of compare-and-branch cost more than the
-// MFMAs of the late steps).
-#define MF_SLOTS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+// dealt round-robin to the 7 workers: worker w owns idx = 7 t + w in register slot t.  Every phase works on a
+// contiguous idx range, i.e. on a contiguous slot range [t_lo, t_hi] of each worker; every slot body is guarded by one
+// scalar range test.  (A fall-through switch into the unrolled bodies was tried: it wrecks register allocation.)
+#define MF_SLOTS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19)
 __device__ static __forceinline__ int mf_cs(int j, int nt_full) { return j * nt_full - (j * (j - 1)) / 2; }
 
 template <int CTRL>
@@ -170,8 +229,8 @@ template <int NT>
 __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 {
     constexpr int NTILES = NT * (NT + 1) / 2;
-    constexpr int TPW = (NTILES + MF_WAVES - 1) / MF_WAVES;
-    static_assert(TPW <= 17, "MF_SLOTS covers 17 slots");
+    constexpr int TPW = (NTILES + MF_WORKERS - 1) / MF_WORKERS;
+    static_assert(TPW <= 20, "MF_SLOTS covers 20 slots");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     double* T = lds + L_EXP;
@@ -179,217 +238,222 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     double* px1 = lds + L_PX1;
     double* yc = lds + L_YC;
     double* zv = lds + L_ZV;
-    double* wpart = lds + L_WV;
+    double* wsum = lds + L_WV;
     double* av = lds + L_AV;
     double* DS = lds + L_DS;
-    int* flag = reinterpret_cast<int*>(lds + L_FLAG);
+    int* flag = reinterpret_cast<int*>(lds + L_FLAG);   // [0] not-SPD
+    int* ready = flag + 1;        // highest tile column whose L_kk^-1, z_k (and y_k) are published by the factor wave
+    int* tile_ready = flag + 2;   // highest diagonal tile handed over to the factor wave
     double* Linv = lds + L_LINV;
-    double* panP = lds + L_PANP;
+    double* LinvT = lds + L_LINVT;
+    double* panBase = lds + L_PANP;
 
     const DenseArgs& A = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ny = A.ny, m = A.m;
+    const bool is_factor = wave == MF_FACTOR_WAVE;
+    const int ny = __builtin_amdgcn_readfirstlane(A.ny), m = A.m;
     const double sf = A.prm.sigmaf_sq, cexp = g.c_exp, noise = A.prm.noise;
 
-    // tile coordinates of this wave's slots (wave-uniform, SGPRs)
+    // tile coordinates of this worker's slots (wave-uniform, SGPRs)
     int tij[TPW];
 #define ti_(t) (tij[t] & 255)
 #define tj_(t) (tij[t] >> 8)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int idx = t * MF_WAVES + wave;
+        const int idx = t * MF_WORKERS + wave;
         int jj = 0;
 #pragma unroll
         for (int j = 1; j < NT; ++j)
             if (idx >= j * NT - (j * (j - 1)) / 2) jj = j;
         const int ii = jj + idx - (jj * NT - (jj * (jj - 1)) / 2);
-        tij[t] = __builtin_amdgcn_readfirstlane((idx < NTILES) ? (ii | (jj << 8)) : (255 | (255 << 8)));
+        tij[t] = __builtin_amdgcn_readfirstlane((idx < NTILES && !is_factor) ? (ii | (jj << 8)) : (255 | (255 << 8)));
     }
 
     gpc_exp_table_init(T);
     MF_STAMP_DECL
 
     // one workgroup per patch, straight-line (a persistent patch loop makes hipcc hoist hundreds of lane-dependent
-    // LDS addresses out of it and spill 1.8 KB/lane; the block hand-over costs ~1-2 us against >100 us of work)
+    // LDS addresses out of it and spill; the block hand-over costs ~1-2 us against ~100 us of work)
     do {
         const int patch = blockIdx.x;
-        const int o = A.off[patch];
-        const int n = A.off[patch + 1] - o;
+        // wave-uniform by construction, but loaded through the vector memory path: without readfirstlane hipcc treats n
+        // (and every `ti < nt` test derived from it) as divergent and lowers the slot guards to EXEC-masked code
+        const int o = __builtin_amdgcn_readfirstlane(A.off[patch]);
+        const int n = __builtin_amdgcn_readfirstlane(A.off[patch + 1]) - o;
         double* fs = A.f_star + (size_t)patch * ny * m;
         if (n <= 0 || n > NT * MF_TS) {
             for (int p = tid; p < m * ny; p += MF_THREADS) fs[p] = (n == 0) ? 0.0 : __builtin_nan("");
             if (tid == 0 && A.status) A.status[patch] = (n == 0) ? GPC_STATUS_OK : GPC_STATUS_NAN;
             continue;
         }
-        const int nt = (n + MF_TS - 1) / MF_TS;   // live tile rows
+        const int nt = __builtin_amdgcn_readfirstlane((n + MF_TS - 1) / MF_TS);   // live tile rows
         for (int i = tid; i < NT * MF_TS; i += MF_THREADS) {
             const bool live = i < n;
             px0[i] = live ? A.x0[o + i] : 0.0;
             px1[i] = live ? A.x1[o + i] : 0.0;
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                if (c < ny) yc[c * MF_NPAD + i] = live ? A.y[(size_t)c * A.n_total + o + i] : 0.0;
-        }
-        if (tid == 0) *flag = 0;
-        __syncthreads();
-
-        // ---- Gram tiles, transposed: acc[t][r] = K[16 i + (l&15)][16 j + (l>>4) + 4 r]; padding = identity ----
-        d4 acc[TPW];
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-            if (ti_(t) < nt) {
-                const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                const int pi = MF_TS * ti_(t) + lr;
-                const double xi0 = px0[pi], xi1 = px1[pi];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pj = MF_TS * tj_(t) + lg + 4 * r;
-                    double v = gpc_rbf(sf, cexp, xi0, xi1, px0[pj], px1[pj], T);
-                    if (pi == pj) {
-                        v += noise;                              // covariance_matrix(..., training)  :59-61
-                        if (A.prm.ref_double_noise) v += noise;  // C.diagonal() += sigman_sq        :21
-                    }
-                    if (pi >= n || pj >= n) v = (pi == pj) ? 1.0 : 0.0;
-                    acc[t][r] = v;
+            for (int c = 0; c < 3; ++c) {
+                if (c < ny) {
+                    yc[c * MF_NPAD + i] = live ? A.y[(size_t)c * A.n_total + o + i] : 0.0;
+                    wsum[c * MF_NPAD + i] = 0.0;
                 }
             }
         }
-        MF_STAMP(0);
+        if (tid == 0) {
+            flag[0] = 0;
+            flag[1] = -1;
+            flag[2] = -1;
+        }
+        __syncthreads();
 
-        // ---- right-looking tiled Cholesky, forward solve riding along ----
-        // Iteration k: [B1] z_k and the TRSM of tile column k [B2] y update, trailing update with panel k.  In the
-        // update the tile (k+1, k+1) goes first and its owner factors it at once (the only inlined copy of
-        // mf_diag_factor), so that the serial 16 x 16 factorisation overlaps the other waves' MFMAs.  k = -1 is the
-        // virtual step that only factors tile (0, 0).
-        bool bad = false;
-        for (int k = -1; k < nt; ++k) {
-            if (k >= 0) {
-                __syncthreads();   // B1: L_kk^-1 published, step k-1 updates finished (panel free to overwrite)
-                MF_STAMP(1);
-                if (*flag) { bad = true; break; }
-                // z_k = L_kk^-1 y_k (y_k already carries -sum_{j<k} L_kj z_j): 16 row-threads of one wave
-                if (wave == (k & 7) && lane < 16) {
-                    const double* Lr = Linv + k * 256 + lane * 4;          // row `lane`: 4 chunks of 4 (k = g + 4 s)
-                    d4 ch[4];
+        d4 acc[TPW];   // worker waves only; never live on the factor wave's path through the factorisation
+        if (!is_factor) {
+            // ================================ WORKER ROLE ================================
+            // ---- Gram tiles, transposed: acc[t][r] = K[16 i + (l&15)][16 j + (l>>4) + 4 r]; padding = identity ----
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) ch[gq] = *reinterpret_cast<const d4*>(Lr + gq * 64);
+            for (int t = 0; t < TPW; ++t) {
+                acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+                if (ti_(t) < nt) {
+                    const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
+                    const int pi = MF_TS * ti_(t) + lr;
+                    const double xi0 = px0[pi], xi1 = px1[pi];
+                    const bool edge = MF_TS * ti_(t) + MF_TS > n;   // tile touches the identity padding (wave-uniform)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        if (c < ny) {
-                            const double* yk = yc + c * MF_NPAD + MF_TS * k;
-                            double s_ = 0.0;
-#pragma unroll
-                            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                                for (int s = 0; s < 4; ++s) s_ = __builtin_fma(ch[gq][s], yk[gq + 4 * s], s_);
-                            zv[c * MF_NPAD + MF_TS * k + lane] = s_;
+                    for (int r = 0; r < 4; ++r) {
+                        const int pj = MF_TS * tj_(t) + lg + 4 * r;
+                        double v = gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T);
+                        if (pi == pj) {
+                            v += noise;                              // covariance_matrix(..., training)  :59-61
+                            if (A.prm.ref_double_noise) v += noise;  // C.diagonal() += sigman_sq        :21
                         }
+                        if (edge && (pi >= n || pj >= n)) v = (pi == pj) ? 1.0 : 0.0;
+                        acc[t][r] = v;
                     }
                 }
-                // panel TRSM: L_ik^T = L_kk^-1 * T_ik  (A operand = L_kk^-1 from LDS, B operand = the accumulator itself)
+            }
+            // tile (0, 0) goes to the factor wave at once
+            if (wave == 0) {
+                const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) DS[(lg + 4 * r) * 17 + lr] = acc[0][r];
+                mf_publish(tile_ready, 0);
+            }
+            MF_STAMP(0);
+
+            // ---- right-looking tiled Cholesky ----
+            // step k:  wait for L_kk^-1 | TRSM of tile column k -> panel buffer k&1 | B2 | update with panel k: the next
+            // diagonal tile first (handed to the factor wave at once), then the forward-solve rows, then the rest.
+            for (int k = 0; k < nt; ++k) {
+                double* panP = panBase + (k & 1) * (16 * 256);
+                mf_wait_ge(ready, k);
+                MF_STAMP(1);
+                if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                 {
                     const int lo_ = mf_cs(k, NT) + 1 - wave, hi_ = mf_cs(k + 1, NT) - 1 - wave;
-                    const int t_lo = (lo_ + 7) >> 3, t_hi = hi_ >> 3;
+                    const int t_lo = __builtin_amdgcn_readfirstlane((lo_ + 6) / 7);
+                    const int t_hi = __builtin_amdgcn_readfirstlane((hi_ + 7) / 7 - 1);
                     if (t_lo <= t_hi) {
                         const d4 lv = *reinterpret_cast<const d4*>(Linv + k * 256 + mf_opaque(lane) * 4);
-                        switch (t_lo) {
 #define MF_TRSM_CASE(t)                                                                                              \
-    case t:                                                                                                          \
-        if constexpr (t < TPW) {                                                                                     \
-            if (t > t_hi) break;                                                                                     \
-            if (ti_(t) < nt) {                                                                                       \
-                d4 D1 = d4{0.0, 0.0, 0.0, 0.0}, D2 = d4{0.0, 0.0, 0.0, 0.0};                                         \
-                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], acc[t][0], D1, 0, 0, 0);                            \
-                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], acc[t][2], D2, 0, 0, 0);                            \
-                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], acc[t][1], D1, 0, 0, 0);                            \
-                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], acc[t][3], D2, 0, 0, 0);                            \
-                acc[t] = D1 + D2; /* = L_ik[l & 15][(l>>4) + 4 r] */                                                 \
-                *reinterpret_cast<d4*>(panP + ti_(t) * 256 + mf_opaque(lane) * 4) = acc[t];                          \
-            }                                                                                                        \
+    if constexpr (t < TPW) {                                                                                         \
+        if (t >= t_lo && t <= t_hi && ti_(t) < nt) {                                                                 \
+            d4 D1 = d4{0.0, 0.0, 0.0, 0.0}, D2 = d4{0.0, 0.0, 0.0, 0.0};                                             \
+            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], acc[t][0], D1, 0, 0, 0);                                \
+            D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], acc[t][2], D2, 0, 0, 0);                                \
+            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], acc[t][1], D1, 0, 0, 0);                                \
+            D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], acc[t][3], D2, 0, 0, 0);                                \
+            acc[t] = D1 + D2; /* = L_ik[l & 15][(l>>4) + 4 r] */                                                     \
+            *reinterpret_cast<d4*>(panP + ti_(t) * 256 + mf_opaque(lane) * 4) = acc[t];                              \
         }                                                                                                            \
-        [[fallthrough]];
-                            MF_SLOTS(MF_TRSM_CASE)
-                            default: break;
-                        }
+    }
+                        MF_SLOTS(MF_TRSM_CASE)
                     }
                 }
                 MF_STAMP(2);
-                __syncthreads();   // B2: panel k and z_k complete
+                __syncthreads();   // B2(k): panel k complete; every wave has left update phase k-1
                 MF_STAMP(3);
-            }
-            // pass 1: the next diagonal tile: T_(k+1)(k+1) -= L_(k+1)k L_(k+1)k^T, then straight to the factor scratch
-            if (k + 1 < nt) {
-                const int idx1 = mf_cs(k + 1, NT);
-                if (wave == (idx1 & 7)) {
-                    const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                    switch (idx1 >> 3) {
+                // the next diagonal tile: T_(k+1)(k+1) -= L_(k+1)k L_(k+1)k^T, then straight to the factor wave
+                if (k + 1 < nt) {
+                    const int idx1 = __builtin_amdgcn_readfirstlane(mf_cs(k + 1, NT));
+                    if (wave == idx1 % MF_WORKERS) {
+                        const int slot1 = idx1 / MF_WORKERS;
+                        const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
+                        const d4 a = *reinterpret_cast<const d4*>(panP + (k + 1) * 256 + ln * 4);
 #define MF_DIAG_CASE(t)                                                                                              \
-    case t:                                                                                                          \
-        if constexpr (t < TPW) {                                                                                     \
-            if (k >= 0) {                                                                                            \
-                const d4 a = *reinterpret_cast<const d4*>(panP + (k + 1) * 256 + ln * 4);                            \
-                /* blgp = 1 on the f64 MFMA is NEG(A): acc - a*b  (tools/probe_mfma_f64.hip) */                      \
-                _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                        \
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], a[s], acc[t], 0, 0, 1);                      \
-            }                                                                                                        \
+    if constexpr (t < TPW) {                                                                                         \
+        if (t == slot1) {                                                                                            \
+            /* blgp = 1 on the f64 MFMA is NEG(A): acc - a*b  (tools/probe_mfma_f64.hip) */                          \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                            \
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], a[s], acc[t], 0, 0, 1);                          \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) DS[(lg + 4 * r) * 17 + lr] = acc[t][r];                    \
         }                                                                                                            \
-        break;
+    }
                         MF_SLOTS(MF_DIAG_CASE)
-                        default: break;
-                    }
-                    MF_STAMP(4);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    mf_diag_factor(DS, Linv + (k + 1) * 256, flag, g.pivot_tol);
-                    MF_STAMP(5);
-                }
-            }
-            if (k >= 0) {
-                // forward solve: y_i -= L_ik z_k for the panel rows, one thread per matrix row, operands from LDS
-                if (tid < MF_TS * (nt - 1 - k)) {
-                    const int i = k + 1 + (tid >> 4), mr = tid & 15;
-                    const double* Pr = panP + i * 256 + mr * 4;
-                    d4 ch[4];
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) ch[gq] = *reinterpret_cast<const d4*>(Pr + gq * 64);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        if (c < ny) {
-                            const double* zk = zv + c * MF_NPAD + MF_TS * k;
-                            double s_ = 0.0;
-#pragma unroll
-                            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                                for (int s = 0; s < 4; ++s) s_ = __builtin_fma(ch[gq][s], zk[gq + 4 * s], s_);
-                            yc[c * MF_NPAD + MF_TS * i + mr] -= s_;
-                        }
+                        mf_publish(tile_ready, k + 1);
                     }
                 }
-                // pass 2: the rest of the trailing matrix, T_ij -= L_jk L_ik^T  (idx > cs(k+1))
-                const int t_first = (mf_cs(k + 1, NT) + 1 - wave + 7) >> 3;
-                switch (t_first) {
+                MF_STAMP(4);
+                // forward solve rows the factor wave does not need first: y_i -= L_ik z_k, i >= k+2, one thread per row
+                if (tid < MF_TS * (nt - 2 - k)) {
+                    const int i = k + 2 + (tid >> 4), mr = tid & 15;
+                    for (int c = 0; c < ny; ++c)
+                        yc[c * MF_NPAD + MF_TS * i + mr] -= mf_row_dot(panP + i * 256, mr, zv + c * MF_NPAD + MF_TS * k);
+                }
+                MF_STAMP(5);
+                // the rest of the trailing matrix, T_ij -= L_jk L_ik^T  (idx > cs(k+1))
+                {
+                    const int t_first = __builtin_amdgcn_readfirstlane((mf_cs(k + 1, NT) + 1 - wave + 6) / 7);
 #define MF_UPD_CASE(t)                                                                                               \
-    case t:                                                                                                          \
-        if constexpr (t < TPW) {                                                                                     \
-            if (ti_(t) < nt) {                                                                                       \
-                const int ln4 = mf_opaque(lane) * 4;                                                                 \
-                const d4 a = *reinterpret_cast<const d4*>(panP + tj_(t) * 256 + ln4);                                \
-                const d4 b = *reinterpret_cast<const d4*>(panP + ti_(t) * 256 + ln4);                                \
-                _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                        \
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc[t], 0, 0, 1);                      \
-            }                                                                                                        \
+    if constexpr (t < TPW) {                                                                                         \
+        if (t >= t_first && ti_(t) < nt) {                                                                           \
+            const int ln4 = mf_opaque(lane) * 4;                                                                     \
+            const d4 a = *reinterpret_cast<const d4*>(panP + tj_(t) * 256 + ln4);                                    \
+            const d4 b = *reinterpret_cast<const d4*>(panP + ti_(t) * 256 + ln4);                                    \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                            \
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc[t], 0, 0, 1);                          \
         }                                                                                                            \
-        [[fallthrough]];
+    }
                     MF_SLOTS(MF_UPD_CASE)
-                    default: break;
                 }
+                MF_STAMP(6);
             }
-            MF_STAMP(6);
+        } else {
+            // ================================ FACTOR ROLE ================================
+            // produces L_jj^-1, L_jj^-T, z_j for j = 0 .. nt-1 and the forward-solve rows of block j; joins B2(k)
+            MF_STAMP(0);
+            for (int j = 0; j < nt; ++j) {
+                const int k = j - 1;                                  // the panel this tile was last updated with
+                if (k >= 0) {
+                    MF_STAMP(1);
+                    __syncthreads();                                  // B2(k)
+                    MF_STAMP(3);
+                    // y_j -= L_jk z_k (rows of block j; the workers do blocks >= j+1)
+                    if (lane < 16) {
+                        const double* panP = panBase + (k & 1) * (16 * 256);
+                        for (int c = 0; c < ny; ++c)
+                            yc[c * MF_NPAD + MF_TS * j + lane] -= mf_row_dot(panP + j * 256, lane, zv + c * MF_NPAD + MF_TS * k);
+                    }
+                }
+                mf_wait_ge(tile_ready, j);
+                MF_STAMP(4);
+                const bool ok = mf_diag_factor(DS, Linv + j * 256, LinvT + j * 256, g.pivot_tol);
+                MF_STAMP(5);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                // z_j = L_jj^-1 y_j  (y_j already carries -sum_{i<j} L_ji z_i): 16 row-threads
+                if (lane < 16)
+                    for (int c = 0; c < ny; ++c)
+                        zv[c * MF_NPAD + MF_TS * j + lane] = mf_row_dot(Linv + j * 256, lane, yc + c * MF_NPAD + MF_TS * j);
+                if (!ok && lane == 0) flag[0] = 1;
+                mf_publish(ready, j);
+                MF_STAMP(2);
+                if (!ok) break;                                       // the workers leave at step j as well
+            }
+            if (!__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) __syncthreads();   // B2(nt-1)
         }
+        __syncthreads();
+        const bool bad = flag[0] != 0;
         if (bad) {
-            __syncthreads();
             for (int p = tid; p < m * ny; p += MF_THREADS) fs[p] = __builtin_nan("");
             if (A.alpha_out)
                 for (int i = tid; i < n * ny; i += MF_THREADS)
@@ -400,50 +464,56 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         MF_STAMP(7);
 
         // ---- backward solve L^T alpha = z, tile columns from the last to the first ----
-        // alpha_k = L_kk^-T (z_k - sum_{i>k} L_ik^T alpha_i).  The column-k tiles sit in registers as
-        // L_ik[l&15][(l>>4)+4r]: each wave sums its tiles' products in registers, reduces over the 16 lanes of a DPP
-        // row (row_ror, no LDS), and publishes one 16-vector per channel; one wave finishes alpha_k.
+        // alpha_k = L_kk^-T (z_k - w_k),  w_k = sum_{i>k} L_ik^T alpha_i.  The column-k tiles sit in the workers'
+        // registers as L_ik[l&15][(l>>4)+4r]: each worker sums its tiles' products in registers, reduces over the 16
+        // lanes of a DPP row (row_ror, no LDS traffic) and adds the 16-vector into w_k with ds_add_f64; the factor
+        // wave then finishes alpha_k with 4 MFMAs on the L_kk^-T image the diagonal factorisation left in LDS.
         for (int k = nt - 1; k >= 0; --k) {
-            const int lo_ = mf_cs(k, NT) + 1 - wave, hi_ = mf_cs(k + 1, NT) - 1 - wave;
-            const int t_lo = (lo_ + 7) >> 3, t_hi = hi_ >> 3;
-            for (int c = 0; c < ny; ++c) {      // one channel at a time keeps the register footprint at 4 doubles
-                const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                d4 pa = d4{0.0, 0.0, 0.0, 0.0};
+            if (!is_factor) {
+                const int lo_ = mf_cs(k, NT) + 1 - wave, hi_ = mf_cs(k + 1, NT) - 1 - wave;
+                const int t_lo = __builtin_amdgcn_readfirstlane((lo_ + 6) / 7);
+                const int t_hi = __builtin_amdgcn_readfirstlane((hi_ + 7) / 7 - 1);
                 if (t_lo <= t_hi) {
-                    const double* avc = av + c * MF_NPAD + lr;
-                    switch (t_lo) {
+                    for (int c = 0; c < ny; ++c) {      // one channel at a time keeps the register footprint at 4 doubles
+                        const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
+                        d4 pa = d4{0.0, 0.0, 0.0, 0.0};
+                        const double* avc = av + c * MF_NPAD + lr;
 #define MF_BWD_CASE(t)                                                                                               \
-    case t:                                                                                                          \
-        if constexpr (t < TPW) {                                                                                     \
-            if (t > t_hi) break;                                                                                     \
-            if (ti_(t) < nt) pa += acc[t] * avc[MF_TS * ti_(t)];                                                     \
-        }                                                                                                            \
-        [[fallthrough]];
+    if constexpr (t < TPW) {                                                                                         \
+        if (t >= t_lo && t <= t_hi && ti_(t) < nt) pa += acc[t] * avc[MF_TS * ti_(t)];                               \
+    }
                         MF_SLOTS(MF_BWD_CASE)
-                        default: break;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) pa[s] = mf_row_allsum(pa[s]);
+                        if (lr == 0) {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) atomicAdd(wsum + c * MF_NPAD + MF_TS * k + lg + 4 * s, pa[s]);
+                        }
                     }
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) pa[s] = mf_row_allsum(pa[s]);
-                }
-                if (lr == 0) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) wpart[(wave * 3 + c) * 16 + lg + 4 * s] = pa[s];
                 }
             }
             __syncthreads();
-            if (wave == (k & 7)) {
-                // lane c' < 16: u[c'] = z_k[c'] - w_k[c'];  alpha_k[c'] = sum_m Linv[m][c'] u[m]
-                const int cc = mf_opaque(lane) & 15;
-                const double* Lc = Linv + k * 256 + (16 * (cc & 3)) * 4 + (cc >> 2);
-                for (int c = 0; c < ny; ++c) {
-                    double w_ = 0.0;
+            if (is_factor) {
+                // alpha_k = L_kk^-T u as one 16x16x16 MFMA product: column n < ny of the B operand carries u of channel n
+                const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
+                const d4 lt = *reinterpret_cast<const d4*>(LinvT + k * 256 + ln * 4);
+                d4 ub = d4{0.0, 0.0, 0.0, 0.0};
+                if (lr < ny) {
 #pragma unroll
-                    for (int w8 = 0; w8 < MF_WAVES; ++w8) w_ += wpart[(w8 * 3 + c) * 16 + cc];
-                    const double u = zv[c * MF_NPAD + MF_TS * k + cc] - w_;
-                    double a_ = 0.0;
+                    for (int s = 0; s < 4; ++s) {
+                        const int q = lr * MF_NPAD + MF_TS * k + lg + 4 * s;
+                        ub[s] = zv[q] - wsum[q];
+                    }
+                }
+                d4 D1 = d4{0.0, 0.0, 0.0, 0.0}, D2 = d4{0.0, 0.0, 0.0, 0.0};
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], ub[0], D1, 0, 0, 0);
+                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], ub[2], D2, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], ub[1], D1, 0, 0, 0);
+                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], ub[3], D2, 0, 0, 0);
+                const d4 al = D1 + D2;              // lanes lr = n < ny: alpha_n[16 k + (l>>4) + 4 r]
+                if (lr < ny) {
 #pragma unroll
-                    for (int mm = 0; mm < MF_TS; ++mm) a_ = __builtin_fma(Lc[mm * 4], mf_readlane(u, mm), a_);
-                    if (lane < 16) av[c * MF_NPAD + MF_TS * k + cc] = a_;
+                    for (int r = 0; r < 4; ++r) av[lr * MF_NPAD + MF_TS * k + lg + 4 * r] = al[r];
                 }
             }
             __syncthreads();
@@ -461,7 +531,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             const int lr = lane & 15, lg = lane >> 4;
             const int sz = A.grid_sz;
             const double res = A.grid_res;
-            double* red = panP;   // 8 waves x 4 tiles x 256 doubles = 64 KB: aliases the (dead) panels
+            double* red = panBase;   // 8 waves x 4 tiles x 256 doubles = 64 KB: aliases the (dead) panel buffers
             double ea[2][8], eb[2][8];
             const int ibase = 32 * wave;
             const bool wave_live = ibase < n;
@@ -475,8 +545,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         const int i = ibase + 4 * s + lg;
                         const bool on = (pq < sz) && (i < n);
                         const double dy = gq - px1[i], dx = gq - px0[i];
-                        ea[h][s] = on ? gpc_exp_tbl(cexp * (dy * dy), T) : 0.0;   // Ey[py = pq][i]
-                        eb[h][s] = on ? gpc_exp_tbl(cexp * (dx * dx), T) : 0.0;   // Ex[px = pq][i]
+                        ea[h][s] = on ? gpc_exp_neg(cexp * (dy * dy), T) : 0.0;   // Ey[py = pq][i]
+                        eb[h][s] = on ? gpc_exp_neg(cexp * (dx * dx), T) : 0.0;   // Ex[px = pq][i]
                     }
                 }
             }
@@ -532,7 +602,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 }
                 double s_[3] = {0.0, 0.0, 0.0};
                 for (int i = 0; i < n; ++i) {
-                    const double kk = gpc_rbf(sf, cexp, px0[i], px1[i], q0, q1, T);
+                    const double kk = gpc_rbf_neg(sf, cexp, px0[i], px1[i], q0, q1, T);
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
                         if (c < ny) s_[c] += kk * av[c * MF_NPAD + i];
@@ -588,26 +658,29 @@ int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a)
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
             (void)hipFree(d);
-            static const char* names[MF_NPH] = {"load+gram", "wait_B1", "z+trsm", "wait_B2", "pass1(diag tile upd)", "diag_factor",
-                                                "yupd+pass2(update)", "post-loop", "backward", "predict", "-", "-"};
-            fprintf(stderr, "[MF_STAMPS] mean cycles per patch, by wave (s_memtime ticks):\n%-22s", "phase");
+            static const char* names[MF_NPH] = {"load+gram", "wait ready | B2 (factor)", "trsm | z+publish (factor)", "wait B2 | y_j (factor)",
+                                                "diag tile upd | wait tile (factor)", "y rows | diag factor (factor)", "trailing update",
+                                                "post-loop", "backward", "predict", "-", "-"};
+            fprintf(stderr, "[MF_STAMPS] mean cycles per patch, by wave (s_memtime ticks); wave 7 is the factor wave:\n%-36s", "phase");
             for (int w = 0; w < MF_WAVES; ++w) fprintf(stderr, "   wave%d", w);
-            fprintf(stderr, "     mean\n");
-            double tot = 0;
+            fprintf(stderr, "\n");
             for (int q = 0; q < 10; ++q) {
-                fprintf(stderr, "%-22s", names[q]);
-                double rowsum = 0;
+                fprintf(stderr, "%-36s", names[q]);
                 for (int w = 0; w < MF_WAVES; ++w) {
                     double s_ = 0;
                     for (int b = 0; b < grid; ++b) s_ += (double)h[((size_t)b * MF_WAVES + w) * MF_NPH + q];
-                    s_ /= grid;
-                    rowsum += s_;
-                    fprintf(stderr, " %7.0f", s_);
+                    fprintf(stderr, " %7.0f", s_ / grid);
                 }
-                fprintf(stderr, "  %7.0f\n", rowsum / MF_WAVES);
-                tot += rowsum / MF_WAVES;
+                fprintf(stderr, "\n");
             }
-            fprintf(stderr, "%-22s total %.0f ticks per patch\n", "", tot);
+            fprintf(stderr, "%-36s", "total");
+            for (int w = 0; w < MF_WAVES; ++w) {
+                double s_ = 0;
+                for (int b = 0; b < grid; ++b)
+                    for (int q = 0; q < 10; ++q) s_ += (double)h[((size_t)b * MF_WAVES + w) * MF_NPH + q];
+                fprintf(stderr, " %7.0f", s_ / grid);
+            }
+            fprintf(stderr, "\n");
         }
     } dump{ctx, g.stamps, grid};
 #endif

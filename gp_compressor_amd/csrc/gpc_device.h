@@ -52,6 +52,26 @@ __host__ __device__ static inline double gpc_exp_tbl(double x, const double* __r
     return (x != x) ? x : v;
 }
 
+// exp(x) for x <= 0 (the RBF exponent): same algorithm without the upper clamp and the NaN select (a NaN argument
+// still comes out as NaN: r and therefore p are NaN).
+__device__ static inline double gpc_exp_neg(double x, const double* __restrict__ T)
+{
+    const double INV_LN2_64 = 92.332482616893656768;
+    const double LN2_64_HI = 0x1.62e42fef80000p-7;
+    const double LN2_64_LO = 0x1.1cf79abc9e3b4p-42;
+    const double xc = x < -760.0 ? -760.0 : x;
+    const double nd = __builtin_rint(xc * INV_LN2_64);
+    const int n = (int)nd;
+    double r = __builtin_fma(-nd, LN2_64_HI, xc);
+    r = __builtin_fma(-nd, LN2_64_LO, r);
+    double p = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    p = __builtin_fma(r, p, 1.0 / 6.0);
+    p = __builtin_fma(r, p, 0.5);
+    p = __builtin_fma(r * r, p, r);
+    const double t = T[n & (GPC_EXP_TABLE_SIZE - 1)];
+    return __builtin_amdgcn_ldexp(__builtin_fma(t, p, t), n >> 6);
+}
+
 __device__ static inline void gpc_exp_table_init(double* T_lds)
 {
     for (int i = threadIdx.x; i < GPC_EXP_TABLE_SIZE; i += blockDim.x) T_lds[i] = c_gpc_exp_table[i];
@@ -64,6 +84,14 @@ __device__ static inline double gpc_rbf(double sf, double c, double xi0, double 
     double d0 = xi0 - xj0, d1 = xi1 - xj1;
     double sq = d0 * d0 + d1 * d1;
     return sf * gpc_exp_tbl(c * sq, T);
+}
+
+// same with the x <= 0 exponential (c < 0 because l_sq > 0 is checked by the API)
+__device__ static inline double gpc_rbf_neg(double sf, double c, double xi0, double xi1, double xj0, double xj1, const double* T)
+{
+    double d0 = xi0 - xj0, d1 = xi1 - xj1;
+    double sq = d0 * d0 + d1 * d1;
+    return sf * gpc_exp_neg(c * sq, T);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -1,0 +1,476 @@
+// gp_compressor.cpp -- host-side mirror of /root/reference/src/gp_compressor.cpp on top of the C-ABI (include/gpc.h).
+#include "gp_compressor.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <tuple>
+#include <unordered_map>
+
+namespace gpc {
+
+double rbf_kernel::kernel_function(const double xi[2], const double xj[2]) const
+{
+    const double d0 = xi[0] - xj[0], d1 = xi[1] - xj[1];
+    return p_[0] * std::exp(-0.5f / p_[1] * (d0 * d0 + d1 * d1));   // src/rbf_kernel.cpp:17
+}
+
+namespace {
+
+struct VoxelKey {
+    int x, y, z;
+    bool operator==(const VoxelKey& o) const { return x == o.x && y == o.y && z == o.z; }
+    bool operator<(const VoxelKey& o) const { return std::tie(z, y, x) < std::tie(o.z, o.y, o.x); }
+};
+struct VoxelHash {
+    size_t operator()(const VoxelKey& k) const
+    {
+        return (size_t)k.x * 73856093u ^ (size_t)k.y * 19349663u ^ (size_t)k.z * 83492791u;
+    }
+};
+
+// eigenvector of the smallest eigenvalue of a symmetric 4x4 matrix (cyclic Jacobi): the last right singular vector of
+// the k x 4 homogeneous point matrix, which is what JacobiSVD(...).matrixV().col(3) gives (src/gp_compressor.cpp:35-36)
+void smallest_eigvec4(double A[4][4], double v[4])
+{
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double offd = 0;
+        for (int p = 0; p < 4; ++p)
+            for (int q = p + 1; q < 4; ++q) offd += A[p][q] * A[p][q];
+        if (offd < 1e-300) break;
+        for (int p = 0; p < 4; ++p) {
+            for (int q = p + 1; q < 4; ++q) {
+                if (std::fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 4; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+        }
+    }
+    int best = 0;
+    for (int i = 1; i < 4; ++i)
+        if (A[i][i] < A[best][best]) best = i;
+    for (int k = 0; k < 4; ++k) v[k] = V[k][best];
+}
+
+void cross(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+void normalize(double a[3])
+{
+    const double n = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    if (n > 0) { a[0] /= n; a[1] /= n; a[2] /= n; }
+}
+
+void check(int rc, gpc_ctx* ctx, const char* what)
+{
+    if (rc != GPC_OK) throw std::runtime_error(std::string(what) + ": " + (ctx ? gpc_last_error(ctx) : "gpc error") +
+                                               " (code " + std::to_string(rc) + ")");
+}
+
+}  // namespace
+
+gp_compressor::gp_compressor(const pointcloud& ncloud, double res, int sz, gp_model model, int device)
+    : rng([] { return std::rand(); }), cloud_(ncloud), res_(res), sz_(sz), model_(model), device_(device)
+{
+    gpc_default_params_sparse(&depth_params, 1);
+    gpc_default_params_sparse(&rgb_params, 3);
+    gpc_default_params_dense(&dense_params);
+}
+
+gp_compressor::~gp_compressor()
+{
+    if (gps_) gpc_sparse_destroy(gps_);
+    if (rgb_gps_) gpc_sparse_destroy(rgb_gps_);
+    if (ctx_) gpc_ctx_destroy(ctx_);
+}
+
+// src/gp_compressor.cpp:21-27
+void gp_compressor::save_compressed(const std::string& /*name: ignored by the reference too*/)
+{
+    project_cloud();
+    train_processes();
+}
+
+// src/gp_compressor.cpp:29-64
+void gp_compressor::compute_rotation(double R[9], const std::vector<double>& pts4, int k) const
+{
+    auto setcol = [&](int c, const double v[3]) { R[3 * c] = v[0]; R[3 * c + 1] = v[1]; R[3 * c + 2] = v[2]; };
+    if (k < 4) {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        std::memcpy(R, I, sizeof(I));
+        return;
+    }
+    double M[4][4] = {};
+    for (int p = 0; p < k; ++p)
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) M[a][b] += pts4[4 * p + a] * pts4[4 * p + b];
+    double v[4];
+    smallest_eigvec4(M, v);
+    double normal[3] = {v[0], v[1], v[2]};
+    normalize(normal);
+    const double x[3] = {1, 0, 0}, y[3] = {0, 1, 0}, z[3] = {0, 0, 1};
+    double c1[3];
+    const double ax = std::fabs(normal[0]), ay = std::fabs(normal[1]), az = std::fabs(normal[2]);
+    if (ax > ay && ax > az) {            // pointing in x dir
+        if (normal[0] < 0) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
+        cross(z, normal, c1);
+    } else if (ay > ax && ay > az) {     // pointing in y dir
+        if (normal[1] < 0) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
+        cross(x, normal, c1);
+    } else {                             // pointing in z dir
+        if (normal[2] < 0) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
+        cross(y, normal, c1);
+    }
+    normalize(c1);
+    double c2[3];
+    cross(normal, c1, c2);
+    setcol(0, normal);
+    setcol(1, c1);
+    setcol(2, c2);
+}
+
+// src/gp_compressor.cpp:177-249 with project_points (:66-118) inlined per leaf
+void gp_compressor::project_cloud()
+{
+    batch_ = patch_batch();
+    batch_.off.push_back(0);
+    const size_t npts = cloud_.size();
+    if (npts == 0) { projected_ = true; return; }
+    // voxel hash of side res, anchored at the cloud's minimum corner
+    double mn[3] = {cloud_[0].x, cloud_[0].y, cloud_[0].z};
+    for (const point& p : cloud_) {
+        mn[0] = std::min<double>(mn[0], p.x);
+        mn[1] = std::min<double>(mn[1], p.y);
+        mn[2] = std::min<double>(mn[2], p.z);
+    }
+    auto key_of = [&](const point& p) {
+        return VoxelKey{(int)std::floor((p.x - mn[0]) / res_), (int)std::floor((p.y - mn[1]) / res_),
+                        (int)std::floor((p.z - mn[2]) / res_)};
+    };
+    std::unordered_map<VoxelKey, std::vector<int>, VoxelHash> grid;
+    for (size_t i = 0; i < npts; ++i) grid[key_of(cloud_[i])].push_back((int)i);
+    std::vector<VoxelKey> leaves;
+    leaves.reserve(grid.size());
+    for (auto& kv : grid) leaves.push_back(kv.first);
+    std::sort(leaves.begin(), leaves.end());   // deterministic leaf order (the octree's depth-first order is PCL's)
+
+    const double radius = std::sqrt(3.0f) / 2.0f * res_;   // :194, sphere encompassing the voxel
+    std::vector<char> occupied(npts, 0);                   // occupied_indices (:200): exclusive point ownership
+    std::vector<int> index_search;
+    std::vector<double> pts4, cols;
+    const int m = sz_ * sz_;
+    for (const VoxelKey& key : leaves) {
+        const double center[3] = {mn[0] + (key.x + 0.5) * res_, mn[1] + (key.y + 0.5) * res_, mn[2] + (key.z + 0.5) * res_};
+        // radiusSearch(center, radius) (:220): radius < res, so the 27 neighbouring voxels cover the sphere
+        index_search.clear();
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    auto it = grid.find(VoxelKey{key.x + dx, key.y + dy, key.z + dz});
+                    if (it == grid.end()) continue;
+                    for (int idx : it->second) {
+                        const point& p = cloud_[idx];
+                        const double ex = p.x - center[0], ey = p.y - center[1], ez = p.z - center[2];
+                        if (ex * ex + ey * ey + ez * ez <= radius * radius) index_search.push_back(idx);
+                    }
+                }
+        std::sort(index_search.begin(), index_search.end());
+        std::array<double, 9> R{};
+        std::array<double, 3> mid{center[0], center[1], center[2]}, cmean{0, 0, 0};
+        const int k = (int)index_search.size();
+        pts4.assign(4 * (size_t)k, 1.0);
+        cols.assign(3 * (size_t)k, 0.0);
+        for (int q = 0; q < k; ++q) {
+            const point& p = cloud_[index_search[q]];
+            pts4[4 * q] = p.x; pts4[4 * q + 1] = p.y; pts4[4 * q + 2] = p.z;
+            cols[3 * q] = p.r; cols[3 * q + 1] = p.g; cols[3 * q + 2] = p.b;
+        }
+        compute_rotation(R.data(), pts4, k);
+        // project_points (:66-118)
+        const size_t first = batch_.x0.size();
+        std::vector<uint8_t> W(m, 0);
+        double mnd = 0;
+        std::vector<std::array<double, 3>> colours;
+        for (int q = 0; q < k; ++q) {
+            const int gi = index_search[q];
+            if (occupied[gi]) continue;                                         // :81-83
+            const double d[3] = {pts4[4 * q] - mid[0], pts4[4 * q + 1] - mid[1], pts4[4 * q + 2] - mid[2]};
+            double pt[3];
+            for (int a = 0; a < 3; ++a) pt[a] = R[3 * a] * d[0] + R[3 * a + 1] * d[1] + R[3 * a + 2] * d[2];   // R^T d
+            if (pt[1] > res_ / 2.0f || pt[1] < -res_ / 2.0f || pt[2] > res_ / 2.0f || pt[2] < -res_ / 2.0f) continue;   // :85-87
+            mnd += pt[0];
+            occupied[gi] = 1;
+            int gx = (int)((double)sz_ * (pt[1] / res_ + 0.5f)), gy = (int)((double)sz_ * (pt[2] / res_ + 0.5f));     // :90-92
+            gx = std::min(std::max(gx, 0), sz_ - 1);
+            gy = std::min(std::max(gy, 0), sz_ - 1);
+            W[sz_ * gx + gy] = 1;
+            batch_.y.push_back(pt[0]);
+            batch_.x0.push_back(pt[1]);
+            batch_.x1.push_back(pt[2]);
+            colours.push_back({cols[3 * q], cols[3 * q + 1], cols[3 * q + 2]});
+            for (int a = 0; a < 3; ++a) cmean[a] += cols[3 * q + a];
+        }
+        const size_t cnt = batch_.x0.size() - first;
+        if (cnt > 0) {
+            mnd /= (double)cnt;                                                 // :101-107
+            for (int a = 0; a < 3; ++a) cmean[a] /= (double)cnt;
+            for (size_t q = first; q < batch_.y.size(); ++q) batch_.y[q] -= mnd;
+            for (int a = 0; a < 3; ++a) mid[a] += mnd * R[a];                   // center += mn*R.col(0)  (:116)
+        }
+        // colours are appended plane-wise after the loop (3 planes of N); keep them per patch for now
+        for (auto& c : colours)
+            for (int a = 0; a < 3; ++a) batch_.rgb.push_back(c[a] - cmean[a]);   // temporary AoS, re-packed below
+        batch_.off.push_back((int32_t)batch_.x0.size());
+        batch_.rotations.push_back(R);
+        batch_.means.push_back(mid);
+        batch_.rgb_means.push_back(cmean);
+        batch_.W.insert(batch_.W.end(), W.begin(), W.end());
+    }
+    // AoS colours -> 3 planes of N (Eigen column-major n x 3, per the C-ABI layout)
+    const size_t N = batch_.x0.size();
+    std::vector<double> planes(3 * N);
+    for (size_t q = 0; q < N; ++q)
+        for (int a = 0; a < 3; ++a) planes[a * N + q] = batch_.rgb[3 * q + a];
+    batch_.rgb.swap(planes);
+    projected_ = true;
+}
+
+// sparse_gp::shuffle (src/sparse_gp.hpp:43-56): ind[i] <-> ind[rand() % i] for i = n-1 .. 1
+void gp_compressor::shuffle(std::vector<int32_t>& perm, int n)
+{
+    const size_t base = perm.size();
+    for (int i = 0; i < n; ++i) perm.push_back(i);
+    for (int i = n - 1; i > 0; --i) {
+        const int r = rng() % i;
+        std::swap(perm[base + i], perm[base + r]);
+    }
+}
+
+// src/gp_compressor.cpp:121-175, batched
+void gp_compressor::train_processes()
+{
+    if (!projected_) project_cloud();
+    const int P = batch_.patches();
+    if (P == 0) { trained_ = true; return; }
+    if (!ctx_) check(gpc_ctx_create(&ctx_, device_), nullptr, "gpc_ctx_create");
+    const int m = sz_ * sz_;
+    status_.assign(P, 0);
+    if (model_ == gp_model::dense) {
+        dense_f_.assign((size_t)P * m, 0.0);
+        dense_c_.assign((size_t)P * 3 * m, 0.0);
+        check(gpc_dense_fit_predict_grid(ctx_, &dense_params, P, batch_.off.data(), batch_.x0.data(), batch_.x1.data(),
+                                         batch_.y.data(), 1, res_, sz_, dense_f_.data(), nullptr, status_.data()),
+              ctx_, "gpc_dense_fit_predict_grid(depth)");
+        check(gpc_dense_fit_predict_grid(ctx_, &dense_params, P, batch_.off.data(), batch_.x0.data(), batch_.x1.data(),
+                                         batch_.rgb.data(), 3, res_, sz_, dense_c_.data(), nullptr, status_.data()),
+              ctx_, "gpc_dense_fit_predict_grid(rgb)");
+        mean_added_ = 0;
+        max_added_ = 0;
+        for (int i = 0; i < P; ++i) {
+            const int n = batch_.off[i + 1] - batch_.off[i];
+            mean_added_ += n;
+            max_added_ = std::max(max_added_, n);
+        }
+        mean_added_ /= P;
+        trained_ = true;
+        return;
+    }
+    if (!gps_) check(gpc_sparse_create(ctx_, &depth_params, P, 1, &gps_), ctx_, "gpc_sparse_create(depth)");
+    if (!rgb_gps_) check(gpc_sparse_create(ctx_, &rgb_params, P, 3, &rgb_gps_), ctx_, "gpc_sparse_create(rgb)");
+    // the reference shuffles inside gps[i].add_measurements and again inside RGB_gps[i].add_measurements, patch by
+    // patch (:162-163): draw the two orders in that interleaving
+    std::vector<int32_t> perm_d, perm_c;
+    for (int i = 0; i < P; ++i) {
+        const int n = batch_.off[i + 1] - batch_.off[i];
+        shuffle(perm_d, n);
+        shuffle(perm_c, n);
+    }
+    check(gpc_sparse_add(gps_, batch_.off.data(), batch_.x0.data(), batch_.x1.data(), batch_.y.data(), perm_d.data(),
+                         status_.data()), ctx_, "gpc_sparse_add(depth)");
+    check(gpc_sparse_add(rgb_gps_, batch_.off.data(), batch_.x0.data(), batch_.x1.data(), batch_.rgb.data(), perm_c.data(),
+                         status_.data()), ctx_, "gpc_sparse_add(rgb)");
+    std::vector<int32_t> bv(P);
+    check(gpc_sparse_sizes(gps_, bv.data()), ctx_, "gpc_sparse_sizes");
+    double mean = 0, added = 0;                  // "Mean added" / "Max added" (:164-168, 173-174)
+    int maxm = 0;
+    for (int i = 0; i < P; ++i) {
+        if (batch_.off[i + 1] == batch_.off[i]) continue;
+        mean = (added * mean + bv[i]) / (added + 1);
+        maxm = std::max(maxm, (int)bv[i]);
+        added += 1;
+    }
+    mean_added_ = mean;
+    max_added_ = maxm;
+    trained_ = true;
+}
+
+// src/gp_compressor.cpp:251-265 (x.cast<short>() as on x86-64, see oracle/gpc_oracle.c)
+void gp_compressor::flatten_colors(uint8_t out[3], const double c[3])
+{
+    for (int i = 0; i < 3; ++i) {
+        const double x = c[i];
+        int v;
+        if (std::isnan(x) || std::isinf(x)) {
+            v = 255;
+        } else {
+            const int32_t w = (x >= 2147483648.0 || x < -2147483648.0) ? INT32_MIN : (int32_t)x;
+            v = (int16_t)(uint16_t)(uint32_t)w;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        out[i] = (uint8_t)v;
+    }
+}
+
+// src/gp_compressor.cpp:267-386
+pointcloud gp_compressor::load_compressed()
+{
+    pointcloud out;
+    if (!trained_) return out;
+    const int P = batch_.patches();
+    const int m = sz_ * sz_;
+    if (P == 0) return out;
+    std::vector<double> xs0(m), xs1(m);
+    int pcount = 0;
+    for (int y = 0; y < sz_; ++y)                     // :320-331, y outer / x inner
+        for (int x = 0; x < sz_; ++x) {
+            xs0[pcount] = res_ * (((double)x + 0.5f) / (double)sz_ - 0.5f);
+            xs1[pcount] = res_ * (((double)y + 0.5f) / (double)sz_ - 0.5f);
+            ++pcount;
+        }
+    std::vector<double> f_star, c_star;
+    std::vector<int32_t> bv(P, 1);
+    if (model_ == gp_model::dense) {
+        f_star = dense_f_;
+        c_star = dense_c_;
+        for (int i = 0; i < P; ++i) bv[i] = batch_.off[i + 1] - batch_.off[i];
+    } else {
+        f_star.assign((size_t)P * m, 0.0);
+        c_star.assign((size_t)P * 3 * m, 0.0);
+        check(gpc_sparse_sizes(gps_, bv.data()), ctx_, "gpc_sparse_sizes");
+        // the caller discards V_star (:333-334), so sigma is not requested
+        check(gpc_sparse_predict(gps_, m, xs0.data(), xs1.data(), f_star.data(), nullptr, 0, nullptr), ctx_, "gpc_sparse_predict(depth)");
+        check(gpc_sparse_predict(rgb_gps_, m, xs0.data(), xs1.data(), c_star.data(), nullptr, 0, nullptr), ctx_, "gpc_sparse_predict(rgb)");
+    }
+    out.reserve((size_t)P * m);
+    for (int i = 0; i < P; ++i) {
+        if (bv[i] == 0) continue;                     // gps[i].size() == 0 (:299-301)
+        const auto& R = batch_.rotations[i];
+        const auto& mean = batch_.means[i];
+        for (int q = 0; q < m; ++q) {
+            const double pt[3] = {f_star[(size_t)i * m + q], xs0[q], xs1[q]};          // :336-338
+            point p;
+            float* xyz[3] = {&p.x, &p.y, &p.z};
+            for (int a = 0; a < 3; ++a) *xyz[a] = (float)(R[a] * pt[0] + R[3 + a] * pt[1] + R[6 + a] * pt[2] + mean[a]);   // :339
+            double c[3];
+            for (int a = 0; a < 3; ++a) c[a] = c_star[((size_t)i * 3 + a) * m + q] + batch_.rgb_means[i][a];           // :367
+            uint8_t rgb[3];
+            flatten_colors(rgb, c);
+            p.r = rgb[0]; p.g = rgb[1]; p.b = rgb[2];
+            out.push_back(p);
+        }
+    }
+    return out;
+}
+
+}  // namespace gpc
+
+// ---- C doors for the Python test-suite -----------------------------------------------------------------------------
+extern "C" {
+
+// host-only: cut and project the patches of a cloud (no GPU needed).  Returns an opaque handle.
+void* gpc_host_create(const float* xyz, const uint8_t* rgb, int n, double res, int sz, int model, int device)
+{
+    gpc::pointcloud c((size_t)n);
+    for (int i = 0; i < n; ++i) c[i] = gpc::point{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+    return new gpc::gp_compressor(c, res, sz, model == 1 ? gpc::gp_model::dense : gpc::gp_model::sparse, device);
+}
+void gpc_host_destroy(void* h) { delete static_cast<gpc::gp_compressor*>(h); }
+void gpc_host_seed(void* h, unsigned seed)
+{
+    // deterministic stand-in for libc rand(): a 31-bit LCG owned by the object
+    auto* g = static_cast<gpc::gp_compressor*>(h);
+    auto state = std::make_shared<uint64_t>(seed);
+    g->rng = [state]() -> int {
+        *state = (*state * 6364136223846793005ULL + 1442695040888963407ULL);
+        return (int)((*state >> 33) & 0x7fffffff);
+    };
+}
+void gpc_host_set_sparse_kernel(void* h, double sigmaf_sq, double l_sq, double s20_depth, double s20_rgb, int capacity)
+{
+    auto* g = static_cast<gpc::gp_compressor*>(h);
+    g->depth_params.sigmaf_sq = g->rgb_params.sigmaf_sq = sigmaf_sq;
+    g->depth_params.l_sq = g->rgb_params.l_sq = l_sq;
+    g->depth_params.noise = s20_depth;
+    g->rgb_params.noise = s20_rgb;
+    g->depth_params.capacity = g->rgb_params.capacity = capacity;
+}
+int gpc_host_project(void* h)
+{
+    try { static_cast<gpc::gp_compressor*>(h)->project_cloud(); return 0; } catch (...) { return -1; }
+}
+int gpc_host_patch_count(void* h) { return static_cast<gpc::gp_compressor*>(h)->patches().patches(); }
+int gpc_host_point_count(void* h) { return (int)static_cast<gpc::gp_compressor*>(h)->patches().x0.size(); }
+// copies the batch: off[P+1], x0/x1/y[N], rgb[3N], R[9P], mean[3P], rgb_mean[3P]
+void gpc_host_get_batch(void* h, int32_t* off, double* x0, double* x1, double* y, double* rgb, double* R, double* mean,
+                        double* rgb_mean)
+{
+    const gpc::patch_batch& b = static_cast<gpc::gp_compressor*>(h)->patches();
+    std::memcpy(off, b.off.data(), sizeof(int32_t) * b.off.size());
+    const size_t N = b.x0.size(), P = (size_t)b.patches();
+    std::memcpy(x0, b.x0.data(), 8 * N);
+    std::memcpy(x1, b.x1.data(), 8 * N);
+    std::memcpy(y, b.y.data(), 8 * N);
+    std::memcpy(rgb, b.rgb.data(), 8 * 3 * N);
+    for (size_t i = 0; i < P; ++i) {
+        std::memcpy(R + 9 * i, b.rotations[i].data(), 72);
+        std::memcpy(mean + 3 * i, b.means[i].data(), 24);
+        std::memcpy(rgb_mean + 3 * i, b.rgb_means[i].data(), 24);
+    }
+}
+// GPU: save_compressed + load_compressed.  out_xyz / out_rgb hold up to P*sz*sz points; returns the count or < 0.
+int gpc_host_roundtrip(void* h, float* out_xyz, uint8_t* out_rgb, int capacity_pts, double* mean_added, int* max_added,
+                       char* err, int errlen)
+{
+    auto* g = static_cast<gpc::gp_compressor*>(h);
+    try {
+        g->save_compressed("unused");
+        gpc::pointcloud c = g->load_compressed();
+        if ((int)c.size() > capacity_pts) return -2;
+        for (size_t i = 0; i < c.size(); ++i) {
+            out_xyz[3 * i] = c[i].x; out_xyz[3 * i + 1] = c[i].y; out_xyz[3 * i + 2] = c[i].z;
+            out_rgb[3 * i] = c[i].r; out_rgb[3 * i + 1] = c[i].g; out_rgb[3 * i + 2] = c[i].b;
+        }
+        if (mean_added) *mean_added = g->mean_added();
+        if (max_added) *max_added = g->max_added();
+        return (int)c.size();
+    } catch (const std::exception& e) {
+        if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+        return -1;
+    }
+}
+
+}  // extern "C"

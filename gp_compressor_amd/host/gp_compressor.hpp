@@ -1,0 +1,109 @@
+// gp_compressor.hpp -- host-side C++ mirror of the reference's class surface for the hot path.
+//
+// Same names, argument meaning and flow as /root/reference/src/gp_compressor.{h,cpp}: a cloud goes in, octree-leaf
+// patches are cut and projected into their plane frames on the host (project_cloud / compute_rotation /
+// project_points, src/gp_compressor.cpp:29-118,177-249), the per-patch GP loops (train_processes :121-175 and the
+// patch loop of load_compressed :298-380) run BATCHED on the GPU through the C-ABI of include/gpc.h, and the
+// predicted grids are re-projected to a coloured cloud (:335-373).  PCL and Eigen are not used: the spatial index is
+// a plain voxel hash of side `res` (enough to feed the hot path; the octree itself is out of scope, SURVEY section 2
+// row 9) and the 4x4 plane fit is a Jacobi eigen-solve.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/gpc.h"
+
+namespace gpc {
+
+// pcl::PointXYZRGB, the fields the path touches (src/gp_compressor.h:20)
+struct point {
+    float x, y, z;
+    uint8_t r, g, b;
+};
+using pointcloud = std::vector<point>;
+
+// Duck-typed functors of the reference, host versions (what the kernels evaluate on the device).
+class rbf_kernel {   // src/rbf_kernel.h:7-25
+    double p_[2];
+public:
+    explicit rbf_kernel(double sigmaf_sq = 100e-0f, double l_sq = 1 * 1) : p_{sigmaf_sq, l_sq} {}
+    int param_size() const { return 2; }
+    const double* param() const { return p_; }
+    double kernel_function(const double xi[2], const double xj[2]) const;   // src/rbf_kernel.cpp:15-18
+};
+class gaussian_noise {   // src/gaussian_noise.h:4-11
+public:
+    double s20;
+    explicit gaussian_noise(double s20_) : s20(s20_) {}
+    double dx_ln(double y, double x, double sigma_x) const { return (y - x) / (s20 + sigma_x); }
+    double dx2_ln(double, double, double sigma_x) const { return -1.0f / (s20 + sigma_x); }
+};
+
+enum class gp_model {
+    sparse,   // sparse_gp<rbf_kernel, gaussian_noise> + sparse_gp_field<rbf_kernel, gaussian_noise_3d>: what the reference runs
+    dense     // gaussian_process (src/gaussian_process.h), the batched-Cholesky model of the north star
+};
+
+// The patch batch project_cloud() hands to the GPU: exactly the X, y, C of src/gp_compressor.cpp:146-155, batched.
+struct patch_batch {
+    std::vector<int32_t> off;            // P + 1
+    std::vector<double> x0, x1;          // patch-frame coordinates pt(1), pt(2)
+    std::vector<double> y;               // depth pt(0), mean-removed
+    std::vector<double> rgb;             // 3 planes of N, mean-removed colours
+    std::vector<std::array<double, 9>> rotations;   // R_i, column-major (columns = normal, u, v)
+    std::vector<std::array<double, 3>> means;       // patch centres after the mean-depth shift (:116)
+    std::vector<std::array<double, 3>> rgb_means;
+    std::vector<uint8_t> W;              // sz*sz occupancy mask per patch (:117)
+    int patches() const { return (int)off.size() - 1; }
+};
+
+class gp_compressor {
+public:
+    // gp_compressor(pointcloud::ConstPtr ncloud, double res = 0.1f, int sz = 10)   src/gp_compressor.h:65
+    gp_compressor(const pointcloud& ncloud, double res = 0.1f, int sz = 10, gp_model model = gp_model::sparse,
+                  int device = 0);
+    ~gp_compressor();
+    gp_compressor(const gp_compressor&) = delete;
+    gp_compressor& operator=(const gp_compressor&) = delete;
+
+    void save_compressed(const std::string& name);   // src/gp_compressor.cpp:21-27 (name unused upstream as well)
+    pointcloud load_compressed();                    // src/gp_compressor.cpp:267-386
+
+    // host-only part, usable without a GPU
+    void project_cloud();                            // src/gp_compressor.cpp:177-249
+    const patch_batch& patches() const { return batch_; }
+    // statistics the reference prints ("Mean added" / "Max added", :173-174)
+    double mean_added() const { return mean_added_; }
+    int max_added() const { return max_added_; }
+    // insertion-order source; default std::rand like sparse_gp::shuffle (src/sparse_gp.hpp:43-56)
+    std::function<int()> rng;
+    // hyper-parameters (defaults = the reference's compile-time constants)
+    gpc_params depth_params, rgb_params, dense_params;
+
+protected:
+    void compute_rotation(double R[9], const std::vector<double>& pts4, int k) const;   // :29-64
+    void train_processes();                                                            // :121-175
+    static void flatten_colors(uint8_t out[3], const double c[3]);                      // :251-265
+    void shuffle(std::vector<int32_t>& perm, int n);
+
+    pointcloud cloud_;
+    double res_;
+    int sz_;
+    gp_model model_;
+    int device_;
+    patch_batch batch_;
+    bool projected_ = false, trained_ = false;
+    gpc_ctx* ctx_ = nullptr;
+    gpc_sparse* gps_ = nullptr;
+    gpc_sparse* rgb_gps_ = nullptr;
+    std::vector<double> dense_f_, dense_c_;   // dense model: grids predicted at training time (fit + predict are fused)
+    std::vector<int32_t> status_;
+    double mean_added_ = 0.0;
+    int max_added_ = 0;
+};
+
+}  // namespace gpc
