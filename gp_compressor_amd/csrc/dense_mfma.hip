@@ -62,6 +62,7 @@ struct MfmaParams {
         t_prev_ = t_now_;                                         \
         __builtin_amdgcn_sched_barrier(0);                        \
     } while (0)
+#define MF_STAMP_FINE(ph) do { if (MF_STAMPS > 1) MF_STAMP(ph); } while (0)
 #define MF_STAMP_FLUSH()                                                                                         \
     do {                                                                                                         \
         if (g.stamps && lane == 0)                                                                               \
@@ -70,6 +71,7 @@ struct MfmaParams {
 #else
 #define MF_STAMP_DECL
 #define MF_STAMP(ph) do { } while (0)
+#define MF_STAMP_FINE(ph) do { } while (0)
 #define MF_STAMP_FLUSH() do { } while (0)
 #endif
 
@@ -102,21 +104,29 @@ __device__ static __forceinline__ int mf_opaque(int v)
 // Spin until *word >= k (an LDS word published with release semantics by another wave of the workgroup).
 // Written as ONE asm statement on purpose: as a C loop it puts a cycle into the CFG of the fully unrolled step body
 // and hipcc's register allocator answers with ~100 spilled accumulator registers.  All lanes read the same word.
-__device__ static __forceinline__ void mf_wait_ge(const int* word, int k)
+__device__ static __forceinline__ bool mf_wait_ge(const int* word, int k)
 {
-    int v;
+    // Bounded: 2^20 polls x s_sleep(1) is tens of milliseconds, three orders of magnitude beyond any legitimate wait.
+    // On expiry the wave simply carries on (every other wait is bounded too, so the workgroup drains) and the patch is
+    // reported as GPC_STATUS_NAN: a protocol failure must never hang the GPU.
+    int v, cnt;
     asm volatile(
+        "s_mov_b32 %1, 0x100000\n\t"
         "1:\n\t"
-        "flat_load_dword %0, %1 sc0\n\t"
+        "flat_load_dword %0, %2 sc0\n\t"
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-        "v_cmp_gt_i32 vcc, %2, %0\n\t"
+        "v_cmp_gt_i32 vcc, %3, %0\n\t"
         "s_cbranch_vccz 2f\n\t"
+        "s_sub_u32 %1, %1, 1\n\t"
+        "s_cmp_eq_u32 %1, 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
         "s_sleep 1\n\t"
         "s_branch 1b\n\t"
         "2:\n\t"
-        : "=&v"(v)
+        : "=&v"(v), "=&s"(cnt)
         : "v"(word), "v"(k)
-        : "vcc", "memory");
+        : "vcc", "scc", "memory");
+    return cnt != 0;
 }
 __device__ static __forceinline__ void mf_publish(int* word, int k)
 {
@@ -205,7 +215,23 @@ __device__ static __forceinline__ double mf_row_dot(const double* img, int mr, c
 // dealt round-robin to the 7 workers: worker w owns idx = 7 t + w in register slot t.  Every phase works on a
 // contiguous idx range, i.e. on a contiguous slot range [t_lo, t_hi] of each worker; every slot body is guarded by one
 // scalar range test.  (A fall-through switch into the unrolled bodies was tried: it wrecks register allocation.)
-#define MF_SLOTS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19)
+// The guards are bit tests on a wave-uniform slot mask (range & live), entered group-wise (5 slots per group) so that
+// the scalar unit skips dead slots in bulk: a plain per-slot compare chain costs ~0.7k cycles per scan, and there are 64
+// scans per patch.
+#define MF_G0(X) X(0) X(1) X(2) X(3) X(4)
+#define MF_G1(X) X(5) X(6) X(7) X(8) X(9)
+#define MF_G2(X) X(10) X(11) X(12) X(13) X(14)
+#define MF_G3(X) X(15) X(16) X(17) X(18) X(19)
+#define MF_SLOTS(X)                           \
+    if (smask & 0x0001Fu) { MF_G0(X) }        \
+    if (smask & 0x003E0u) { MF_G1(X) }        \
+    if (smask & 0x07C00u) { MF_G2(X) }        \
+    if (smask & 0xF8000u) { MF_G3(X) }
+// bits t_lo .. t_hi (empty when t_hi < t_lo); 0 <= t_lo, t_hi < 31
+__device__ static __forceinline__ unsigned mf_range_mask(int t_lo, int t_hi)
+{
+    return (t_hi >= t_lo) ? (((2u << t_hi) - 1u) & ~((1u << t_lo) - 1u)) : 0u;
+}
 __device__ static __forceinline__ int mf_cs(int j, int nt_full) { return j * nt_full - (j * (j - 1)) / 2; }
 
 template <int CTRL>
@@ -230,7 +256,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 {
     constexpr int NTILES = NT * (NT + 1) / 2;
     constexpr int TPW = (NTILES + MF_WORKERS - 1) / MF_WORKERS;
-    static_assert(TPW <= 20, "MF_SLOTS covers 20 slots");
+    static_assert(TPW <= 20, "MF_G0..MF_G3 cover 20 slots");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     double* T = lds + L_EXP;
@@ -307,7 +333,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         }
         __syncthreads();
 
+        unsigned live_mask = 0;   // slots whose tile row is live (ti < nt)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) live_mask |= (ti_(t) < nt) ? (1u << t) : 0u;
+        live_mask = __builtin_amdgcn_readfirstlane(live_mask);
         d4 acc[TPW];   // worker waves only; never live on the factor wave's path through the factorisation
+        bool timed_out = false;
         if (!is_factor) {
             // ================================ WORKER ROLE ================================
             // ---- Gram tiles, transposed: acc[t][r] = K[16 i + (l&15)][16 j + (l>>4) + 4 r]; padding = identity ----
@@ -346,18 +377,19 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             // diagonal tile first (handed to the factor wave at once), then the forward-solve rows, then the rest.
             for (int k = 0; k < nt; ++k) {
                 double* panP = panBase + (k & 1) * (16 * 256);
-                mf_wait_ge(ready, k);
-                MF_STAMP(1);
+                timed_out |= !mf_wait_ge(ready, k);
+                MF_STAMP_FINE(1);
                 if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                 {
                     const int lo_ = mf_cs(k, NT) + 1 - wave, hi_ = mf_cs(k + 1, NT) - 1 - wave;
                     const int t_lo = __builtin_amdgcn_readfirstlane((lo_ + 6) / 7);
                     const int t_hi = __builtin_amdgcn_readfirstlane((hi_ + 7) / 7 - 1);
-                    if (t_lo <= t_hi) {
+                    const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_lo, t_hi) & live_mask);
+                    if (smask) {
                         const d4 lv = *reinterpret_cast<const d4*>(Linv + k * 256 + mf_opaque(lane) * 4);
 #define MF_TRSM_CASE(t)                                                                                              \
     if constexpr (t < TPW) {                                                                                         \
-        if (t >= t_lo && t <= t_hi && ti_(t) < nt) {                                                                 \
+        if (smask & (1u << t)) {                                                                                     \
             d4 D1 = d4{0.0, 0.0, 0.0, 0.0}, D2 = d4{0.0, 0.0, 0.0, 0.0};                                             \
             D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], acc[t][0], D1, 0, 0, 0);                                \
             D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], acc[t][2], D2, 0, 0, 0);                                \
@@ -370,19 +402,19 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         MF_SLOTS(MF_TRSM_CASE)
                     }
                 }
-                MF_STAMP(2);
+                MF_STAMP_FINE(2);
                 __syncthreads();   // B2(k): panel k complete; every wave has left update phase k-1
-                MF_STAMP(3);
+                MF_STAMP_FINE(3);
                 // the next diagonal tile: T_(k+1)(k+1) -= L_(k+1)k L_(k+1)k^T, then straight to the factor wave
                 if (k + 1 < nt) {
                     const int idx1 = __builtin_amdgcn_readfirstlane(mf_cs(k + 1, NT));
                     if (wave == idx1 % MF_WORKERS) {
-                        const int slot1 = idx1 / MF_WORKERS;
+                        const unsigned smask = __builtin_amdgcn_readfirstlane(1u << (idx1 / MF_WORKERS));
                         const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
                         const d4 a = *reinterpret_cast<const d4*>(panP + (k + 1) * 256 + ln * 4);
 #define MF_DIAG_CASE(t)                                                                                              \
     if constexpr (t < TPW) {                                                                                         \
-        if (t == slot1) {                                                                                            \
+        if (smask & (1u << t)) {                                                                                     \
             /* blgp = 1 on the f64 MFMA is NEG(A): acc - a*b  (tools/probe_mfma_f64.hip) */                          \
             _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                            \
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], a[s], acc[t], 0, 0, 1);                          \
@@ -393,20 +425,21 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         mf_publish(tile_ready, k + 1);
                     }
                 }
-                MF_STAMP(4);
+                MF_STAMP_FINE(4);
                 // forward solve rows the factor wave does not need first: y_i -= L_ik z_k, i >= k+2, one thread per row
                 if (tid < MF_TS * (nt - 2 - k)) {
                     const int i = k + 2 + (tid >> 4), mr = tid & 15;
                     for (int c = 0; c < ny; ++c)
                         yc[c * MF_NPAD + MF_TS * i + mr] -= mf_row_dot(panP + i * 256, mr, zv + c * MF_NPAD + MF_TS * k);
                 }
-                MF_STAMP(5);
+                MF_STAMP_FINE(5);
                 // the rest of the trailing matrix, T_ij -= L_jk L_ik^T  (idx > cs(k+1))
                 {
-                    const int t_first = __builtin_amdgcn_readfirstlane((mf_cs(k + 1, NT) + 1 - wave + 6) / 7);
+                    const int t_first = (mf_cs(k + 1, NT) + 1 - wave + 6) / 7;
+                    const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_first, 30) & live_mask);
 #define MF_UPD_CASE(t)                                                                                               \
     if constexpr (t < TPW) {                                                                                         \
-        if (t >= t_first && ti_(t) < nt) {                                                                           \
+        if (smask & (1u << t)) {                                                                                     \
             const int ln4 = mf_opaque(lane) * 4;                                                                     \
             const d4 a = *reinterpret_cast<const d4*>(panP + tj_(t) * 256 + ln4);                                    \
             const d4 b = *reinterpret_cast<const d4*>(panP + ti_(t) * 256 + ln4);                                    \
@@ -416,7 +449,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     }
                     MF_SLOTS(MF_UPD_CASE)
                 }
-                MF_STAMP(6);
+                MF_STAMP_FINE(6);
             }
         } else {
             // ================================ FACTOR ROLE ================================
@@ -425,9 +458,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             for (int j = 0; j < nt; ++j) {
                 const int k = j - 1;                                  // the panel this tile was last updated with
                 if (k >= 0) {
-                    MF_STAMP(1);
+                    MF_STAMP_FINE(1);
                     __syncthreads();                                  // B2(k)
-                    MF_STAMP(3);
+                    MF_STAMP_FINE(3);
                     // y_j -= L_jk z_k (rows of block j; the workers do blocks >= j+1)
                     if (lane < 16) {
                         const double* panP = panBase + (k & 1) * (16 * 256);
@@ -435,10 +468,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                             yc[c * MF_NPAD + MF_TS * j + lane] -= mf_row_dot(panP + j * 256, lane, zv + c * MF_NPAD + MF_TS * k);
                     }
                 }
-                mf_wait_ge(tile_ready, j);
-                MF_STAMP(4);
+                timed_out |= !mf_wait_ge(tile_ready, j);
+                MF_STAMP_FINE(4);
                 const bool ok = mf_diag_factor(DS, Linv + j * 256, LinvT + j * 256, g.pivot_tol);
-                MF_STAMP(5);
+                MF_STAMP_FINE(5);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 // z_j = L_jj^-1 y_j  (y_j already carries -sum_{i<j} L_ji z_i): 16 row-threads
                 if (lane < 16)
@@ -446,7 +479,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         zv[c * MF_NPAD + MF_TS * j + lane] = mf_row_dot(Linv + j * 256, lane, yc + c * MF_NPAD + MF_TS * j);
                 if (!ok && lane == 0) flag[0] = 1;
                 mf_publish(ready, j);
-                MF_STAMP(2);
+                MF_STAMP_FINE(2);
                 if (!ok) break;                                       // the workers leave at step j as well
             }
             if (!__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) __syncthreads();   // B2(nt-1)
@@ -473,14 +506,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 const int lo_ = mf_cs(k, NT) + 1 - wave, hi_ = mf_cs(k + 1, NT) - 1 - wave;
                 const int t_lo = __builtin_amdgcn_readfirstlane((lo_ + 6) / 7);
                 const int t_hi = __builtin_amdgcn_readfirstlane((hi_ + 7) / 7 - 1);
-                if (t_lo <= t_hi) {
+                const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_lo, t_hi) & live_mask);
+                if (smask) {
                     for (int c = 0; c < ny; ++c) {      // one channel at a time keeps the register footprint at 4 doubles
                         const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
                         d4 pa = d4{0.0, 0.0, 0.0, 0.0};
                         const double* avc = av + c * MF_NPAD + lr;
 #define MF_BWD_CASE(t)                                                                                               \
     if constexpr (t < TPW) {                                                                                         \
-        if (t >= t_lo && t <= t_hi && ti_(t) < nt) pa += acc[t] * avc[MF_TS * ti_(t)];                               \
+        if (smask & (1u << t)) pa += acc[t] * avc[MF_TS * ti_(t)];                                                   \
     }
                         MF_SLOTS(MF_BWD_CASE)
 #pragma unroll
@@ -492,7 +526,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     }
                 }
             }
+            MF_STAMP_FINE(10);
             __syncthreads();
+            MF_STAMP_FINE(1);
             if (is_factor) {
                 // alpha_k = L_kk^-T u as one 16x16x16 MFMA product: column n < ny of the B operand carries u of channel n
                 const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
@@ -516,7 +552,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     for (int r = 0; r < 4; ++r) av[lr * MF_NPAD + MF_TS * k + lg + 4 * r] = al[r];
                 }
             }
+            MF_STAMP_FINE(11);
             __syncthreads();
+            MF_STAMP_FINE(3);
         }
         if (A.alpha_out)
             for (int i = tid; i < n; i += MF_THREADS)
@@ -614,7 +652,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         }
         MF_STAMP(9);
         MF_STAMP_FLUSH();
-        if (tid == 0 && A.status) A.status[patch] = GPC_STATUS_OK;
+        if (timed_out && lane == 0) flag[0] = 2;
+        __syncthreads();
+        if (tid == 0 && A.status) A.status[patch] = flag[0] ? GPC_STATUS_NAN : GPC_STATUS_OK;
     } while (0);
 }
 
@@ -660,11 +700,11 @@ int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a)
             (void)hipFree(d);
             static const char* names[MF_NPH] = {"load+gram", "wait ready | B2 (factor)", "trsm | z+publish (factor)", "wait B2 | y_j (factor)",
                                                 "diag tile upd | wait tile (factor)", "y rows | diag factor (factor)", "trailing update",
-                                                "post-loop", "backward", "predict", "-", "-"};
+                                                "post-loop", "backward", "predict", "bwd: worker part (fine)", "bwd: factor part (fine)"};
             fprintf(stderr, "[MF_STAMPS] mean cycles per patch, by wave (s_memtime ticks); wave 7 is the factor wave:\n%-36s", "phase");
             for (int w = 0; w < MF_WAVES; ++w) fprintf(stderr, "   wave%d", w);
             fprintf(stderr, "\n");
-            for (int q = 0; q < 10; ++q) {
+            for (int q = 0; q < MF_NPH; ++q) {
                 fprintf(stderr, "%-36s", names[q]);
                 for (int w = 0; w < MF_WAVES; ++w) {
                     double s_ = 0;

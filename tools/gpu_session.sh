@@ -27,6 +27,9 @@ fi
 if [ "${RUN_STAMP:-0}" = "1" ]; then
   step 300 $OUT/stamp_$TAG.log python tools/stamp_mfma.py
   tail -16 $OUT/stamp_$TAG.log
+  if [ -f gp_compressor_amd/libgpc_hip_stamps2.so ]; then
+    GPC_LIB_PATH=$PWD/gp_compressor_amd/libgpc_hip_stamps2.so step 300 $OUT/stamp2_$TAG.log python tools/stamp_mfma.py
+  fi
 fi
 if [ "${RUN_BENCH:-1}" = "1" ]; then
   step 600 $OUT/bench_$TAG.log python bench.py --steps ${BENCH_STEPS:-10} --warmup 2

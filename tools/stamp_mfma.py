@@ -12,7 +12,7 @@ STAMP_LIB = os.path.join(ROOT, "gp_compressor_amd", "libgpc_hip_stamps.so")
 
 if "--build" in sys.argv:
     from gp_compressor_amd import build
-    print(build.build(lib=STAMP_LIB, extra_flags=("-DMF_STAMPS",), verbose=True))
+    print(build.build(lib=STAMP_LIB, extra_flags=("-DMF_STAMPS=" + os.environ.get("MF_STAMPS", "1"),), verbose=True))
     sys.exit(0)
 
 os.environ.setdefault("GPC_LIB_PATH", STAMP_LIB)
