@@ -75,6 +75,28 @@ struct MfmaParams {
 #define MF_STAMP_FLUSH() do { } while (0)
 #endif
 
+// Timing-only ablation switches (cdna_hip_programming.md section 7, "The diagnostic loop", step 2): each removes one piece of
+// the factorisation loop so that its share of the critical path can be read off the coarse stamps.  Builds with any of
+// them produce WRONG results and are never shipped (tools/ablate_mfma.py).
+#ifndef MF_ABL_DIAG
+#define MF_ABL_DIAG 0
+#endif
+#ifndef MF_ABL_UPD
+#define MF_ABL_UPD 0
+#endif
+#ifndef MF_ABL_TRSM
+#define MF_ABL_TRSM 0
+#endif
+#ifndef MF_ABL_YROWS
+#define MF_ABL_YROWS 0
+#endif
+#ifndef MF_ABL_FWD
+#define MF_ABL_FWD 0
+#endif
+#ifndef MF_ABL_PASS1
+#define MF_ABL_PASS1 0
+#endif
+
 // ---- LDS carve (doubles) ----------------------------------------------------------------------------------
 #define L_EXP 0                          // 64    exp table
 #define L_PX0 64                         // 256   x0
@@ -391,11 +413,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     if constexpr (t < TPW) {                                                                                         \
         if (smask & (1u << t)) {                                                                                     \
             d4 D1 = d4{0.0, 0.0, 0.0, 0.0}, D2 = d4{0.0, 0.0, 0.0, 0.0};                                             \
+            if (!MF_ABL_TRSM) {                                                                                      \
             D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], acc[t][0], D1, 0, 0, 0);                                \
             D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], acc[t][2], D2, 0, 0, 0);                                \
             D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], acc[t][1], D1, 0, 0, 0);                                \
             D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], acc[t][3], D2, 0, 0, 0);                                \
-            acc[t] = D1 + D2; /* = L_ik[l & 15][(l>>4) + 4 r] */                                                     \
+            acc[t] = D1 + D2; /* = L_ik[l & 15][(l>>4) + 4 r] */ }                                                   \
             *reinterpret_cast<d4*>(panP + ti_(t) * 256 + mf_opaque(lane) * 4) = acc[t];                              \
         }                                                                                                            \
     }
@@ -416,8 +439,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     if constexpr (t < TPW) {                                                                                         \
         if (smask & (1u << t)) {                                                                                     \
             /* blgp = 1 on the f64 MFMA is NEG(A): acc - a*b  (tools/probe_mfma_f64.hip) */                          \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                            \
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], a[s], acc[t], 0, 0, 1);                          \
+            if (!MF_ABL_PASS1) { _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], a[s], acc[t], 0, 0, 1); }                        \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) DS[(lg + 4 * r) * 17 + lr] = acc[t][r];                    \
         }                                                                                                            \
     }
@@ -427,7 +450,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 }
                 MF_STAMP_FINE(4);
                 // forward solve rows the factor wave does not need first: y_i -= L_ik z_k, i >= k+2, one thread per row
-                if (tid < MF_TS * (nt - 2 - k)) {
+                if (!MF_ABL_YROWS && tid < MF_TS * (nt - 2 - k)) {
                     const int i = k + 2 + (tid >> 4), mr = tid & 15;
                     for (int c = 0; c < ny; ++c)
                         yc[c * MF_NPAD + MF_TS * i + mr] -= mf_row_dot(panP + i * 256, mr, zv + c * MF_NPAD + MF_TS * k);
@@ -439,7 +462,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_first, 30) & live_mask);
 #define MF_UPD_CASE(t)                                                                                               \
     if constexpr (t < TPW) {                                                                                         \
-        if (smask & (1u << t)) {                                                                                     \
+        if (!MF_ABL_UPD && (smask & (1u << t))) {                                                                    \
             const int ln4 = mf_opaque(lane) * 4;                                                                     \
             const d4 a = *reinterpret_cast<const d4*>(panP + tj_(t) * 256 + ln4);                                    \
             const d4 b = *reinterpret_cast<const d4*>(panP + ti_(t) * 256 + ln4);                                    \
@@ -462,7 +485,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     __syncthreads();                                  // B2(k)
                     MF_STAMP_FINE(3);
                     // y_j -= L_jk z_k (rows of block j; the workers do blocks >= j+1)
-                    if (lane < 16) {
+                    if (!MF_ABL_FWD && lane < 16) {
                         const double* panP = panBase + (k & 1) * (16 * 256);
                         for (int c = 0; c < ny; ++c)
                             yc[c * MF_NPAD + MF_TS * j + lane] -= mf_row_dot(panP + j * 256, lane, zv + c * MF_NPAD + MF_TS * k);
@@ -470,11 +493,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 }
                 timed_out |= !mf_wait_ge(tile_ready, j);
                 MF_STAMP_FINE(4);
-                const bool ok = mf_diag_factor(DS, Linv + j * 256, LinvT + j * 256, g.pivot_tol);
+                const bool ok = MF_ABL_DIAG ? true : mf_diag_factor(DS, Linv + j * 256, LinvT + j * 256, g.pivot_tol);
                 MF_STAMP_FINE(5);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 // z_j = L_jj^-1 y_j  (y_j already carries -sum_{i<j} L_ji z_i): 16 row-threads
-                if (lane < 16)
+                if (!MF_ABL_FWD && lane < 16)
                     for (int c = 0; c < ny; ++c)
                         zv[c * MF_NPAD + MF_TS * j + lane] = mf_row_dot(Linv + j * 256, lane, yc + c * MF_NPAD + MF_TS * j);
                 if (!ok && lane == 0) flag[0] = 1;

@@ -26,7 +26,7 @@ def test_compress_roundtrip_c1(H, model):
     if model == "sparse":
         # a kernel that lets the sparse GP follow the surface (at the reference defaults every K_ij is within 2 % of
         # sigma_f^2 and the BV set stays tiny -- covered by tests/test_sparse_gpu.py)
-        g.set_sparse_kernel(1.0, (res / 4) ** 2, 1e-4, 25.0, 40)
+        g.set_sparse_kernel(1.0, (res / 2) ** 2, 1e-2, 25.0, 40)      # the CPU oracle reconstructs to 0.6 mm rms with these
     oxyz, orgb, mean_added, max_added = g.roundtrip()
     P = 64
     assert len(oxyz) == P * sz * sz                          # every patch decompresses to a full sz x sz grid

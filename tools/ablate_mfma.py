@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Timing-only ablation study of dense_mfma_kernel (diagnostic; results of the ablated builds are wrong by design).
+  python tools/ablate_mfma.py --build     (container: builds gp_compressor_amd/abl/libgpc_<variant>.so, all with coarse stamps)
+  python tools/ablate_mfma.py             (GPU box: runs each variant on the C2 workload, prints the coarse phase table)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ABL = os.path.join(ROOT, "gp_compressor_amd", "abl")
+VARIANTS = {
+    "base": (),
+    "nodiag": ("-DMF_ABL_DIAG=1",),
+    "noupd": ("-DMF_ABL_UPD=1",),
+    "notrsm": ("-DMF_ABL_TRSM=1",),
+    "noyrows": ("-DMF_ABL_YROWS=1",),
+    "nofwd": ("-DMF_ABL_FWD=1",),
+    "nopass1": ("-DMF_ABL_PASS1=1",),
+    "nodiag_nofwd_nopass1": ("-DMF_ABL_DIAG=1", "-DMF_ABL_FWD=1", "-DMF_ABL_PASS1=1"),
+    "noupd_notrsm": ("-DMF_ABL_UPD=1", "-DMF_ABL_TRSM=1"),
+}
+if "--build" in sys.argv:
+    from gp_compressor_amd import build
+    os.makedirs(ABL, exist_ok=True)
+    for name, flags in VARIANTS.items():
+        build.build(lib=os.path.join(ABL, f"libgpc_{name}.so"), extra_flags=("-DMF_STAMPS=1",) + flags)
+        print("built", name, flush=True)
+    sys.exit(0)
+for name in VARIANTS:
+    env = dict(os.environ, GPC_LIB_PATH=os.path.join(ABL, f"libgpc_{name}.so"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stamp_mfma.py")], env=env, capture_output=True, text=True)
+    lines = [l for l in (out.stderr + out.stdout).splitlines() if l.startswith(("load+gram", "post-loop", "backward", "predict", "total"))]
+    print(f"=== {name}")
+    for l in lines[-5:]:
+        print("   ", l)
+    sys.stdout.flush()
