@@ -126,7 +126,7 @@ __device__ static __forceinline__ int mf_opaque(int v)
 // Spin until *word >= k (an LDS word published with release semantics by another wave of the workgroup).
 // Written as ONE asm statement on purpose: as a C loop it puts a cycle into the CFG of the fully unrolled step body
 // and hipcc's register allocator answers with ~100 spilled accumulator registers.  All lanes read the same word.
-__device__ static __forceinline__ bool mf_wait_ge(const int* word, int k)
+__device__ static __forceinline__ bool mf_wait_ge(unsigned lds_byte_addr, int k)
 {
     // Bounded: 2^20 polls x s_sleep(1) is tens of milliseconds, three orders of magnitude beyond any legitimate wait.
     // On expiry the wave simply carries on (every other wait is bounded too, so the workgroup drains) and the patch is
@@ -135,8 +135,8 @@ __device__ static __forceinline__ bool mf_wait_ge(const int* word, int k)
     asm volatile(
         "s_mov_b32 %1, 0x100000\n\t"
         "1:\n\t"
-        "flat_load_dword %0, %2 sc0\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        "ds_read_b32 %0, %2\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
         "v_cmp_gt_i32 vcc, %3, %0\n\t"
         "s_cbranch_vccz 2f\n\t"
         "s_sub_u32 %1, %1, 1\n\t"
@@ -146,7 +146,7 @@ __device__ static __forceinline__ bool mf_wait_ge(const int* word, int k)
         "s_branch 1b\n\t"
         "2:\n\t"
         : "=&v"(v), "=&s"(cnt)
-        : "v"(word), "v"(k)
+        : "v"(lds_byte_addr), "v"(k)
         : "vcc", "scc", "memory");
     return cnt != 0;
 }
@@ -292,6 +292,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     int* flag = reinterpret_cast<int*>(lds + L_FLAG);   // [0] not-SPD
     int* ready = flag + 1;        // highest tile column whose L_kk^-1, z_k (and y_k) are published by the factor wave
     int* tile_ready = flag + 2;   // highest diagonal tile handed over to the factor wave
+    // 32-bit LDS byte addresses of the two words for the ds_read polling loops (dynamic LDS starts after the static part)
+    const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
+    const unsigned ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 4), tile_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 8);
     double* Linv = lds + L_LINV;
     double* LinvT = lds + L_LINVT;
     double* panBase = lds + L_PANP;
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             // diagonal tile first (handed to the factor wave at once), then the forward-solve rows, then the rest.
             for (int k = 0; k < nt; ++k) {
                 double* panP = panBase + (k & 1) * (16 * 256);
-                timed_out |= !mf_wait_ge(ready, k);
+                timed_out |= !mf_wait_ge(ready_addr, k);
                 MF_STAMP_FINE(1);
                 if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                 {
@@ -439,8 +442,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     if constexpr (t < TPW) {                                                                                         \
         if (smask & (1u << t)) {                                                                                     \
             /* blgp = 1 on the f64 MFMA is NEG(A): acc - a*b  (tools/probe_mfma_f64.hip) */                          \
-            if (!MF_ABL_PASS1) { _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], a[s], acc[t], 0, 0, 1); }                        \
+            if (!MF_ABL_PASS1) {                                                                                     \
+                d4 S2 = d4{0.0, 0.0, 0.0, 0.0};   /* two chains of two: halves the dependent MFMA latency */       \
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[t], 0, 0, 1);                          \
+                S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], a[2], S2, 0, 0, 1);                                  \
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], a[1], acc[t], 0, 0, 1);                          \
+                S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], a[3], S2, 0, 0, 1);                                  \
+                acc[t] += S2;                                                                                        \
+            }                                                                                                        \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) DS[(lg + 4 * r) * 17 + lr] = acc[t][r];                    \
         }                                                                                                            \
     }
@@ -476,7 +485,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             }
         } else {
             // ================================ FACTOR ROLE ================================
-            // produces L_jj^-1, L_jj^-T, z_j for j = 0 .. nt-1 and the forward-solve rows of block j; joins B2(k)
+            // produces L_jj^-1, L_jj^-T, z_j for j = 0 .. nt-1 and the forward-solve rows of block j; joins B2(k).
+            // It is the critical path of every late step and shares its SIMD (and that SIMD's FP64 pipe) with a worker
+            // that streams MFMAs: static priority lets its short dependent FP64 chain win the arbitration
+            // (MI355X_MICROARCH.md, 'Two waves per SIMD', item 4).
+            __builtin_amdgcn_s_setprio(3);
             MF_STAMP(0);
             for (int j = 0; j < nt; ++j) {
                 const int k = j - 1;                                  // the panel this tile was last updated with
@@ -491,7 +504,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                             yc[c * MF_NPAD + MF_TS * j + lane] -= mf_row_dot(panP + j * 256, lane, zv + c * MF_NPAD + MF_TS * k);
                     }
                 }
-                timed_out |= !mf_wait_ge(tile_ready, j);
+                timed_out |= !mf_wait_ge(tile_ready_addr, j);
                 MF_STAMP_FINE(4);
                 const bool ok = MF_ABL_DIAG ? true : mf_diag_factor(DS, Linv + j * 256, LinvT + j * 256, g.pivot_tol);
                 MF_STAMP_FINE(5);
@@ -506,6 +519,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 if (!ok) break;                                       // the workers leave at step j as well
             }
             if (!__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) __syncthreads();   // B2(nt-1)
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         const bool bad = flag[0] != 0;
