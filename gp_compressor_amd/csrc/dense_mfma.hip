@@ -112,9 +112,9 @@ struct MfmaParams {
 #define L_WV (L_ZV + 3 * MF_NPAD)        // 3*256 backward-solve accumulators w_k[c][16 k + .] (ds_add_f64 targets)
 #define L_AV (L_WV + 3 * MF_NPAD)        // 3*256 alpha
 #define L_DS (L_AV + 3 * MF_NPAD)        // 16*17 (+ pad to 288) diagonal-tile hand-over scratch
-#define L_FLAG (L_DS + 288)              // 4     ints: [0] not-SPD/timeout, [1] ready, [2] tile_ready, [3] alpha_ready,
-                                         //       [4] pre_cnt, [5] sub_cnt (backward-solve hand-over counters)
-#define L_LINV (L_FLAG + 4)              // 16*256 L_kk^-1, operand layout
+#define L_FLAG (L_DS + 288)              // 12    ints: [0] not-SPD/timeout, [1] ready, [2] tile_ready, [3] alpha_ready,
+                                         //       [5] sub_cnt, [8..23] pre_cnt[s] (backward-solve hand-over counters)
+#define L_LINV (L_FLAG + 12)              // 16*256 L_kk^-1, operand layout
 #define L_LINVT (L_LINV + 16 * 256)      // 16*256 L_kk^-T, operand layout (backward solve)
 #define L_PANP (L_LINVT + 16 * 256)      // 2 x 16*256 panel L_ik, operand layout, double-buffered by k & 1 (also the
                                          // predict reduction buffer: 8*4*256)
@@ -302,10 +302,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     // 32-bit LDS byte addresses of the two words for the ds_read polling loops (dynamic LDS starts after the static part)
     const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
     const unsigned ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 4), tile_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 8);
-    const unsigned alpha_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 12), pre_cnt_addr = lds0 + (unsigned)(L_FLAG * 8 + 16);
+    const unsigned alpha_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 12), pre_cnt_addr = lds0 + (unsigned)(L_FLAG * 8 + 32);
     const unsigned sub_cnt_addr = lds0 + (unsigned)(L_FLAG * 8 + 20);
     int* alpha_ready = flag + 3;
-    int* pre_cnt = flag + 4;
+    int* pre_cnt = flag + 8;      // one counter per backward iteration: a single running counter lets fast, tile-less
+                                  // workers of iteration s stand in for a slow worker of iteration s-1
     int* sub_cnt = flag + 5;
     double* Linv = lds + L_LINV;
     double* LinvT = lds + L_LINVT;
@@ -377,9 +378,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             flag[1] = -1;
             flag[2] = -1;
             flag[3] = 0;
-            flag[4] = 0;
             flag[5] = 0;
         }
+        if (tid < 16) flag[8 + tid] = 0;
         __syncthreads();
 
         unsigned live_mask = 0;   // slots whose tile row is live (ti < nt)
@@ -572,8 +573,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         for (int s = 0; s < nt; ++s) {
             const int k = nt - 1 - s;
             if (is_factor) {
-                timed_out |= !mf_wait_ge(pre_cnt_addr, MF_WORKERS * s);
+                if (s > 0) timed_out |= !mf_wait_ge(pre_cnt_addr + 4u * (unsigned)(s - 1), MF_WORKERS);
                 timed_out |= !mf_wait_ge(sub_cnt_addr, s);
+                MF_STAMP_FINE(10);
                 // alpha_k = L_kk^-T u as one 16x16x16 MFMA product: column n < ny of the B operand carries u of channel n
                 const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
                 const d4 lt = *reinterpret_cast<const d4*>(LinvT + k * 256 + ln * 4);
@@ -596,6 +598,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     for (int r = 0; r < 4; ++r) av[lr * MF_NPAD + MF_TS * k + lg + 4 * r] = al[r];
                 }
                 mf_publish(alpha_ready, s + 1);
+                MF_STAMP_FINE(11);
             } else {
                 const int j = k - 1;                // the column being accumulated
                 if (j >= 0) {
@@ -623,13 +626,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         }
                     }
                 }
-                if (lane == 0) __hip_atomic_fetch_add(pre_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) __hip_atomic_fetch_add(pre_cnt + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                MF_STAMP_FINE(1);
                 if (j >= 0) {
                     // (b) the sub-diagonal tile (k, j): idx = cs(j) + 1
                     const int idx1 = __builtin_amdgcn_readfirstlane(mf_cs(j, NT) + 1);
                     if (wave == idx1 % MF_WORKERS) {
                         const unsigned smask = __builtin_amdgcn_readfirstlane(1u << (idx1 / MF_WORKERS));
                         timed_out |= !mf_wait_ge(alpha_ready_addr, s + 1);
+                        MF_STAMP_FINE(10);
                         for (int c = 0; c < ny; ++c) {
                             const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
                             d4 pa = d4{0.0, 0.0, 0.0, 0.0};
@@ -647,6 +652,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                             }
                         }
                         if (lane == 0) __hip_atomic_fetch_add(sub_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        MF_STAMP_FINE(11);
                     }
                 }
             }
@@ -796,7 +802,7 @@ int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a)
             (void)hipFree(d);
             static const char* names[MF_NPH] = {"load+gram", "wait ready | B2 (factor)", "trsm | z+publish (factor)", "wait B2 | y_j (factor)",
                                                 "diag tile upd | wait tile (factor)", "y rows | diag factor (factor)", "trailing update",
-                                                "post-loop", "backward", "predict", "bwd: worker part (fine)", "bwd: factor part (fine)"};
+                                                "post-loop", "backward", "predict", "bwd: waits (fine)", "bwd: alpha | sub-diag product (fine)"};
             fprintf(stderr, "[MF_STAMPS] mean cycles per patch, by wave (s_memtime ticks); wave 7 is the factor wave:\n%-36s", "phase");
             for (int w = 0; w < MF_WAVES; ++w) fprintf(stderr, "   wave%d", w);
             fprintf(stderr, "\n");
