@@ -440,13 +440,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 #define MF_TRSM_CASE(t)                                                                                              \
     if constexpr (t < TPW) {                                                                                         \
         if (smask & (1u << t)) {                                                                                     \
-            d4 D1 = d4{0.0, 0.0, 0.0, 0.0}, D2 = d4{0.0, 0.0, 0.0, 0.0};                                             \
-            if (!MF_ABL_TRSM) {                                                                                      \
-            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], acc[t][0], D1, 0, 0, 0);                                \
-            D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], acc[t][2], D2, 0, 0, 0);                                \
-            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], acc[t][1], D1, 0, 0, 0);                                \
-            D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], acc[t][3], D2, 0, 0, 0);                                \
-            acc[t] = D1 + D2; /* = L_ik[l & 15][(l>>4) + 4 r] */ }                                                   \
+            if (!MF_ABL_TRSM) {   /* four independent products (one MFMA latency instead of four), then a tree sum */ \
+            const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};                                                                    \
+            const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], acc[t][0], z4, 0, 0, 0);                       \
+            const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], acc[t][1], z4, 0, 0, 0);                       \
+            const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], acc[t][2], z4, 0, 0, 0);                       \
+            const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], acc[t][3], z4, 0, 0, 0);                       \
+            acc[t] = (D0 + D1) + (D2 + D3); /* = L_ik[l & 15][(l>>4) + 4 r] */ }                                     \
             *reinterpret_cast<d4*>(panP + ti_(t) * 256 + mf_opaque(lane) * 4) = acc[t];                              \
         }                                                                                                            \
     }
@@ -468,12 +468,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         if (smask & (1u << t)) {                                                                                     \
             /* blgp = 1 on the f64 MFMA is NEG(A): acc - a*b  (tools/probe_mfma_f64.hip) */                          \
             if (!MF_ABL_PASS1) {                                                                                     \
-                d4 S2 = d4{0.0, 0.0, 0.0, 0.0};   /* two chains of two: halves the dependent MFMA latency */       \
+                const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};   /* independent products: one MFMA latency on the chain */  \
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[t], 0, 0, 1);                          \
-                S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], a[2], S2, 0, 0, 1);                                  \
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], a[1], acc[t], 0, 0, 1);                          \
-                S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], a[3], S2, 0, 0, 1);                                  \
-                acc[t] += S2;                                                                                        \
+                const d4 S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], a[1], z4, 0, 0, 1);                         \
+                const d4 S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], a[2], z4, 0, 0, 1);                         \
+                const d4 S3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], a[3], z4, 0, 0, 1);                         \
+                acc[t] += (S1 + S2) + S3;                                                                            \
             }                                                                                                        \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) DS[(lg + 4 * r) * 17 + lr] = acc[t][r];                    \
         }                                                                                                            \
@@ -587,12 +587,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         ub[q4] = zv[q] - wsum[q];
                     }
                 }
-                d4 D1 = d4{0.0, 0.0, 0.0, 0.0}, D2 = d4{0.0, 0.0, 0.0, 0.0};
-                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], ub[0], D1, 0, 0, 0);
-                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], ub[2], D2, 0, 0, 0);
-                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], ub[1], D1, 0, 0, 0);
-                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], ub[3], D2, 0, 0, 0);
-                const d4 al = D1 + D2;              // lanes lr = n < ny: alpha_n[16 k + (l>>4) + 4 r]
+                const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
+                const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], ub[0], z4, 0, 0, 0);
+                const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], ub[1], z4, 0, 0, 0);
+                const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], ub[2], z4, 0, 0, 0);
+                const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], ub[3], z4, 0, 0, 0);
+                const d4 al = (D0 + D1) + (D2 + D3);   // lanes lr = n < ny: alpha_n[16 k + (l>>4) + 4 r]
                 if (lr < ny) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) av[lr * MF_NPAD + MF_TS * k + lg + 4 * r] = al[r];
@@ -644,12 +644,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         if (smask & (1u << t)) pa = acc[t] * ak;                                                                     \
     }
                             MF_SLOTS(MF_BWD1_CASE)
+                            // on the critical chain: let the LDS atomic unit do the 16-lane sums (4 ds_add_f64, 16 lanes
+                            // per address) instead of a ~130-instruction DPP reduction
 #pragma unroll
-                            for (int q4 = 0; q4 < 4; ++q4) pa[q4] = mf_row_allsum(pa[q4]);
-                            if (lr == 0) {
-#pragma unroll
-                                for (int q4 = 0; q4 < 4; ++q4) atomicAdd(wsum + c * MF_NPAD + MF_TS * j + lg + 4 * q4, pa[q4]);
-                            }
+                            for (int q4 = 0; q4 < 4; ++q4) atomicAdd(wsum + c * MF_NPAD + MF_TS * j + lg + 4 * q4, pa[q4]);
+                            (void)lr;
                         }
                         if (lane == 0) __hip_atomic_fetch_add(sub_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         MF_STAMP_FINE(11);
