@@ -189,12 +189,33 @@ __device__ static __forceinline__ double mf_rcp(double d)
     return y;
 }
 
+// ---- operand image ------------------------------------------------------------------------------------------
+// A 16 x 16 matrix M as MFMA A/B operand data: lane l needs M[l & 15][(l >> 4) + 4 s], s = 0..3.  The image is two
+// planes of 64 x 16 bytes: plane s>>1 holds, for lane l, the pair (s&1 = 0, 1) at byte l*16.  Each ds_read_b128 /
+// ds_write_b128 then moves 16 contiguous bytes per lane at a 16-byte lane stride, which is bank-conflict free (a
+// single 32-byte-per-lane image makes every b128 access a 2-way conflict: rocprof showed 30 % of the LDS cycles lost).
+typedef double d2 __attribute__((ext_vector_type(2)));
+#define MF_IMG 256   // doubles per image
+__device__ static __forceinline__ int mf_img_off(int l, int s) { return (s >> 1) * 128 + l * 2 + (s & 1); }
+// element (r, c) of M (c is the contraction index)
+__device__ static __forceinline__ int mf_img_rc(int r, int c) { return mf_img_off(r + 16 * (c & 3), c >> 2); }
+__device__ static __forceinline__ d4 mf_img_load(const double* img, int l)
+{
+    const d2 a = *reinterpret_cast<const d2*>(img + l * 2);
+    const d2 b = *reinterpret_cast<const d2*>(img + 128 + l * 2);
+    return d4{a[0], a[1], b[0], b[1]};
+}
+__device__ static __forceinline__ void mf_img_store(double* img, int l, d4 v)
+{
+    *reinterpret_cast<d2*>(img + l * 2) = d2{v[0], v[1]};
+    *reinterpret_cast<d2*>(img + 128 + l * 2) = d2{v[2], v[3]};
+}
+
 // Inverse Cholesky factor of the 16 x 16 SPD tile in S (row stride 17).  Square-root-free forward elimination on
 // [A | I] gives [D Lu^T | Lu^-1] with Lu unit lower triangular; L^-1 = D^-1/2 Lu^-1.  Only the reciprocal of the
 // pivot sits on the dependency chain, the 16 reciprocal square roots are independent of each other.
 // One wave; lane j < 16 holds column j of A, lane 16 + j column j of I (lanes 32..63 mirror them); the multipliers
-// are wave-uniform (v_readlane).  Writes L^-1 and L^-T in operand layout (element (r, c) of the stored matrix at
-// (r + 16 (c & 3)) * 4 + (c >> 2)) and returns false when a pivot is <= pivot_tol.
+// are wave-uniform (v_readlane).  Writes L^-1 and L^-T in operand layout (mf_img_rc) and returns false when a pivot is <= pivot_tol.
 __device__ __forceinline__ static bool mf_diag_factor(const double* S, double* Linv_out, double* LinvT_out, double pivot_tol)
 {
     const int lane = threadIdx.x & 63;
@@ -215,24 +236,21 @@ __device__ __forceinline__ static bool mf_diag_factor(const double* S, double* L
     }
     if ((lane >> 4) == 1) {
 #pragma unroll
-        for (int i = 0; i < MF_TS; ++i) Linv_out[(i + 16 * (j & 3)) * 4 + (j >> 2)] = reg[i];   // (r = i, c = j)
-        // L^-T: element (r = j, c = i) = Linv[i][j]: for fixed j the four i = g, g+4, g+8, g+12 are contiguous
+        for (int i = 0; i < MF_TS; ++i) Linv_out[mf_img_rc(i, j)] = reg[i];                     // (r = i, c = j)
+        // L^-T: element (r = j, c = i) = Linv[i][j]: for fixed j the four i = g, g+4, g+8, g+12 belong to one lane image
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-            *reinterpret_cast<d4*>(LinvT_out + (j + 16 * gq) * 4) = d4{reg[gq], reg[gq + 4], reg[gq + 8], reg[gq + 12]};
+        for (int gq = 0; gq < 4; ++gq) mf_img_store(LinvT_out, j + 16 * gq, d4{reg[gq], reg[gq + 4], reg[gq + 8], reg[gq + 12]});
     }
     return ok;
 }
 
-// out[mr] = sum_kk M[mr][kk] * v[kk] for a 16 x 16 matrix stored as an operand image (row mr = 4 chunks of 4 doubles
-// at (mr + 16 g) * 4, holding k = g, g+4, g+8, g+12), one thread per row.
+// out[mr] = sum_kk M[mr][kk] * v[kk] for a 16 x 16 matrix stored as an operand image, one thread per row
 __device__ static __forceinline__ double mf_row_dot(const double* img, int mr, const double* v)
 {
-    const double* Pr = img + mr * 4;
     double s_ = 0.0;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-        const d4 ch = *reinterpret_cast<const d4*>(Pr + gq * 64);
+        const d4 ch = mf_img_load(img, mr + 16 * gq);      // k = gq, gq+4, gq+8, gq+12
 #pragma unroll
         for (int s = 0; s < 4; ++s) s_ = __builtin_fma(ch[s], v[gq + 4 * s], s_);
     }
@@ -278,6 +296,25 @@ __device__ static __forceinline__ double mf_row_allsum(double v)
     v += mf_dpp<0x124>(v);
     v += mf_dpp<0x128>(v);
     return v;
+}
+
+// Sums the four components of x over the 16 lanes of a DPP row in 5 exchange rounds instead of 16: after the xor-8 and
+// half-mirror rounds a lane keeps only ONE component, sel = 2 (l>>3 & 1) + (l>>2 & 1), which the two quad rounds finish.
+// Every lane returns the row total of its component `sel` (so lanes l&3 == 0 hold one total each: 0, 1, 2, 3 at l&15 =
+// 0, 4, 8, 12).  ~40 VALU instructions against ~130 for four independent all-reduces.
+__device__ static __forceinline__ double mf_row_reduce4(d4 x, int lr)
+{
+    const bool hi8 = (lr & 8) != 0, hi4 = (lr & 4) != 0;
+    double k0 = hi8 ? x[2] : x[0], k1 = hi8 ? x[3] : x[1];
+    const double s0 = hi8 ? x[0] : x[2], s1 = hi8 ? x[1] : x[3];
+    k0 += mf_dpp<0x128>(s0);            // row_ror:8  (l <-> l ^ 8)
+    k1 += mf_dpp<0x128>(s1);
+    double k = hi4 ? k1 : k0;
+    const double sd = hi4 ? k0 : k1;
+    k += mf_dpp<0x141>(sd);             // row_half_mirror (l <-> 7 - l inside each half row)
+    k += mf_dpp<0xB1>(k);               // quad_perm [1,0,3,2]
+    k += mf_dpp<0x4E>(k);               // quad_perm [2,3,0,1]
+    return k;
 }
 
 template <int NT>
@@ -400,11 +437,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     const int pi = MF_TS * ti_(t) + lr;
                     const double xi0 = px0[pi], xi1 = px1[pi];
                     const bool edge = MF_TS * ti_(t) + MF_TS > n;   // tile touches the identity padding (wave-uniform)
+                    const bool diag_tile = ti_(t) == tj_(t);        // only these carry the noise diagonal (wave-uniform)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int pj = MF_TS * tj_(t) + lg + 4 * r;
                         double v = gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T);
-                        if (pi == pj) {
+                        if (diag_tile && pi == pj) {
                             v += noise;                              // covariance_matrix(..., training)  :59-61
                             if (A.prm.ref_double_noise) v += noise;  // C.diagonal() += sigman_sq        :21
                         }
@@ -436,7 +474,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     const int t_hi = __builtin_amdgcn_readfirstlane((hi_ + 7) / 7 - 1);
                     const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_lo, t_hi) & live_mask);
                     if (smask) {
-                        const d4 lv = *reinterpret_cast<const d4*>(Linv + k * 256 + mf_opaque(lane) * 4);
+                        const d4 lv = mf_img_load(Linv + k * MF_IMG, mf_opaque(lane));
 #define MF_TRSM_CASE(t)                                                                                              \
     if constexpr (t < TPW) {                                                                                         \
         if (smask & (1u << t)) {                                                                                     \
@@ -447,7 +485,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], acc[t][2], z4, 0, 0, 0);                       \
             const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], acc[t][3], z4, 0, 0, 0);                       \
             acc[t] = (D0 + D1) + (D2 + D3); /* = L_ik[l & 15][(l>>4) + 4 r] */ }                                     \
-            *reinterpret_cast<d4*>(panP + ti_(t) * 256 + mf_opaque(lane) * 4) = acc[t];                              \
+            mf_img_store(panP + ti_(t) * MF_IMG, mf_opaque(lane), acc[t]);                                          \
         }                                                                                                            \
     }
                         MF_SLOTS(MF_TRSM_CASE)
@@ -462,7 +500,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     if (wave == idx1 % MF_WORKERS) {
                         const unsigned smask = __builtin_amdgcn_readfirstlane(1u << (idx1 / MF_WORKERS));
                         const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                        const d4 a = *reinterpret_cast<const d4*>(panP + (k + 1) * 256 + ln * 4);
+                        const d4 a = mf_img_load(panP + (k + 1) * MF_IMG, ln);
 #define MF_DIAG_CASE(t)                                                                                              \
     if constexpr (t < TPW) {                                                                                         \
         if (smask & (1u << t)) {                                                                                     \
@@ -497,9 +535,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 #define MF_UPD_CASE(t)                                                                                               \
     if constexpr (t < TPW) {                                                                                         \
         if (!MF_ABL_UPD && (smask & (1u << t))) {                                                                    \
-            const int ln4 = mf_opaque(lane) * 4;                                                                     \
-            const d4 a = *reinterpret_cast<const d4*>(panP + tj_(t) * 256 + ln4);                                    \
-            const d4 b = *reinterpret_cast<const d4*>(panP + ti_(t) * 256 + ln4);                                    \
+            const int lnq = mf_opaque(lane);                                                                         \
+            const d4 a = mf_img_load(panP + tj_(t) * MF_IMG, lnq);                                                   \
+            const d4 b = mf_img_load(panP + ti_(t) * MF_IMG, lnq);                                                   \
             _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                            \
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc[t], 0, 0, 1);                          \
         }                                                                                                            \
@@ -578,7 +616,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 MF_STAMP_FINE(10);
                 // alpha_k = L_kk^-T u as one 16x16x16 MFMA product: column n < ny of the B operand carries u of channel n
                 const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                const d4 lt = *reinterpret_cast<const d4*>(LinvT + k * 256 + ln * 4);
+                const d4 lt = mf_img_load(LinvT + k * MF_IMG, ln);
                 d4 ub = d4{0.0, 0.0, 0.0, 0.0};
                 if (lr < ny) {
 #pragma unroll
@@ -617,12 +655,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         if (smask & (1u << t)) pa += acc[t] * avc[MF_TS * ti_(t)];                                                   \
     }
                             MF_SLOTS(MF_BWD_CASE)
-#pragma unroll
-                            for (int q4 = 0; q4 < 4; ++q4) pa[q4] = mf_row_allsum(pa[q4]);
-                            if (lr == 0) {
-#pragma unroll
-                                for (int q4 = 0; q4 < 4; ++q4) atomicAdd(wsum + c * MF_NPAD + MF_TS * j + lg + 4 * q4, pa[q4]);
-                            }
+                            const double tot = mf_row_reduce4(pa, lr);       // lanes lr = 0, 4, 8, 12 hold components 0..3
+                            if ((lr & 3) == 0) atomicAdd(wsum + c * MF_NPAD + MF_TS * j + lg + 4 * (lr >> 2), tot);
                         }
                     }
                 }
@@ -644,11 +678,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         if (smask & (1u << t)) pa = acc[t] * ak;                                                                     \
     }
                             MF_SLOTS(MF_BWD1_CASE)
-                            // on the critical chain: let the LDS atomic unit do the 16-lane sums (4 ds_add_f64, 16 lanes
-                            // per address) instead of a ~130-instruction DPP reduction
-#pragma unroll
-                            for (int q4 = 0; q4 < 4; ++q4) atomicAdd(wsum + c * MF_NPAD + MF_TS * j + lg + 4 * q4, pa[q4]);
-                            (void)lr;
+                            // (letting the LDS atomic unit do the 16-lane sums -- 4 ds_add_f64 with 16 lanes per address --
+                            // was measured slower than this DPP reduction: +5.6k cycles per patch)
+                            const double tot = mf_row_reduce4(pa, lr);
+                            if ((lr & 3) == 0) atomicAdd(wsum + c * MF_NPAD + MF_TS * j + lg + 4 * (lr >> 2), tot);
                         }
                         if (lane == 0) __hip_atomic_fetch_add(sub_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         MF_STAMP_FINE(11);

@@ -61,6 +61,18 @@ def test_tile_enumeration_covers_lower_triangle_once():
             assert max(cnt) - min(cnt) <= 1
 
 
+def img_off(l, s):
+    """operand image of csrc/dense_mfma.hip (mf_img_off): two planes of 64 lanes x 2 doubles."""
+    return (s >> 1) * 128 + l * 2 + (s & 1)
+
+
+def img_rc(r, c):
+    return img_off(r + 16 * (c & 3), c >> 2)
+
+
+IMG_LS = np.array([[img_off(l, s) for s in range(4)] for l in range(64)])   # (64, 4) gather index: lane, s -> offset
+
+
 def diag_factor(S):
     """mf_diag_factor: forward elimination on [A | I] -> [L^T | L^-1], lane = column; returns the operand image."""
     reg = np.zeros((16, 32))            # reg[i][lane]
@@ -79,7 +91,7 @@ def diag_factor(S):
     out = np.zeros(256)
     for j in range(16):
         for i in range(16):
-            out[(i + 16 * (j & 3)) * 4 + (j >> 2)] = reg[i, 16 + j]
+            out[img_rc(i, j)] = reg[i, 16 + j]
     return out, ok
 
 
@@ -115,13 +127,13 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
     DS = np.zeros(16 * 17)
     for k in range(-1, nt):
         if k >= 0:
-            lv = Linv[k].reshape(64, 4)
+            lv = Linv[k][IMG_LS]
             # z_k = L_kk^-1 y_k by 16 row-threads reading the operand image: row m = 4 chunks of 4 at (m + 16 g) * 4
             for c in range(ny):
                 for mrow in range(16):
                     s_ = 0.0
                     for gq in range(4):
-                        ch = Linv[k][(mrow + 16 * gq) * 4:(mrow + 16 * gq) * 4 + 4]
+                        ch = Linv[k][IMG_LS[mrow + 16 * gq]]
                         for s in range(4):
                             s_ += ch[s] * yc[c, 16 * k + gq + 4 * s]
                     zv[c, 16 * k + mrow] = s_
@@ -133,21 +145,21 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
                 D2 = mfma(lv[:, 3], acc[(i, k)][:, 3], D2)
                 D = D1 + D2
                 acc[(i, k)] = D
-                pan[i] = D.reshape(256)
+                pan[i][IMG_LS] = D
             # y_i -= L_ik z_k by row-threads reading the LDS panel
             for i in range(k + 1, nt):
                 for mrow in range(16):
                     for c in range(ny):
                         s_ = 0.0
                         for gq in range(4):
-                            ch = pan[i][(mrow + 16 * gq) * 4:(mrow + 16 * gq) * 4 + 4]
+                            ch = pan[i][IMG_LS[mrow + 16 * gq]]
                             for s in range(4):
                                 s_ += ch[s] * zv[c, 16 * k + gq + 4 * s]
                         yc[c, 16 * i + mrow] -= s_
         if k + 1 < nt:
             a_ = acc[(k + 1, k + 1)]
             if k >= 0:
-                p = pan[k + 1].reshape(64, 4)
+                p = pan[k + 1][IMG_LS]
                 for s in range(4):
                     a_ = mfma(p[:, s], p[:, s], a_, neg_a=True)
                 acc[(k + 1, k + 1)] = a_
@@ -160,8 +172,8 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
                 for i in range(j, nt):
                     if (i, j) == (k + 1, k + 1):
                         continue
-                    a = pan[j].reshape(64, 4)
-                    b = pan[i].reshape(64, 4)
+                    a = pan[j][IMG_LS]
+                    b = pan[i][IMG_LS]
                     t = acc[(i, j)]
                     for s in range(4):
                         t = mfma(a[:, s], b[:, s], t, neg_a=True)
@@ -180,7 +192,7 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
             for cc in range(16):
                 a_ = 0.0
                 for mm in range(16):
-                    a_ += Linv[k][(mm + 16 * (cc & 3)) * 4 + (cc >> 2)] * u[mm]
+                    a_ += Linv[k][img_rc(mm, cc)] * u[mm]
                 av[c, 16 * k + cc] = a_
     # separable predictive mean on the sz x sz grid, wave w takes points [32 w, 32 w + 32)
     f = np.zeros((ny, sz * sz))
@@ -239,3 +251,27 @@ def test_register_tile_data_flow_matches_cholesky_solve():
             if i > k:
                 for r in range(4):
                     assert np.allclose(t[:, r], Lp[16 * i + LR, 16 * k + LG + 4 * r], rtol=0, atol=1e-13)
+
+
+def test_transposing_row_reduction():
+    """mf_row_reduce4 (csrc/dense_mfma.hip): four components summed over the 16 lanes of a DPP row in five rounds --
+    row_ror:8 (l <-> l^8), row_half_mirror (l <-> 7-l inside each half row), quad_perm [1,0,3,2] and [2,3,0,1]."""
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(16, 4))
+    l = np.arange(16)
+    hi8, hi4 = (l & 8) != 0, (l & 4) != 0
+    ror8 = lambda v: v[(l + 8) % 16]
+    half_mirror = lambda v: v[np.where(l < 8, 7 - l, 23 - l)]
+    qp = lambda v, perm: v[(l & ~3) | np.array(perm)[l & 3]]
+    k0 = np.where(hi8, x[:, 2], x[:, 0]); k1 = np.where(hi8, x[:, 3], x[:, 1])
+    s0 = np.where(hi8, x[:, 0], x[:, 2]); s1 = np.where(hi8, x[:, 1], x[:, 3])
+    k0 = k0 + ror8(s0); k1 = k1 + ror8(s1)
+    k = np.where(hi4, k1, k0); sd = np.where(hi4, k0, k1)
+    k = k + half_mirror(sd)
+    k = k + qp(k, [1, 0, 3, 2])
+    k = k + qp(k, [2, 3, 0, 1])
+    tot = x.sum(axis=0)
+    for lane in (0, 4, 8, 12):
+        assert abs(k[lane] - tot[lane >> 2]) < 1e-12
+    sel = 2 * ((l >> 3) & 1) + ((l >> 2) & 1)
+    assert np.allclose(k, tot[sel])
