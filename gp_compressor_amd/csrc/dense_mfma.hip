@@ -111,7 +111,7 @@ struct MfmaParams {
 #define L_ZV (L_YC + 3 * MF_NPAD)        // 3*256 z = L^-1 y
 #define L_WV (L_ZV + 3 * MF_NPAD)        // 3*256 backward-solve accumulators w_k[c][16 k + .] (ds_add_f64 targets)
 #define L_AV (L_WV + 3 * MF_NPAD)        // 3*256 alpha
-#define L_DS (L_AV + 3 * MF_NPAD)        // 16*17 (+ pad to 288) diagonal-tile hand-over scratch
+#define L_DS (L_AV + 3 * MF_NPAD)        // 256 + 16 (+ pad to 288) diagonal-tile hand-over (register layout) + rsqrt row
 #define L_FLAG (L_DS + 288)              // 12    ints: [0] not-SPD/timeout, [1] ready, [2] tile_ready, [3] alpha_ready,
                                          //       [5] sub_cnt, [8..23] pre_cnt[s] (backward-solve hand-over counters)
 #define L_LINV (L_FLAG + 12)              // 16*256 L_kk^-1, operand layout
@@ -211,36 +211,56 @@ __device__ static __forceinline__ void mf_img_store(double* img, int l, d4 v)
     *reinterpret_cast<d2*>(img + 128 + l * 2) = d2{v[2], v[3]};
 }
 
-// Inverse Cholesky factor of the 16 x 16 SPD tile in S (row stride 17).  Square-root-free forward elimination on
-// [A | I] gives [D Lu^T | Lu^-1] with Lu unit lower triangular; L^-1 = D^-1/2 Lu^-1.  Only the reciprocal of the
-// pivot sits on the dependency chain, the 16 reciprocal square roots are independent of each other.
-// One wave; lane j < 16 holds column j of A, lane 16 + j column j of I (lanes 32..63 mirror them); the multipliers
-// are wave-uniform (v_readlane).  Writes L^-1 and L^-T in operand layout (mf_img_rc) and returns false when a pivot is <= pivot_tol.
-__device__ __forceinline__ static bool mf_diag_factor(const double* S, double* Linv_out, double* LinvT_out, double pivot_tol)
+// Inverse Cholesky factor of a 16 x 16 SPD tile, on the MFMA pipe.  `Wt` holds the tile in C/D register layout
+// (lane l, register r: A[(l>>4) + 4 r][l & 15]; the diagonal tile is symmetric, so the workers' transposed storage is
+// the same thing).  Square-root-free Gauss-Jordan elimination IN PLACE: pivot c is ONE rank-1 v_mfma_f64_16x16x4
+//     W[i][j] -= m_i * w_j,   m_i = W[i][c] / p_c (i > c, else 0),   w_j = W[c][j] + [j == c]
+// whose only non-zero contraction slot is k = c & 3 -- pivot row c lives in register c >> 2 of exactly the 16 lanes
+// that form slot k of both operands, so no data moves across lanes.  Columns j > c are the Schur complement, columns
+// j < c the rows of the unit-lower inverse Lu^-1, and the dead column c receives -m_i = Lu^-1[i][c]: after 15 pivots the
+// tile is [D Lu^T \ Lu^-1] and L^-1 = D^-1/2 Lu^-1.  The reciprocal of pivot c+1 is formed one step AHEAD from two
+// scalars of the current tile (p_(c+1) = W[c+1][c+1] - W[c][c+1]^2 / p_c), so the dependency chain per pivot is
+// one MFMA plus two VALU ops; the square roots are taken once, vectorised, at the end.  (The previous version ran the
+// elimination on the VALU with v_readlane multipliers: ~650 dependent-issue instructions, 4.6k cycles per tile, on
+// the critical path of every step.)  Writes L^-1 and L^-T as operand images; false when a pivot is <= pivot_tol.
+__device__ __forceinline__ static bool mf_diag_factor(const double* Wt, double* rsbuf, double* Linv_out, double* LinvT_out,
+                                                      double pivot_tol)
 {
     const int lane = threadIdx.x & 63;
-    const int j = lane & 15;
-    const bool ident = (lane & 16) != 0;
-    double reg[MF_TS];
+    const int lr = lane & 15, lg = lane >> 4;
+    d4 W = *reinterpret_cast<const d4*>(Wt + lane * 4);
+    double rp = mf_rcp(mf_readlane(W[0], 0));
 #pragma unroll
-    for (int i = 0; i < MF_TS; ++i) reg[i] = ident ? (i == j ? 1.0 : 0.0) : S[i * 17 + j];
-    bool ok = true;
-#pragma unroll
-    for (int c = 0; c < MF_TS; ++c) {
-        const double d = mf_readlane(reg[c], c);
-        ok = ok && (d > pivot_tol);
-        const double prow = reg[c] * mf_rcp(d);       // pivot row / pivot
-        reg[c] *= mf_rsqrt(d);                         // row c is final: row c of L^-1 = row c of Lu^-1 / sqrt(d_c)
-#pragma unroll                                         // (off the dependency chain: nothing below reads reg[c])
-        for (int i = c + 1; i < MF_TS; ++i) reg[i] = __builtin_fma(-mf_readlane(reg[i], c), prow, reg[i]);
+    for (int c = 0; c < MF_TS - 1; ++c) {
+        const int q = c & 3, r = c >> 2, q1 = (c + 1) & 3, r1 = (c + 1) >> 2;
+        const bool inq = lg == q;
+        const double s01 = mf_readlane(W[r], 16 * q + c + 1);      // W[c][c+1]
+        const double s11 = mf_readlane(W[r1], 16 * q1 + c + 1);    // W[c+1][c+1]
+        const double rpv = (inq && lr > c) ? rp : 0.0;
+        const double ev = (inq && lr == c) ? 1.0 : 0.0;
+        const double a_op = W[r] * rpv;
+        const double b_op = __builtin_fma(W[r], inq ? 1.0 : 0.0, ev);
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, W, 0, 0, 1);   // blgp = 1: NEG(A)
+        const double t = s01 * rp;
+        rp = mf_rcp(__builtin_fma(-t, s01, s11));
     }
-    if ((lane >> 4) == 1) {
+    // the pivots are the diagonal of the tile: row lg + 4 r == column lr  <=>  lane 16 (i & 3) + i, register i >> 2
+    const int rsel = lr >> 2;
+    const double pd = rsel == 0 ? W[0] : rsel == 1 ? W[1] : rsel == 2 ? W[2] : W[3];
+    const bool on_diag = (lr & 3) == lg;
+    const bool ok = __builtin_amdgcn_ballot_w64(on_diag && !(pd > pivot_tol)) == 0;
+    const double rs = mf_rsqrt(on_diag ? pd : 1.0);
+    if (on_diag) rsbuf[lr] = rs;       // one wave: LDS operations execute in program order, no barrier needed
+    d4 fin;
 #pragma unroll
-        for (int i = 0; i < MF_TS; ++i) Linv_out[mf_img_rc(i, j)] = reg[i];                     // (r = i, c = j)
-        // L^-T: element (r = j, c = i) = Linv[i][j]: for fixed j the four i = g, g+4, g+8, g+12 belong to one lane image
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) mf_img_store(LinvT_out, j + 16 * gq, d4{reg[gq], reg[gq + 4], reg[gq + 8], reg[gq + 12]});
+    for (int r = 0; r < 4; ++r) {
+        const int row = lg + 4 * r;
+        const double rsr = rsbuf[row];
+        fin[r] = (lr < row) ? W[r] * rsr : (lr == row ? rsr : 0.0);
     }
+    mf_img_store(LinvT_out, lane, fin);     // C/D registers of L^-1 = operand image of L^-T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Linv_out[mf_img_rc(lg + 4 * r, lr)] = fin[r];
     return ok;
 }
 
@@ -453,9 +473,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             }
             // tile (0, 0) goes to the factor wave at once
             if (wave == 0) {
-                const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) DS[(lg + 4 * r) * 17 + lr] = acc[0][r];
+                const int ln = mf_opaque(lane);
+                *reinterpret_cast<d4*>(DS + ln * 4) = acc[0];   // register layout, as the factor wave consumes it
                 mf_publish(tile_ready, 0);
             }
             MF_STAMP(0);
@@ -499,7 +518,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     const int idx1 = __builtin_amdgcn_readfirstlane(mf_cs(k + 1, NT));
                     if (wave == idx1 % MF_WORKERS) {
                         const unsigned smask = __builtin_amdgcn_readfirstlane(1u << (idx1 / MF_WORKERS));
-                        const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
+                        const int ln = mf_opaque(lane);
                         const d4 a = mf_img_load(panP + (k + 1) * MF_IMG, ln);
 #define MF_DIAG_CASE(t)                                                                                              \
     if constexpr (t < TPW) {                                                                                         \
@@ -513,7 +532,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 const d4 S3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], a[3], z4, 0, 0, 1);                         \
                 acc[t] += (S1 + S2) + S3;                                                                            \
             }                                                                                                        \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) DS[(lg + 4 * r) * 17 + lr] = acc[t][r];                    \
+            *reinterpret_cast<d4*>(DS + ln * 4) = acc[t];                                                            \
         }                                                                                                            \
     }
                         MF_SLOTS(MF_DIAG_CASE)
@@ -569,7 +588,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 }
                 if (!MF_ABL_NOWAIT) timed_out |= !mf_wait_ge(tile_ready_addr, j);
                 MF_STAMP_FINE(4);
-                const bool ok = MF_ABL_DIAG ? true : mf_diag_factor(DS, Linv + j * 256, LinvT + j * 256, g.pivot_tol);
+                const bool ok = MF_ABL_DIAG ? true : mf_diag_factor(DS, DS + 256, Linv + j * 256, LinvT + j * 256, g.pivot_tol);
                 MF_STAMP_FINE(5);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 // z_j = L_jj^-1 y_j  (y_j already carries -sum_{i<j} L_ji z_i): 16 row-threads

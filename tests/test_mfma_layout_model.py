@@ -73,26 +73,36 @@ def img_rc(r, c):
 IMG_LS = np.array([[img_off(l, s) for s in range(4)] for l in range(64)])   # (64, 4) gather index: lane, s -> offset
 
 
-def diag_factor(S):
-    """mf_diag_factor: forward elimination on [A | I] -> [L^T | L^-1], lane = column; returns the operand image."""
-    reg = np.zeros((16, 32))            # reg[i][lane]
-    for lane in range(32):
-        j = lane & 15
-        reg[:, lane] = (np.arange(16) == j) if lane & 16 else S[np.arange(16) * 17 + j]
-    ok = True
-    for c in range(16):
-        d = reg[c, c]
-        ok = ok and d > 0
-        rs = 1.0 / np.sqrt(d)
-        reg[c, :] *= rs
-        for i in range(c + 1, 16):
-            mlt = reg[i, c] * rs
-            reg[i, :] -= mlt * reg[c, :]
+def diag_factor(Wc):
+    """mf_diag_factor: in-place Gauss-Jordan on the MFMA pipe.  Wc (64, 4) is the SPD tile in the C/D layout
+    (Wc[l][r] = A[(l>>4) + 4 r][l & 15]).  Pivot c = one rank-1 MFMA whose only non-zero contraction slot is
+    k = c & 3: the A operand carries the multipliers of the rows below the pivot, the B operand the pivot row with
+    1 added in column c, so that column c of the tile (dead after the elimination) receives column c of the unit
+    lower inverse.  The reciprocal of the next pivot is formed one step ahead from two scalars of the current
+    tile.  Returns the operand image of L^-1, the C/D-layout registers of L^-1 (= operand image of L^-T) and ok."""
+    W = Wc.copy()
+    rp = 1.0 / W[0, 0]
+    for c in range(15):
+        q, r, q1, r1 = c & 3, c >> 2, (c + 1) & 3, (c + 1) >> 2
+        inq = LG == q
+        s01 = W[16 * q + c + 1, r]              # A^(c)[c][c+1]
+        s11 = W[16 * q1 + c + 1, r1]            # A^(c)[c+1][c+1]
+        a_op = W[:, r] * np.where(inq & (LR > c), rp, 0.0)
+        b_op = W[:, r] * inq + (inq & (LR == c))
+        W = mfma(a_op, b_op, W, neg_a=True)
+        t = s01 * rp
+        rp = 1.0 / (s11 - t * s01)
+    row = LG[:, None] + 4 * np.arange(4)[None, :]
+    col = np.broadcast_to(LR[:, None], row.shape)
+    pd = np.array([W[16 * (i & 3) + i, i >> 2] for i in range(16)])   # pivots: lane 16 (i&3) + i, register i >> 2
+    ok = bool(np.all(pd > 0))
+    rs = 1.0 / np.sqrt(np.where(pd > 0, pd, 1.0))
+    fin = np.where(col < row, W * rs[row], np.where(col == row, rs[row], 0.0))
     out = np.zeros(256)
-    for j in range(16):
-        for i in range(16):
-            out[img_rc(i, j)] = reg[i, 16 + j]
-    return out, ok
+    for r in range(4):
+        for l in range(64):
+            out[img_rc(LG[l] + 4 * r, LR[l])] = fin[l, r]
+    return out, fin, ok
 
 
 def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
@@ -124,7 +134,7 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
             acc[(i, j)] = a
     Linv = np.zeros((NT, 256))
     pan = np.zeros((NT, 256))
-    DS = np.zeros(16 * 17)
+    LinvT = np.zeros((NT, 256))
     for k in range(-1, nt):
         if k >= 0:
             lv = Linv[k][IMG_LS]
@@ -163,9 +173,9 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
                 for s in range(4):
                     a_ = mfma(p[:, s], p[:, s], a_, neg_a=True)
                 acc[(k + 1, k + 1)] = a_
-            for r in range(4):
-                DS[(LG + 4 * r) * 17 + LR] = a_[:, r]
-            Linv[k + 1], ok = diag_factor(DS)
+            # hand-over in register layout (the tile is symmetric, so the transposed storage does not matter)
+            Linv[k + 1], fin, ok = diag_factor(a_)
+            LinvT[k + 1][IMG_LS] = fin              # mf_img_store of the C/D registers = operand image of L^-T
             assert ok
         if k >= 0:
             for j in range(k + 1, nt):
@@ -192,7 +202,7 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
             for cc in range(16):
                 a_ = 0.0
                 for mm in range(16):
-                    a_ += Linv[k][img_rc(mm, cc)] * u[mm]
+                    a_ += LinvT[k][img_rc(cc, mm)] * u[mm]      # the L^-T image feeds the alpha MFMAs
                 av[c, 16 * k + cc] = a_
     # separable predictive mean on the sz x sz grid, wave w takes points [32 w, 32 w + 32)
     f = np.zeros((ny, sz * sz))
