@@ -27,33 +27,34 @@ def _stale():
 
 def build(force=False, verbose=False, extra_flags=(), lib=None):
     """Compile every HIP source for gfx950 into gp_compressor_amd/libgpc_hip.so (cross-compiles without a GPU).
-    `lib` + `extra_flags` build a diagnostic variant next to it (e.g. -DMF_STAMPS -> libgpc_hip_stamps.so)."""
-    global LIB
-    if lib is not None:
-        saved = LIB
-        LIB = lib
-        try:
-            return build(force=True, verbose=verbose, extra_flags=extra_flags)
-        finally:
-            LIB = saved
-    if not force and not _stale():
-        return LIB
+    `lib` + `extra_flags` build a diagnostic variant (e.g. -DMF_STAMPS -> libgpc_hip_stamps.so); its objects carry the
+    variant's name, so several variants can be built concurrently."""
+    if lib is None:
+        if not force and not _stale():
+            return LIB
+        target, tag = LIB, ""
+    else:
+        target = lib
+        tag = "." + os.path.splitext(os.path.basename(lib))[0]
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libgpc_hip.so (and there is no CPU fallback)")
     objs = []
     for src in sources():
-        obj = os.path.splitext(src)[0] + (".o" if not extra_flags else ".diag.o")
+        obj = os.path.splitext(src)[0] + tag + ".o"
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-c", src, "-o", obj, *extra_flags]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target + ".tmp", *objs]
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(target + ".tmp", target)
+    if tag:
+        for o in objs:
+            os.remove(o)
+    return target
 
 
 if __name__ == "__main__":

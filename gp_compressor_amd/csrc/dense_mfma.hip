@@ -113,7 +113,7 @@ struct MfmaParams {
 #define L_AV (L_WV + 3 * MF_NPAD)        // 3*256 alpha
 #define L_DS (L_AV + 3 * MF_NPAD)        // 256 + 16 (+ pad to 288) diagonal-tile hand-over (register layout) + rsqrt row
 #define L_FLAG (L_DS + 288)              // 12    ints: [0] not-SPD/timeout, [1] ready, [2] tile_ready, [3] alpha_ready,
-                                         //       [5] sub_cnt, [8..23] pre_cnt[s] (backward-solve hand-over counters)
+                                         //       [8..23] pre_cnt[s] (backward-solve hand-over counters)
 #define L_LINV (L_FLAG + 12)              // 16*256 L_kk^-1, operand layout
 #define L_LINVT (L_LINV + 16 * 256)      // 16*256 L_kk^-T, operand layout (backward solve)
 #define L_PANP (L_LINVT + 16 * 256)      // 2 x 16*256 panel L_ik, operand layout, double-buffered by k & 1 (also the
@@ -230,19 +230,25 @@ __device__ __forceinline__ static bool mf_diag_factor(const double* Wt, double* 
     const int lr = lane & 15, lg = lane >> 4;
     d4 W = *reinterpret_cast<const d4*>(Wt + lane * 4);
     double rp = mf_rcp(mf_readlane(W[0], 0));
+    double rpv = (lg == 0 && lr > 0) ? rp : 0.0;
 #pragma unroll
     for (int c = 0; c < MF_TS - 1; ++c) {
         const int q = c & 3, r = c >> 2, q1 = (c + 1) & 3, r1 = (c + 1) >> 2;
         const bool inq = lg == q;
-        const double s01 = mf_readlane(W[r], 16 * q + c + 1);      // W[c][c+1]
-        const double s11 = mf_readlane(W[r1], 16 * q1 + c + 1);    // W[c+1][c+1]
-        const double rpv = (inq && lr > c) ? rp : 0.0;
         const double ev = (inq && lr == c) ? 1.0 : 0.0;
+        // on the chain: two VALU ops and the MFMA
         const double a_op = W[r] * rpv;
         const double b_op = __builtin_fma(W[r], inq ? 1.0 : 0.0, ev);
-        W = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, W, 0, 0, 1);   // blgp = 1: NEG(A)
+        const d4 Wn = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, W, 0, 0, 1);   // blgp = 1: NEG(A)
+        __builtin_amdgcn_sched_barrier(0);
+        // in the shadow of the MFMA: the reciprocal of the next pivot from the OLD tile (kept alive in its own registers)
+        const double s01 = mf_readlane(W[r], 16 * q + c + 1);      // W[c][c+1]
+        const double s11 = mf_readlane(W[r1], 16 * q1 + c + 1);    // W[c+1][c+1]
         const double t = s01 * rp;
         rp = mf_rcp(__builtin_fma(-t, s01, s11));
+        rpv = (lg == q1 && lr > c + 1) ? rp : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        W = Wn;
     }
     // the pivots are the diagonal of the tile: row lg + 4 r == column lr  <=>  lane 16 (i & 3) + i, register i >> 2
     const int rsel = lr >> 2;
@@ -360,14 +366,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
     const unsigned ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 4), tile_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 8);
     const unsigned alpha_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 12), pre_cnt_addr = lds0 + (unsigned)(L_FLAG * 8 + 32);
-    const unsigned sub_cnt_addr = lds0 + (unsigned)(L_FLAG * 8 + 20);
     int* alpha_ready = flag + 3;
     int* pre_cnt = flag + 8;      // one counter per backward iteration: a single running counter lets fast, tile-less
                                   // workers of iteration s stand in for a slow worker of iteration s-1
-    int* sub_cnt = flag + 5;
     double* Linv = lds + L_LINV;
     double* LinvT = lds + L_LINVT;
     double* panBase = lds + L_PANP;
+    double* Gzero = panBase + 16 * 256;   // image slot 0 of panel buffer 1 (tile row 0 is never part of a panel): G_0
 
     const DenseArgs& A = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -435,7 +440,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             flag[1] = -1;
             flag[2] = -1;
             flag[3] = 0;
-            flag[5] = 0;
         }
         if (tid < 16) flag[8 + tid] = 0;
         __syncthreads();
@@ -579,11 +583,25 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     MF_STAMP_FINE(1);
                     if (!MF_ABL_NOBAR) __syncthreads();               // B2(k)
                     MF_STAMP_FINE(3);
+                    const double* panP = panBase + (k & 1) * (16 * 256);
                     // y_j -= L_jk z_k (rows of block j; the workers do blocks >= j+1)
                     if (!MF_ABL_FWD && lane < 16) {
-                        const double* panP = panBase + (k & 1) * (16 * 256);
                         for (int c = 0; c < ny; ++c)
                             yc[c * MF_NPAD + MF_TS * j + lane] -= mf_row_dot(panP + j * 256, lane, zv + c * MF_NPAD + MF_TS * k);
+                    }
+                    // backward-solve shortcut: G_k = L_kk^-T L_jk^T (j = k+1) folds the sub-diagonal tile into the factor
+                    // wave's own recurrence, alpha_k = L_kk^-T (z_k - w_k) - G_k alpha_(k+1).  (L_jk L_kk^-1) in C/D layout is
+                    // the operand image of its transpose G_k; it lands in the image slot of L_(k-1)(k-1)^-1, dead since B2(k-1).
+                    {
+                        const int ln = mf_opaque(lane);
+                        const d4 Ln = mf_img_load(panP + j * MF_IMG, ln);
+                        const d4 lt = mf_img_load(LinvT + k * MF_IMG, ln);
+                        const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
+                        const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[0], lt[0], z4, 0, 0, 0);
+                        const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[1], lt[1], z4, 0, 0, 0);
+                        const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[2], lt[2], z4, 0, 0, 0);
+                        const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[3], lt[3], z4, 0, 0, 0);
+                        mf_img_store(k > 0 ? Linv + (k - 1) * MF_IMG : Gzero, ln, (D0 + D1) + (D2 + D3));
                     }
                 }
                 if (!MF_ABL_NOWAIT) timed_out |= !mf_wait_ge(tile_ready_addr, j);
@@ -616,24 +634,24 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         MF_STAMP(7);
 
         // ---- backward solve L^T alpha = z, tile columns from the last to the first ----
-        // alpha_k = L_kk^-T (z_k - w_k),  w_k = sum_{i>k} L_ik^T alpha_i.  The column-k tiles sit in the workers'
-        // registers as L_ik[l&15][(l>>4)+4r]: each worker sums its tiles' products in registers, reduces over the 16
-        // lanes of a DPP row (row_ror, no LDS traffic) and adds the 16-vector into w_k with ds_add_f64; the factor
-        // wave then finishes alpha_k with 4 MFMAs on the L_kk^-T image the diagonal factorisation left in LDS.
-        // No workgroup barrier inside the loop.  Iteration s handles tile column k = nt-1-s:
-        //   factor : waits until column k is fully accumulated (pre_cnt >= 7 s, sub_cnt >= s), computes alpha_k, publishes
-        //            alpha_ready = s + 1;
-        //   workers: (a) accumulate column k-1 over the tiles (i, k-1), i >= k+1 -- needs only alpha_i published one
-        //            iteration earlier, so it overlaps the factor wave's alpha_k -- then count up pre_cnt;
-        //            (b) the owner of the sub-diagonal tile (k, k-1) waits for alpha_k, adds its product, counts up sub_cnt.
-        // The chain per iteration is alpha_k -> one tile product -> alpha_(k-1).
+        // alpha_k = L_kk^-T (z_k - w_k) - G_k alpha_(k+1),  w_k = sum_{i>=k+2} L_ik^T alpha_i,  G_k = L_kk^-T L_(k+1)k^T.
+        // The column-k tiles sit in the workers' registers as L_ik[l&15][(l>>4)+4r]: each worker sums its tiles' products
+        // in registers, reduces over the 16 lanes of a DPP row (no LDS traffic) and adds the 16-vector into w_k with
+        // ds_add_f64.  The nearest tile, (k+1, k), never enters w_k: the factor wave folded it into G_k while it had both
+        // factors at hand, so the alpha_(k+1) -> alpha_k dependency is 4 MFMAs inside one wave.  What the workers add
+        // needs alpha_(k+2) and older only, i.e. it has a whole iteration of slack.  No workgroup barrier in the loop.
+        // Iteration s handles tile column k = nt-1-s:
+        //   factor : waits until w_k is complete (pre_cnt[s-1] == 7), computes alpha_k, publishes alpha_ready = s + 1;
+        //   workers: accumulate w_(k-1) over the tiles (i, k-1), i >= k+1 (needs alpha_ready >= s), count up pre_cnt[s].
+        d4 al = d4{0.0, 0.0, 0.0, 0.0};   // factor wave: alpha of the previous iteration, B-operand layout
         for (int s = 0; s < nt; ++s) {
             const int k = nt - 1 - s;
             if (is_factor) {
                 if (s > 0) timed_out |= !mf_wait_ge(pre_cnt_addr + 4u * (unsigned)(s - 1), MF_WORKERS);
-                timed_out |= !mf_wait_ge(sub_cnt_addr, s);
                 MF_STAMP_FINE(10);
-                // alpha_k = L_kk^-T u as one 16x16x16 MFMA product: column n < ny of the B operand carries u of channel n
+                // alpha_k = L_kk^-T u - G_k alpha_(k+1) as 16x16x16 MFMA products: column n < ny of the B operand carries
+                // channel n.  alpha_(k+1) is still in this wave's registers from the previous iteration, in exactly the B
+                // operand layout, so the recurrence never leaves the wave; the workers' sums only enter through u.
                 const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
                 const d4 lt = mf_img_load(LinvT + k * MF_IMG, ln);
                 d4 ub = d4{0.0, 0.0, 0.0, 0.0};
@@ -645,11 +663,18 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     }
                 }
                 const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
-                const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], ub[0], z4, 0, 0, 0);
-                const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], ub[1], z4, 0, 0, 0);
-                const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], ub[2], z4, 0, 0, 0);
-                const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], ub[3], z4, 0, 0, 0);
-                const d4 al = (D0 + D1) + (D2 + D3);   // lanes lr = n < ny: alpha_n[16 k + (l>>4) + 4 r]
+                d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], ub[0], z4, 0, 0, 0);
+                d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], ub[1], z4, 0, 0, 0);
+                d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], ub[2], z4, 0, 0, 0);
+                d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], ub[3], z4, 0, 0, 0);
+                if (s > 0) {
+                    const d4 gk = mf_img_load(k > 0 ? Linv + (k - 1) * MF_IMG : Gzero, ln);
+                    D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[0], al[0], D0, 0, 0, 1);   // blgp = 1: NEG(A)
+                    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[1], al[1], D1, 0, 0, 1);
+                    D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[2], al[2], D2, 0, 0, 1);
+                    D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[3], al[3], D3, 0, 0, 1);
+                }
+                al = (D0 + D1) + (D2 + D3);   // lanes lr = n < ny: alpha_n[16 k + (l>>4) + 4 r]; zero elsewhere
                 if (lr < ny) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) av[lr * MF_NPAD + MF_TS * k + lg + 4 * r] = al[r];
@@ -681,31 +706,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 }
                 if (lane == 0) __hip_atomic_fetch_add(pre_cnt + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 MF_STAMP_FINE(1);
-                if (j >= 0) {
-                    // (b) the sub-diagonal tile (k, j): idx = cs(j) + 1
-                    const int idx1 = __builtin_amdgcn_readfirstlane(mf_cs(j, NT) + 1);
-                    if (wave == idx1 % MF_WORKERS) {
-                        const unsigned smask = __builtin_amdgcn_readfirstlane(1u << (idx1 / MF_WORKERS));
-                        timed_out |= !mf_wait_ge(alpha_ready_addr, s + 1);
-                        MF_STAMP_FINE(10);
-                        for (int c = 0; c < ny; ++c) {
-                            const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                            d4 pa = d4{0.0, 0.0, 0.0, 0.0};
-                            const double ak = av[c * MF_NPAD + MF_TS * k + lr];
-#define MF_BWD1_CASE(t)                                                                                              \
-    if constexpr (t < TPW) {                                                                                         \
-        if (smask & (1u << t)) pa = acc[t] * ak;                                                                     \
-    }
-                            MF_SLOTS(MF_BWD1_CASE)
-                            // (letting the LDS atomic unit do the 16-lane sums -- 4 ds_add_f64 with 16 lanes per address --
-                            // was measured slower than this DPP reduction: +5.6k cycles per patch)
-                            const double tot = mf_row_reduce4(pa, lr);
-                            if ((lr & 3) == 0) atomicAdd(wsum + c * MF_NPAD + MF_TS * j + lg + 4 * (lr >> 2), tot);
-                        }
-                        if (lane == 0) __hip_atomic_fetch_add(sub_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        MF_STAMP_FINE(11);
-                    }
-                }
             }
         }
         __syncthreads();

@@ -135,6 +135,7 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
     Linv = np.zeros((NT, 256))
     pan = np.zeros((NT, 256))
     LinvT = np.zeros((NT, 256))
+    G = np.zeros((NT, 256))
     for k in range(-1, nt):
         if k >= 0:
             lv = Linv[k][IMG_LS]
@@ -156,6 +157,13 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
                 D = D1 + D2
                 acc[(i, k)] = D
                 pan[i][IMG_LS] = D
+            if k + 1 < nt:
+                # G_k: (L_(k+1)k L_kk^-1) in C/D layout = operand image of its transpose L_kk^-T L_(k+1)k^T
+                Ln, ltk = pan[k + 1][IMG_LS], LinvT[k][IMG_LS]
+                Dg = np.zeros((64, 4))
+                for s in range(4):
+                    Dg = mfma(Ln[:, s], ltk[:, s], Dg)
+                G[k][IMG_LS] = Dg
             # y_i -= L_ik z_k by row-threads reading the LDS panel
             for i in range(k + 1, nt):
                 for mrow in range(16):
@@ -188,22 +196,37 @@ def run_model(n, ny, seed, NT=None, sz=20, res=0.15):
                     for s in range(4):
                         t = mfma(a[:, s], b[:, s], t, neg_a=True)
                     acc[(i, j)] = t
-    # backward solve, left-looking over tile columns: alpha_k = L_kk^-T (z_k - sum_{i>k} L_ik^T alpha_i)
+    # backward solve over tile columns: alpha_k = L_kk^-T (z_k - w_k) - G_k alpha_(k+1), w_k = sum_{i>=k+2} L_ik^T alpha_i.
+    # The sub-diagonal tile is folded into G_k = L_kk^-T L_(k+1)k^T (built by the factor wave during the factorisation,
+    # stored as an operand image), so the recurrence stays inside the factor wave: alpha_(k+1) is consumed in the
+    # register layout the previous iteration's MFMAs left it in.
+    al = np.zeros((64, 4))
     for k in range(nt - 1, -1, -1):
+        ub = np.zeros((64, 4))
         for c in range(ny):
             w = np.zeros(16)
             pa = np.zeros((64, 4))
-            for i in range(k + 1, nt):
+            for i in range(k + 2, nt):
                 pa += acc[(i, k)] * av[c, 16 * i + LR][:, None]
             for s in range(4):
                 for g in range(4):
-                    w[g + 4 * s] = pa[LG == g, s].sum()          # mf_row_allsum over the 16 lanes of a DPP row
+                    w[g + 4 * s] = pa[LG == g, s].sum()          # mf_row_reduce4 + ds_add_f64
             u = zv[c, 16 * k:16 * k + 16] - w
-            for cc in range(16):
-                a_ = 0.0
-                for mm in range(16):
-                    a_ += LinvT[k][img_rc(cc, mm)] * u[mm]      # the L^-T image feeds the alpha MFMAs
-                av[c, 16 * k + cc] = a_
+            for q4 in range(4):
+                ub[LR == c, q4] = u[LG[LR == c] + 4 * q4]
+        lt = LinvT[k][IMG_LS]
+        D = np.zeros((64, 4))
+        for s in range(4):
+            D = mfma(lt[:, s], ub[:, s], D)
+        if k + 1 < nt:
+            gk = G[k][IMG_LS]
+            for s in range(4):
+                D = mfma(gk[:, s], al[:, s], D, neg_a=True)
+        al = D
+        assert np.all(al[LR >= ny] == 0.0)
+        for c in range(ny):
+            for r in range(4):
+                av[c, 16 * k + LG[LR == c] + 4 * r] = al[LR == c, r]
     # separable predictive mean on the sz x sz grid, wave w takes points [32 w, 32 w + 32)
     f = np.zeros((ny, sz * sz))
     for c in range(ny):
