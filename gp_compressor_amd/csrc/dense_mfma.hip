@@ -113,7 +113,7 @@ struct MfmaParams {
 #define L_AV (L_WV + 3 * MF_NPAD)        // 3*256 alpha
 #define L_DS (L_AV + 3 * MF_NPAD)        // 256 + 16 (+ pad to 288) diagonal-tile hand-over (register layout) + rsqrt row
 #define L_FLAG (L_DS + 288)              // 12    ints: [0] not-SPD/timeout, [1] ready, [2] tile_ready, [3] alpha_ready,
-                                         //       [8..23] pre_cnt[s] (backward-solve hand-over counters)
+                                         //       [8..23] pre_cnt[k] (backward solve: tiles added into w_k)
 #define L_LINV (L_FLAG + 12)              // 16*256 L_kk^-1, operand layout
 #define L_LINVT (L_LINV + 16 * 256)      // 16*256 L_kk^-T, operand layout (backward solve)
 #define L_PANP (L_LINVT + 16 * 256)      // 2 x 16*256 panel L_ik, operand layout, double-buffered by k & 1 (also the
@@ -367,8 +367,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     const unsigned ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 4), tile_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 8);
     const unsigned alpha_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 12), pre_cnt_addr = lds0 + (unsigned)(L_FLAG * 8 + 32);
     int* alpha_ready = flag + 3;
-    int* pre_cnt = flag + 8;      // one counter per backward iteration: a single running counter lets fast, tile-less
-                                  // workers of iteration s stand in for a slow worker of iteration s-1
+    int* pre_cnt = flag + 8;      // one counter per tile column: tiles (i, k), i >= k+2, already added into w_k
     double* Linv = lds + L_LINV;
     double* LinvT = lds + L_LINVT;
     double* panBase = lds + L_PANP;
@@ -635,25 +634,31 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 
         // ---- backward solve L^T alpha = z, tile columns from the last to the first ----
         // alpha_k = L_kk^-T (z_k - w_k) - G_k alpha_(k+1),  w_k = sum_{i>=k+2} L_ik^T alpha_i,  G_k = L_kk^-T L_(k+1)k^T.
-        // The column-k tiles sit in the workers' registers as L_ik[l&15][(l>>4)+4r]: each worker sums its tiles' products
-        // in registers, reduces over the 16 lanes of a DPP row (no LDS traffic) and adds the 16-vector into w_k with
-        // ds_add_f64.  The nearest tile, (k+1, k), never enters w_k: the factor wave folded it into G_k while it had both
-        // factors at hand, so the alpha_(k+1) -> alpha_k dependency is 4 MFMAs inside one wave.  What the workers add
-        // needs alpha_(k+2) and older only, i.e. it has a whole iteration of slack.  No workgroup barrier in the loop.
-        // Iteration s handles tile column k = nt-1-s:
-        //   factor : waits until w_k is complete (pre_cnt[s-1] == 7), computes alpha_k, publishes alpha_ready = s + 1;
-        //   workers: accumulate w_(k-1) over the tiles (i, k-1), i >= k+1 (needs alpha_ready >= s), count up pre_cnt[s].
-        d4 al = d4{0.0, 0.0, 0.0, 0.0};   // factor wave: alpha of the previous iteration, B-operand layout
-        for (int s = 0; s < nt; ++s) {
-            const int k = nt - 1 - s;
-            if (is_factor) {
-                if (s > 0) timed_out |= !mf_wait_ge(pre_cnt_addr + 4u * (unsigned)(s - 1), MF_WORKERS);
-                MF_STAMP_FINE(10);
-                // alpha_k = L_kk^-T u - G_k alpha_(k+1) as 16x16x16 MFMA products: column n < ny of the B operand carries
-                // channel n.  alpha_(k+1) is still in this wave's registers from the previous iteration, in exactly the B
-                // operand layout, so the recurrence never leaves the wave; the workers' sums only enter through u.
+        // The nearest tile, (k+1, k), never enters w_k: the factor wave folded it into G_k while it had both factors at
+        // hand, so the alpha_(k+1) -> alpha_k dependency is 4 MFMAs inside one wave, and what the workers add needs
+        // alpha_(k+2) and older only.  No workgroup barrier.
+        //   factor : for k = nt-1 .. 0: waits until w_k is complete (pre_cnt[k] == number of live tiles (i, k), i >= k+2),
+        //            computes alpha_k, publishes alpha_ready = nt - k;
+        //   workers: ONE static sweep over their register slots from the last tile to the first.  Column-major dealing
+        //            makes that sweep visit the columns in exactly the order the factor wave needs them and, inside a
+        //            column, the rows from the bottom up, i.e. in the order their alpha_i appear.  Products of one
+        //            column are summed in registers, reduced over the 16 lanes of a DPP row and added to w_k with
+        //            ds_add_f64; pre_cnt[k] counts the tiles added.  (The previous version ran a 16-iteration loop in
+        //            every worker, each iteration re-deriving its slot range and scanning 20 slot guards: 2.2k cycles per
+        //            iteration of pure overhead.)
+        if (is_factor) {
+            d4 al = d4{0.0, 0.0, 0.0, 0.0};   // alpha of the previous iteration, B-operand layout
+            for (int k = nt - 1; k >= 0; --k) {
                 const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
+                // operands that do not depend on the workers: fetched before the wait
                 const d4 lt = mf_img_load(LinvT + k * MF_IMG, ln);
+                d4 gk = d4{0.0, 0.0, 0.0, 0.0};
+                if (k + 1 < nt) gk = mf_img_load(k > 0 ? Linv + (k - 1) * MF_IMG : Gzero, ln);
+                const int expect = nt - k - 2;
+                if (expect > 0) timed_out |= !mf_wait_ge(pre_cnt_addr + 4u * (unsigned)k, expect);
+                MF_STAMP_FINE(10);
+                // 16x16x16 MFMA products: column n < ny of the B operand carries channel n.  alpha_(k+1) is still in this
+                // wave's registers from the previous iteration, in exactly the B operand layout.
                 d4 ub = d4{0.0, 0.0, 0.0, 0.0};
                 if (lr < ny) {
 #pragma unroll
@@ -663,50 +668,62 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     }
                 }
                 const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
-                d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], ub[0], z4, 0, 0, 0);
-                d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], ub[1], z4, 0, 0, 0);
-                d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], ub[2], z4, 0, 0, 0);
-                d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], ub[3], z4, 0, 0, 0);
-                if (s > 0) {
-                    const d4 gk = mf_img_load(k > 0 ? Linv + (k - 1) * MF_IMG : Gzero, ln);
-                    D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[0], al[0], D0, 0, 0, 1);   // blgp = 1: NEG(A)
-                    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[1], al[1], D1, 0, 0, 1);
-                    D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[2], al[2], D2, 0, 0, 1);
-                    D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[3], al[3], D3, 0, 0, 1);
-                }
+                d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[0], al[0], z4, 0, 0, 1);   // blgp = 1: NEG(A)
+                d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[1], al[1], z4, 0, 0, 1);
+                d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[2], al[2], z4, 0, 0, 1);
+                d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[3], al[3], z4, 0, 0, 1);
+                D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], ub[0], D0, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], ub[1], D1, 0, 0, 0);
+                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], ub[2], D2, 0, 0, 0);
+                D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], ub[3], D3, 0, 0, 0);
                 al = (D0 + D1) + (D2 + D3);   // lanes lr = n < ny: alpha_n[16 k + (l>>4) + 4 r]; zero elsewhere
                 if (lr < ny) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) av[lr * MF_NPAD + MF_TS * k + lg + 4 * r] = al[r];
                 }
-                mf_publish(alpha_ready, s + 1);
+                mf_publish(alpha_ready, nt - k);
                 MF_STAMP_FINE(11);
-            } else {
-                const int j = k - 1;                // the column being accumulated
-                if (j >= 0) {
-                    // (a) tiles (i, j), i >= j + 2  <=>  idx in [cs(j) + 2, cs(j+1) - 1]
-                    const int lo_ = mf_cs(j, NT) + 2 - wave, hi_ = mf_cs(j + 1, NT) - 1 - wave;
-                    const int t_lo = (lo_ + 6) / 7, t_hi = (hi_ + 7) / 7 - 1;
-                    const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_lo, t_hi) & live_mask);
-                    if (smask) {
-                        timed_out |= !mf_wait_ge(alpha_ready_addr, s);
-                        for (int c = 0; c < ny; ++c) {      // one channel at a time keeps the register footprint at 4 doubles
-                            const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                            d4 pa = d4{0.0, 0.0, 0.0, 0.0};
-                            const double* avc = av + c * MF_NPAD + lr;
+            }
+        } else {
+            int cur_col = -1, cnt = 0, known = 0;
+            d4 pa[3];
+#define MF_BWD_FLUSH()                                                                                               \
+    do {                                                                                                             \
+        const int lnf = mf_opaque(lane), lrf = lnf & 15, lgf = lnf >> 4;                                             \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) {   /* static index: pa[] must stay in registers */            \
+            if (c < ny) {                                                                                            \
+                const double tot = mf_row_reduce4(pa[c], lrf);   /* lanes lr = 0, 4, 8, 12 hold components 0..3 */   \
+                if ((lrf & 3) == 0) atomicAdd(wsum + c * MF_NPAD + MF_TS * cur_col + lgf + 4 * (lrf >> 2), tot);     \
+            }                                                                                                        \
+        }                                                                                                            \
+        if (lane == 0) __hip_atomic_fetch_add(pre_cnt + cur_col, cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    } while (0)
 #define MF_BWD_CASE(t)                                                                                               \
     if constexpr (t < TPW) {                                                                                         \
-        if (smask & (1u << t)) pa += acc[t] * avc[MF_TS * ti_(t)];                                                   \
+        if ((live_mask & (1u << t)) && ti_(t) >= tj_(t) + 2) {                                                       \
+            if (tj_(t) != cur_col) {                                                                                 \
+                if (cnt) MF_BWD_FLUSH();                                                                             \
+                cur_col = tj_(t);                                                                                    \
+                cnt = 0;                                                                                             \
+                _Pragma("unroll") for (int c = 0; c < 3; ++c) pa[c] = d4{0.0, 0.0, 0.0, 0.0};                        \
+            }                                                                                                        \
+            const int need = nt - ti_(t);   /* alpha_ti is published as alpha_ready = nt - ti */                     \
+            if (known < need) {                                                                                      \
+                timed_out |= !mf_wait_ge(alpha_ready_addr, need);                                                    \
+                known = need;                                                                                        \
+            }                                                                                                        \
+            const double* avq = av + MF_TS * ti_(t) + (mf_opaque(lane) & 15);                                        \
+            _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                            \
+                if (c < ny) pa[c] += acc[t] * avq[c * MF_NPAD];                                                      \
+            ++cnt;                                                                                                   \
+        }                                                                                                            \
     }
-                            MF_SLOTS(MF_BWD_CASE)
-                            const double tot = mf_row_reduce4(pa, lr);       // lanes lr = 0, 4, 8, 12 hold components 0..3
-                            if ((lr & 3) == 0) atomicAdd(wsum + c * MF_NPAD + MF_TS * j + lg + 4 * (lr >> 2), tot);
-                        }
-                    }
-                }
-                if (lane == 0) __hip_atomic_fetch_add(pre_cnt + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                MF_STAMP_FINE(1);
-            }
+            MF_BWD_CASE(19) MF_BWD_CASE(18) MF_BWD_CASE(17) MF_BWD_CASE(16) MF_BWD_CASE(15)
+            MF_BWD_CASE(14) MF_BWD_CASE(13) MF_BWD_CASE(12) MF_BWD_CASE(11) MF_BWD_CASE(10)
+            MF_BWD_CASE(9) MF_BWD_CASE(8) MF_BWD_CASE(7) MF_BWD_CASE(6) MF_BWD_CASE(5)
+            MF_BWD_CASE(4) MF_BWD_CASE(3) MF_BWD_CASE(2) MF_BWD_CASE(1) MF_BWD_CASE(0)
+            if (cnt) MF_BWD_FLUSH();
+            MF_STAMP_FINE(1);
         }
         __syncthreads();
         if (A.alpha_out)

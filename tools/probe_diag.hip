@@ -25,14 +25,25 @@ __global__ __launch_bounds__(512) void probe_kernel(const double* tile, double* 
         if (lane == 0) { cyc[blockIdx.x] = t1 - t0; out[512] = ok ? 1.0 : 0.0; }
         for (int i = lane; i < 512; i += 64) out[i] = sm[288 + i];
     } else if ((mode & 1) && wave == 3) {
-        // same SIMD as wave 7: independent MFMA streams (like a worker's trailing update)
+        // same SIMD as wave 7: MFMA streams like a worker's trailing update.  mode bits 2..3 pick the pattern:
+        // 0 = four independent accumulators, 1 = one dependent chain, 2 = dependent chain + s_sleep 1 after every 4
         d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
         const double x = 1.0 + lane * 1e-3, y = 0.5 - lane * 1e-3;
+        const int pat = (mode >> 2) & 3;
         for (int i = 0; i < reps * 12; ++i) {
-            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a2, 0, 0, 0);
-            a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a3, 0, 0, 0);
+            if (pat == 0) {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a3, 0, 0, 0);
+            } else {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+                if (pat == 2) __builtin_amdgcn_s_sleep(1);
+                if (pat == 3) __builtin_amdgcn_s_sleep(4);
+            }
         }
         out[1024 + lane] = a0[0] + a1[1] + a2[2] + a3[3];
     } else if ((mode & 2) && wave != 7) {
@@ -55,7 +66,7 @@ int main()
     unsigned long long* dC;
     hipMalloc(&dT, 256 * 8); hipMalloc(&dO, 4096 * 8); hipMalloc(&dC, 8 * 64);
     hipMemcpy(dT, W.data(), 256 * 8, hipMemcpyHostToDevice);
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode : {0, 1, 5, 9, 13, 3}) {
         for (int rep = 0; rep < 2; ++rep) {
             hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(512), 0, 0, dT, dO, dC, reps, mode);
             hipDeviceSynchronize();
@@ -63,9 +74,9 @@ int main()
         unsigned long long c; double ok;
         hipMemcpy(&c, dC, 8, hipMemcpyDeviceToHost);
         hipMemcpy(&ok, dO + 512, 8, hipMemcpyDeviceToHost);
-        printf("mode %d (%s%s): %.1f s_memtime ticks (100 MHz) per diag factor = ~%.0f cycles at 2.4 GHz, ok=%g\n", mode,
-               (mode & 1) ? "MFMA stream on the same SIMD" : "alone", (mode & 2) ? " + VALU load on all other waves" : "",
-               (double)c / reps, (double)c / reps * 24.0, ok);
+        static const char* pats[4] = {"4 independent accumulators", "one dependent chain", "dependent chain + s_sleep 1 per 4", "dependent chain + s_sleep 4 per 4"};
+        printf("mode %2d (%s%s%s): %.0f s_memtime ticks per diag factor, ok=%g\n", mode, (mode & 1) ? "MFMA stream on the same SIMD: " : "alone",
+               (mode & 1) ? pats[(mode >> 2) & 3] : "", (mode & 2) ? " + FP64 VALU load on all other waves" : "", (double)c / reps, ok);
     }
     // check the result: Linv * A * Linv^T = I
     std::vector<double> o(512);
