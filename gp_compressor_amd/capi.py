@@ -64,6 +64,7 @@ PROTOTYPES = {
     "gpc_sparse_ld": (C.c_int, [_vp]),
     "gpc_partition_patches": (C.c_int, [_i, _vp, _i, _i, _vp]),
     "gpc_test_exp_host": (None, [_vp, _vp, _i]),
+    "gpc_test_exp_small_host": (None, [_vp, _vp, _i]),
 }
 
 _lib = None
@@ -286,8 +287,9 @@ def partition_patches(off, world, sparse_capacity=0):
     return out[:world * S].reshape(world, S)
 
 
-def exp_host(x):
+def exp_host(x, small=False):
+    """the kernels' exp() evaluated on the host: table-driven (any x) or the small-argument polynomial (-2^-5 <= x <= 0)"""
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = np.zeros_like(x)
-    load().gpc_test_exp_host(_ptr(x), _ptr(out), x.size)
+    (load().gpc_test_exp_small_host if small else load().gpc_test_exp_host)(_ptr(x), _ptr(out), x.size)
     return out

@@ -422,10 +422,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             continue;
         }
         const int nt = __builtin_amdgcn_readfirstlane((n + MF_TS - 1) / MF_TS);   // live tile rows
+        // extent of the patch around its first point (max-norm): bounds every kernel argument of this patch, see below
+        const double xo0 = A.x0[o], xo1 = A.x1[o];
+        double dev = 0.0;
         for (int i = tid; i < NT * MF_TS; i += MF_THREADS) {
             const bool live = i < n;
-            px0[i] = live ? A.x0[o + i] : 0.0;
-            px1[i] = live ? A.x1[o + i] : 0.0;
+            const double q0 = live ? A.x0[o + i] : xo0, q1 = live ? A.x1[o + i] : xo1;
+            dev = __builtin_fmax(dev, __builtin_fmax(__builtin_fabs(q0 - xo0), __builtin_fabs(q1 - xo1)));
+            px0[i] = live ? q0 : 0.0;
+            px1[i] = live ? q1 : 0.0;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 if (c < ny) {
@@ -441,7 +446,28 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             flag[3] = 0;
         }
         if (tid < 16) flag[8 + tid] = 0;
+        dev = __builtin_fmax(dev, mf_dpp<0x121>(dev));     // max over the 16 lanes of a DPP row
+        dev = __builtin_fmax(dev, mf_dpp<0x122>(dev));
+        dev = __builtin_fmax(dev, mf_dpp<0x124>(dev));
+        dev = __builtin_fmax(dev, mf_dpp<0x128>(dev));
+        if ((lane & 15) == 0) DS[tid >> 4] = dev;          // 32 row maxima (DS is free until the first tile hand-over)
         __syncthreads();
+        // Small-argument regime: every Gram argument satisfies |c| d^2 <= |c| 2 (2 r)^2 and every argument of the separable
+        // grid factors |c| (res/2 + |x_first| + r)^2, r = patch extent.  When both are <= 2^-5 the exponential is the plain
+        // degree-7 polynomial (gpc_exp_small); otherwise the table-driven gpc_exp_neg.  Wave-uniform.
+        bool small_gram, small_grid;
+        {
+            double r = DS[lane & 31];
+            r = __builtin_fmax(r, mf_dpp<0x121>(r));
+            r = __builtin_fmax(r, mf_dpp<0x122>(r));
+            r = __builtin_fmax(r, mf_dpp<0x124>(r));
+            r = __builtin_fmax(r, mf_dpp<0x128>(r));
+            r = __builtin_fmax(mf_readlane(r, 0), mf_readlane(r, 16));
+            const double b = 0.5 * A.grid_res + __builtin_fmax(__builtin_fabs(xo0), __builtin_fabs(xo1)) + r;
+            small_gram = -cexp * (8.0 * r * r) <= GPC_EXP_SMALL_MAX;      // false for NaN / inf extents
+            small_grid = -cexp * (b * b) <= GPC_EXP_SMALL_MAX;
+        }
+        __syncthreads();                                   // DS is read; the hand-over may overwrite it
 
         unsigned live_mask = 0;   // slots whose tile row is live (ti < nt)
 #pragma unroll
@@ -452,27 +478,58 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         if (!is_factor) {
             // ================================ WORKER ROLE ================================
             // ---- Gram tiles, transposed: acc[t][r] = K[16 i + (l&15)][16 j + (l>>4) + 4 r]; padding = identity ----
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-                if (live_mask & (1u << t)) {
-                    const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;
-                    const int pi = MF_TS * ti_(t) + lr;
-                    const double xi0 = px0[pi], xi1 = px1[pi];
-                    const bool edge = MF_TS * ti_(t) + MF_TS > n;   // tile touches the identity padding (wave-uniform)
-                    const bool diag_tile = ti_(t) == tj_(t);        // only these carry the noise diagonal (wave-uniform)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int pj = MF_TS * tj_(t) + lg + 4 * r;
-                        double v = gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T);
-                        if (diag_tile && pi == pj) {
-                            v += noise;                              // covariance_matrix(..., training)  :59-61
-                            if (A.prm.ref_double_noise) v += noise;  // C.diagonal() += sigman_sq        :21
-                        }
-                        if (edge && (pi >= n || pj >= n)) v = (pi == pj) ? 1.0 : 0.0;
-                        acc[t][r] = v;
-                    }
-                }
+            // Off-diagonal interior tiles (120 of 136 at n = 256) take the bare kernel evaluation; the noise diagonal and
+            // the identity padding live in a separate branch.  (Written as one body with wave-uniform conditions, hipcc
+            // if-converts them into ~18 selects and compares per ELEMENT -- more than the exponential itself.  The opaque
+            // lane id inside the special branch is what keeps it a branch.)
+#define MF_GRAM(RBF)                                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                                                \
+        acc[t] = d4{0.0, 0.0, 0.0, 0.0};                                                                             \
+        if (live_mask & (1u << t)) {                                                                                 \
+            const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;                                              \
+            const int pi = MF_TS * ti_(t) + lr;                                                                      \
+            const double xi0 = px0[pi], xi1 = px1[pi];                                                               \
+            const bool edge = MF_TS * ti_(t) + MF_TS > n;   /* tile touches the identity padding (wave-uniform) */    \
+            const bool diag_tile = ti_(t) == tj_(t);        /* only these carry the noise diagonal (wave-uniform) */  \
+            if (__builtin_expect(edge || diag_tile, 0)) {                                                            \
+                const int lg2 = mf_opaque(ln) >> 4;                                                                  \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                      \
+                    const int pj = MF_TS * tj_(t) + lg2 + 4 * r;                                                     \
+                    double v = RBF;                                                                                  \
+                    if (diag_tile && pi == pj) {                                                                     \
+                        v += noise;                              /* covariance_matrix(..., training)  :59-61 */      \
+                        if (A.prm.ref_double_noise) v += noise;  /* C.diagonal() += sigman_sq        :21 */          \
+                    }                                                                                                \
+                    if (edge && (pi >= n || pj >= n)) v = (pi == pj) ? 1.0 : 0.0;                                    \
+                    acc[t][r] = v;                                                                                   \
+                }                                                                                                    \
+            } else {                                                                                                 \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                      \
+                    const int pj = MF_TS * tj_(t) + lg + 4 * r;                                                      \
+                    acc[t][r] = RBF;                                                                                 \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+            if (small_gram) {
+                // sigma_f^2 folded into the polynomial coefficients: sf exp(x) in 7 FMAs
+                const double k7 = sf * (1.0 / 5040.0), k6 = sf * (1.0 / 720.0), k5 = sf * (1.0 / 120.0), k4 = sf * (1.0 / 24.0),
+                             k3 = sf * (1.0 / 6.0), k2 = sf * 0.5;
+#define MF_RBF_SMALL(xa, ya, xb, yb)                                                                                 \
+    ([&]() __attribute__((always_inline)) {                                                                          \
+        const double d0_ = (xa) - (xb), d1_ = (ya) - (yb);                                                           \
+        const double x_ = cexp * __builtin_fma(d0_, d0_, d1_ * d1_);                                                 \
+        double p_ = __builtin_fma(x_, k7, k6);                                                                       \
+        p_ = __builtin_fma(x_, p_, k5);                                                                              \
+        p_ = __builtin_fma(x_, p_, k4);                                                                              \
+        p_ = __builtin_fma(x_, p_, k3);                                                                              \
+        p_ = __builtin_fma(x_, p_, k2);                                                                              \
+        p_ = __builtin_fma(x_, p_, sf);                                                                              \
+        return __builtin_fma(x_, p_, sf);                                                                            \
+    }())
+                MF_GRAM(MF_RBF_SMALL(xi0, xi1, px0[pj], px1[pj]))
+            } else {
+                MF_GRAM(gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T))
             }
             // tile (0, 0) goes to the factor wave at once
             if (wave == 0) {
@@ -654,28 +711,37 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 const d4 lt = mf_img_load(LinvT + k * MF_IMG, ln);
                 d4 gk = d4{0.0, 0.0, 0.0, 0.0};
                 if (k + 1 < nt) gk = mf_img_load(k > 0 ? Linv + (k - 1) * MF_IMG : Gzero, ln);
-                const int expect = nt - k - 2;
-                if (expect > 0) timed_out |= !mf_wait_ge(pre_cnt_addr + 4u * (unsigned)k, expect);
-                MF_STAMP_FINE(10);
-                // 16x16x16 MFMA products: column n < ny of the B operand carries channel n.  alpha_(k+1) is still in this
-                // wave's registers from the previous iteration, in exactly the B operand layout.
-                d4 ub = d4{0.0, 0.0, 0.0, 0.0};
+                // L_kk^-T z_k - G_k alpha_(k+1) does not depend on the workers: issued before the wait.  16x16x16 MFMA
+                // products, column n < ny of the B operand carries channel n; alpha_(k+1) is still in this wave's
+                // registers from the previous iteration, in exactly the B operand layout.
+                d4 zb = d4{0.0, 0.0, 0.0, 0.0};
                 if (lr < ny) {
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const int q = lr * MF_NPAD + MF_TS * k + lg + 4 * q4;
-                        ub[q4] = zv[q] - wsum[q];
-                    }
+                    for (int q4 = 0; q4 < 4; ++q4) zb[q4] = zv[lr * MF_NPAD + MF_TS * k + lg + 4 * q4];
                 }
                 const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
                 d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[0], al[0], z4, 0, 0, 1);   // blgp = 1: NEG(A)
                 d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[1], al[1], z4, 0, 0, 1);
                 d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[2], al[2], z4, 0, 0, 1);
                 d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[3], al[3], z4, 0, 0, 1);
-                D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], ub[0], D0, 0, 0, 0);
-                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], ub[1], D1, 0, 0, 0);
-                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], ub[2], D2, 0, 0, 0);
-                D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], ub[3], D3, 0, 0, 0);
+                D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], zb[0], D0, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], zb[1], D1, 0, 0, 0);
+                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], zb[2], D2, 0, 0, 0);
+                D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], zb[3], D3, 0, 0, 0);
+                const int expect = nt - k - 2;
+                if (expect > 0) {
+                    timed_out |= !mf_wait_ge(pre_cnt_addr + 4u * (unsigned)k, expect);
+                    MF_STAMP_FINE(10);
+                    d4 wb = d4{0.0, 0.0, 0.0, 0.0};
+                    if (lr < ny) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) wb[q4] = wsum[lr * MF_NPAD + MF_TS * k + lg + 4 * q4];
+                    }
+                    D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], wb[0], D0, 0, 0, 1);
+                    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], wb[1], D1, 0, 0, 1);
+                    D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], wb[2], D2, 0, 0, 1);
+                    D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], wb[3], D3, 0, 0, 1);
+                }
                 al = (D0 + D1) + (D2 + D3);   // lanes lr = n < ny: alpha_n[16 k + (l>>4) + 4 r]; zero elsewhere
                 if (lr < ny) {
 #pragma unroll
@@ -753,8 +819,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         const int i = ibase + 4 * s + lg;
                         const bool on = (pq < sz) && (i < n);
                         const double dy = gq - px1[i], dx = gq - px0[i];
-                        ea[h][s] = on ? gpc_exp_neg(cexp * (dy * dy), T) : 0.0;   // Ey[py = pq][i]
-                        eb[h][s] = on ? gpc_exp_neg(cexp * (dx * dx), T) : 0.0;   // Ex[px = pq][i]
+                        if (small_grid) {
+                            ea[h][s] = on ? gpc_exp_small(cexp * (dy * dy)) : 0.0;    // Ey[py = pq][i]
+                            eb[h][s] = on ? gpc_exp_small(cexp * (dx * dx)) : 0.0;    // Ex[px = pq][i]
+                        } else {
+                            ea[h][s] = on ? gpc_exp_neg(cexp * (dy * dy), T) : 0.0;
+                            eb[h][s] = on ? gpc_exp_neg(cexp * (dx * dx), T) : 0.0;
+                        }
                     }
                 }
             }

@@ -314,5 +314,9 @@ void gpc_test_exp_host(const double* x, double* out, int n)
 {
     for (int i = 0; i < n; ++i) out[i] = gpc_exp_tbl(x[i], h_gpc_exp_table);
 }
+void gpc_test_exp_small_host(const double* x, double* out, int n)
+{
+    for (int i = 0; i < n; ++i) out[i] = gpc_exp_small(x[i]);
+}
 
 }  // extern "C"

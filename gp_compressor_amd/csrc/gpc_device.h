@@ -72,6 +72,23 @@ __device__ static inline double gpc_exp_neg(double x, const double* __restrict__
     return __builtin_amdgcn_ldexp(__builtin_fma(t, p, t), n >> 6);
 }
 
+// exp(x) for -2^-5 <= x <= 0: the degree-7 Taylor polynomial, no table and no range reduction (truncation
+// x^8/8! <= 2.3e-17 relative, i.e. below half an ulp; measured <= 1 ulp vs libm, tests/test_capi_cpu.py).  This is the
+// regime of a GP patch model whose length scale exceeds the patch (c d^2 = -d^2 / (2 l^2) is tiny): a third of the
+// instructions of the table-driven path and no LDS access.  Callers prove the argument range from a bound on the patch
+// extent (dense_mfma.hip) and fall back to gpc_exp_neg otherwise.
+#define GPC_EXP_SMALL_MAX 0.03125
+__host__ __device__ static inline double gpc_exp_small(double x)
+{
+    double p = __builtin_fma(x, 1.0 / 5040.0, 1.0 / 720.0);
+    p = __builtin_fma(x, p, 1.0 / 120.0);
+    p = __builtin_fma(x, p, 1.0 / 24.0);
+    p = __builtin_fma(x, p, 1.0 / 6.0);
+    p = __builtin_fma(x, p, 0.5);
+    p = __builtin_fma(x, p, 1.0);
+    return __builtin_fma(x, p, 1.0);
+}
+
 __device__ static inline void gpc_exp_table_init(double* T_lds)
 {
     for (int i = threadIdx.x; i < GPC_EXP_TABLE_SIZE; i += blockDim.x) T_lds[i] = c_gpc_exp_table[i];
@@ -92,6 +109,13 @@ __device__ static inline double gpc_rbf_neg(double sf, double c, double xi0, dou
     double d0 = xi0 - xj0, d1 = xi1 - xj1;
     double sq = d0 * d0 + d1 * d1;
     return sf * gpc_exp_neg(c * sq, T);
+}
+
+__device__ static inline double gpc_rbf_small(double sf, double c, double xi0, double xi1, double xj0, double xj1)
+{
+    double d0 = xi0 - xj0, d1 = xi1 - xj1;
+    double sq = d0 * d0 + d1 * d1;
+    return sf * gpc_exp_small(c * sq);
 }
 
 // ---------------------------------------------------------------------------------------------------------

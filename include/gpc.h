@@ -155,6 +155,9 @@ int gpc_partition_patches(int P, const int32_t* off, int world, int sparse_capac
 /* Host-side evaluation of the table-driven exp() the kernels use for the RBF kernel (same source, csrc/gpc_device.h),
  * so that its error against libm -- which the reference calls, src/rbf_kernel.cpp:17 -- can be bounded without a GPU. */
 void gpc_test_exp_host(const double* x, double* out, int n);
+/* Same for the small-argument polynomial (-2^-5 <= x <= 0) the register-tile kernel switches to when the patch extent
+ * proves the range. */
+void gpc_test_exp_small_host(const double* x, double* out, int n);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,18 @@ def test_exp_table_accuracy(capi):
     assert np.isnan(capi.exp_host(np.array([np.nan]))[0])
 
 
+def test_exp_small_argument_polynomial(capi):
+    """The degree-7 polynomial the register-tile kernel uses when |c| d^2 <= 2^-5 stays within 1 ulp of libm."""
+    rng = np.random.default_rng(1)
+    x = -np.concatenate([rng.uniform(0, 2.0 ** -5, 200000), 10.0 ** rng.uniform(-18, -1.6, 50000), [0.0, 2.0 ** -5]])
+    x = x[x >= -2.0 ** -5]
+    got = capi.exp_host(x, small=True)
+    want = np.exp(x)
+    ulp = np.abs(got - want) / np.spacing(want)
+    assert ulp.max() <= 1.0, ulp.max()
+    assert got[x == 0.0][0] == 1.0
+
+
 def test_partition_patches(capi):
     rng = np.random.default_rng(3)
     counts = rng.integers(1, 513, size=1000)

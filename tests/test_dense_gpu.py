@@ -102,6 +102,29 @@ def test_dense_other_hyperparameters(gp, oracle):
     assert np.max(np.abs(v - vo)) <= 1e-9
 
 
+@pytest.mark.parametrize("l_sq,shift,tol", [(0.05 ** 2, 0.0, 1e-8), (0.5 ** 2, 0.0, FTOL), (9.0, 0.4, FTOL), (9.0, 30.0, FTOL)])
+def test_dense_mfma_exp_regimes(gp, oracle, l_sq, shift, tol):
+    """The register-tile kernel picks its exponential per patch: the degree-7 polynomial when the patch extent proves
+    |c| d^2 <= 2^-5 for every Gram (resp. grid) argument, the table-driven exp otherwise.  Short length scale -> table
+    everywhere; l = 0.5 -> polynomial Gram, table grid (|c| (res/2 + |x| + r)^2 > 2^-5); patches far from the origin
+    of their frame -> polynomial Gram, table grid; defaults are polynomial everywhere (other tests)."""
+    capi, ctx = gp
+    res, sz = 0.15, 20
+    off, x0, x1, y = synth.make_patches(5, 200, seed=33, ragged=True)
+    x0, x1 = x0 + shift, x1 - shift
+    kw = dict(sigmaf_sq=0.5, l_sq=l_sq, noise=1e-3)
+    p = capi.default_params_dense(**kw)
+    po = oracle.dense_params(kw["sigmaf_sq"], kw["l_sq"], kw["noise"])
+    xs0, xs1 = oracle.grid(res, sz)
+    f1, st1 = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz)
+    assert ctx.last_dense_kernel().startswith("dense_mfma")
+    f2, _, st2 = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1)
+    fo, _, so = oracle.dense_fit_predict_batch(po, off, x0, x1, y, xs0, xs1)
+    assert np.all(st1 == 0) and np.all(st2 == 0) and np.all(so == 0)
+    _close(f1, fo, tol)
+    _close(f2, fo, tol)
+
+
 def test_dense_edge_cases(gp, oracle):
     capi, ctx = gp
     xs0, xs1 = synth.grid(0.15, 5)
