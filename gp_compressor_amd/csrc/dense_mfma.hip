@@ -75,32 +75,19 @@ struct MfmaParams {
 #define MF_STAMP_FLUSH() do { } while (0)
 #endif
 
-// Timing-only ablation switches (cdna_hip_programming.md section 7, "The diagnostic loop", step 2): each removes one piece of
-// the factorisation loop so that its share of the critical path can be read off the coarse stamps.  Builds with any of
-// them produce WRONG results and are never shipped (tools/ablate_mfma.py).
-#ifndef MF_ABL_DIAG
-#define MF_ABL_DIAG 0
-#endif
-#ifndef MF_ABL_UPD
-#define MF_ABL_UPD 0
-#endif
-#ifndef MF_ABL_TRSM
-#define MF_ABL_TRSM 0
-#endif
-#ifndef MF_ABL_YROWS
-#define MF_ABL_YROWS 0
-#endif
-#ifndef MF_ABL_FWD
-#define MF_ABL_FWD 0
-#endif
-#ifndef MF_ABL_PASS1
-#define MF_ABL_PASS1 0
-#endif
-#ifndef MF_ABL_NOWAIT
-#define MF_ABL_NOWAIT 0
-#endif
-#ifndef MF_ABL_NOBAR
-#define MF_ABL_NOBAR 0
+// Diagnostic timeline (-DMF_TRACE, tools/stamp_mfma.py --trace): lane 0 of every wave drops s_memtime at fixed points of
+// every factorisation step into global memory; the host prints the mean timeline of factor wave and workers.
+#define MF_NTR 160
+#ifdef MF_TRACE
+#define MF_TRACE_AT(slot)                                                                                            \
+    do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        const unsigned long long t_tr_ = __builtin_amdgcn_s_memtime();                                               \
+        if (lane == 0) g.stamps[((size_t)blockIdx.x * MF_WAVES + wave) * MF_NTR + (slot)] = t_tr_;                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#else
+#define MF_TRACE_AT(slot) do { } while (0)
 #endif
 
 // ---- LDS carve (doubles) ----------------------------------------------------------------------------------
@@ -112,8 +99,8 @@ struct MfmaParams {
 #define L_WV (L_ZV + 3 * MF_NPAD)        // 3*256 backward-solve accumulators w_k[c][16 k + .] (ds_add_f64 targets)
 #define L_AV (L_WV + 3 * MF_NPAD)        // 3*256 alpha
 #define L_DS (L_AV + 3 * MF_NPAD)        // 256 + 16 (+ pad to 288) diagonal-tile hand-over (register layout) + rsqrt row
-#define L_FLAG (L_DS + 288)              // 12    ints: [0] not-SPD/timeout, [1] ready, [2] tile_ready, [3] alpha_ready,
-                                         //       [8..23] pre_cnt[k] (backward solve: tiles added into w_k)
+#define L_FLAG (L_DS + 288)              // 12    ints: [0] not-SPD/timeout, [1] ready, [2] tile_ready, [3] alpha_ready, [4] sub_ready,
+                                         //       [5] pan_cnt, [6] t00_ready, [7] z_ready, [8..23] pre_cnt[k] (backward solve)
 #define L_LINV (L_FLAG + 12)              // 16*256 L_kk^-1, operand layout
 #define L_LINVT (L_LINV + 16 * 256)      // 16*256 L_kk^-T, operand layout (backward solve)
 #define L_PANP (L_LINVT + 16 * 256)      // 2 x 16*256 panel L_ik, operand layout, double-buffered by k & 1 (also the
@@ -211,7 +198,7 @@ __device__ static __forceinline__ void mf_img_store(double* img, int l, d4 v)
     *reinterpret_cast<d2*>(img + 128 + l * 2) = d2{v[2], v[3]};
 }
 
-// Inverse Cholesky factor of a 16 x 16 SPD tile, on the MFMA pipe.  `Wt` holds the tile in C/D register layout
+// Inverse Cholesky factor of a 16 x 16 SPD tile, on the MFMA pipe.  `W` holds the tile in C/D register layout
 // (lane l, register r: A[(l>>4) + 4 r][l & 15]; the diagonal tile is symmetric, so the workers' transposed storage is
 // the same thing).  Square-root-free Gauss-Jordan elimination IN PLACE: pivot c is ONE rank-1 v_mfma_f64_16x16x4
 //     W[i][j] -= m_i * w_j,   m_i = W[i][c] / p_c (i > c, else 0),   w_j = W[c][j] + [j == c]
@@ -223,12 +210,10 @@ __device__ static __forceinline__ void mf_img_store(double* img, int l, d4 v)
 // one MFMA plus two VALU ops; the square roots are taken once, vectorised, at the end.  (The previous version ran the
 // elimination on the VALU with v_readlane multipliers: ~650 dependent-issue instructions, 4.6k cycles per tile, on
 // the critical path of every step.)  Writes L^-1 and L^-T as operand images; false when a pivot is <= pivot_tol.
-__device__ __forceinline__ static bool mf_diag_factor(const double* Wt, double* rsbuf, double* Linv_out, double* LinvT_out,
-                                                      double pivot_tol)
+__device__ __forceinline__ static bool mf_diag_factor(d4 W, double* rsbuf, double* Linv_out, double* LinvT_out, double pivot_tol)
 {
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lg = lane >> 4;
-    d4 W = *reinterpret_cast<const d4*>(Wt + lane * 4);
     double rp = mf_rcp(mf_readlane(W[0], 0));
     double rpv = (lg == 0 && lr > 0) ? rp : 0.0;
 #pragma unroll
@@ -359,19 +344,28 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     double* wsum = lds + L_WV;
     double* av = lds + L_AV;
     double* DS = lds + L_DS;
-    int* flag = reinterpret_cast<int*>(lds + L_FLAG);   // [0] not-SPD
-    int* ready = flag + 1;        // highest tile column whose L_kk^-1, z_k (and y_k) are published by the factor wave
-    int* tile_ready = flag + 2;   // highest diagonal tile handed over to the factor wave
-    // 32-bit LDS byte addresses of the two words for the ds_read polling loops (dynamic LDS starts after the static part)
-    const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
-    const unsigned ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 4), tile_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 8);
-    const unsigned alpha_ready_addr = lds0 + (unsigned)(L_FLAG * 8 + 12), pre_cnt_addr = lds0 + (unsigned)(L_FLAG * 8 + 32);
+    int* flag = reinterpret_cast<int*>(lds + L_FLAG);   // [0] not-SPD / protocol timeout
+    int* ready = flag + 1;        // highest tile column whose L_kk^-1 and z_k are published by the factor wave
+    int* tile_ready = flag + 2;   // highest diagonal tile (j, j), j >= 1, handed to the factor wave (updated through panel j-2)
     int* alpha_ready = flag + 3;
+    int* sub_ready = flag + 4;    // highest sub-diagonal tile (j, j-1) handed to the factor wave (updated through panel j-2)
+    int* pan_cnt = flag + 5;      // panel-complete counter: 8 increments per tile column (7 workers + the factor wave)
+    int* t00_ready = flag + 6;    // tile (0, 0) handed over
+    int* z_ready = flag + 7;      // highest tile column whose z_k = L_kk^-1 y_k is published (initially -1)
     int* pre_cnt = flag + 8;      // one counter per tile column: tiles (i, k), i >= k+2, already added into w_k
+    // 32-bit LDS byte addresses of the words for the ds_read polling loops (dynamic LDS starts after the static part)
+    const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
+    const unsigned flag_addr = lds0 + (unsigned)(L_FLAG * 8);
+    const unsigned ready_addr = flag_addr + 4, tile_ready_addr = flag_addr + 8, alpha_ready_addr = flag_addr + 12;
+    const unsigned sub_ready_addr = flag_addr + 16, pan_cnt_addr = flag_addr + 20, t00_ready_addr = flag_addr + 24;
+    const unsigned z_ready_addr = flag_addr + 28;
+    const unsigned pre_cnt_addr = flag_addr + 32;
     double* Linv = lds + L_LINV;
     double* LinvT = lds + L_LINVT;
     double* panBase = lds + L_PANP;
-    double* Gzero = panBase + 16 * 256;   // image slot 0 of panel buffer 1 (tile row 0 is never part of a panel): G_0
+    // Image slot 0 of either panel buffer is never part of a panel (tile row 0 has no sub-diagonal tiles):
+    double* SubX = panBase;               // hand-over of the sub-diagonal tile (j, j-1) to the factor wave (register layout)
+    double* Gzero = panBase + 16 * 256;   // hand-over of tile (0, 0), afterwards G_0 (backward solve)
 
     const DenseArgs& A = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -442,8 +436,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         if (tid == 0) {
             flag[0] = 0;
             flag[1] = -1;
-            flag[2] = -1;
+            flag[2] = 0;
             flag[3] = 0;
+            flag[4] = 0;
+            flag[5] = 0;
+            flag[6] = 0;
+            flag[7] = -1;
         }
         if (tid < 16) flag[8 + tid] = 0;
         dev = __builtin_fmax(dev, mf_dpp<0x121>(dev));     // max over the 16 lanes of a DPP row
@@ -531,24 +529,47 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             } else {
                 MF_GRAM(gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T))
             }
-            // tile (0, 0) goes to the factor wave at once
+            // ---- first hand-overs: tile (0,0), and tiles (1,0) / (1,1) as they are (no panel precedes them) ----
+#define MF_HAND_CASE(t)                                                                                              \
+    if constexpr (t < TPW) {                                                                                         \
+        if (smask & (1u << t)) *reinterpret_cast<d4*>(hand_to + mf_opaque(lane) * 4) = acc[t];                       \
+    }
             if (wave == 0) {
-                const int ln = mf_opaque(lane);
-                *reinterpret_cast<d4*>(DS + ln * 4) = acc[0];   // register layout, as the factor wave consumes it
-                mf_publish(tile_ready, 0);
+                *reinterpret_cast<d4*>(Gzero + mf_opaque(lane) * 4) = acc[0];   // register layout, as the factor wave consumes it
+                mf_publish(t00_ready, 1);
+            }
+            if (nt > 1) {
+                if (wave == 1 % MF_WORKERS) {                       // idx 1 = tile (1, 0)
+                    double* hand_to = SubX;
+                    const unsigned smask = 1u << (1 / MF_WORKERS);
+                    MF_SLOTS(MF_HAND_CASE)
+                    mf_publish(sub_ready, 1);
+                }
+                if (wave == NT % MF_WORKERS) {                      // idx cs(1) = NT = tile (1, 1)
+                    double* hand_to = DS;
+                    const unsigned smask = __builtin_amdgcn_readfirstlane(1u << (NT / MF_WORKERS));
+                    MF_SLOTS(MF_HAND_CASE)
+                    mf_publish(tile_ready, 1);
+                }
             }
             MF_STAMP(0);
 
-            // ---- right-looking tiled Cholesky ----
-            // step k:  wait for L_kk^-1 | TRSM of tile column k -> panel buffer k&1 | B2 | update with panel k: the next
-            // diagonal tile first (handed to the factor wave at once), then the forward-solve rows, then the rest.
-            for (int k = 0; k < nt; ++k) {
+            // ---- right-looking tiled Cholesky, worker side ----
+            // The factor wave owns the whole critical chain of a tile column: diag factor (k,k) -> TRSM of the sub-diagonal
+            // tile (k+1,k) -> update and factor of (k+1,k+1).  It gets both tiles one step AHEAD (updated through panel k-1)
+            // from their owners, who update and hand them over first thing after panel k-1 is complete.  A worker's step k:
+            //   wait for L_kk^-1 | TRSM of its tiles (i,k), i >= k+2 -> panel buffer k&1 | count up pan_cnt, wait for
+            //   8 (k+1) | owner of (k+1,k): take the final tile back from the panel, build G_k | owners of (k+2,k+1) and
+            //   (k+2,k+2): update with panel k, hand over | forward-solve rows | the rest of the trailing update.
+            // No workgroup barrier: the factor wave only counts up pan_cnt, it never waits for the workers' TRSMs.
+            for (int k = 0; k + 1 < nt; ++k) {
                 double* panP = panBase + (k & 1) * (16 * 256);
-                if (!MF_ABL_NOWAIT) timed_out |= !mf_wait_ge(ready_addr, k);
+                timed_out |= !mf_wait_ge(ready_addr, k);
                 MF_STAMP_FINE(1);
+                MF_TRACE_AT(8 * k + 0);
                 if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                 {
-                    const int lo_ = mf_cs(k, NT) + 1 - wave, hi_ = mf_cs(k + 1, NT) - 1 - wave;
+                    const int lo_ = mf_cs(k, NT) + 2 - wave, hi_ = mf_cs(k + 1, NT) - 1 - wave;
                     const int t_lo = __builtin_amdgcn_readfirstlane((lo_ + 6) / 7);
                     const int t_hi = __builtin_amdgcn_readfirstlane((hi_ + 7) / 7 - 1);
                     const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_lo, t_hi) & live_mask);
@@ -557,13 +578,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 #define MF_TRSM_CASE(t)                                                                                              \
     if constexpr (t < TPW) {                                                                                         \
         if (smask & (1u << t)) {                                                                                     \
-            if (!MF_ABL_TRSM) {   /* four independent products (one MFMA latency instead of four), then a tree sum */ \
+            /* four independent products (one MFMA latency instead of four), then a tree sum */                     \
             const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};                                                                    \
             const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], acc[t][0], z4, 0, 0, 0);                       \
             const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], acc[t][1], z4, 0, 0, 0);                       \
             const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], acc[t][2], z4, 0, 0, 0);                       \
             const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], acc[t][3], z4, 0, 0, 0);                       \
-            acc[t] = (D0 + D1) + (D2 + D3); /* = L_ik[l & 15][(l>>4) + 4 r] */ }                                     \
+            acc[t] = (D0 + D1) + (D2 + D3); /* = L_ik[l & 15][(l>>4) + 4 r] */                                       \
             mf_img_store(panP + ti_(t) * MF_IMG, mf_opaque(lane), acc[t]);                                          \
         }                                                                                                            \
     }
@@ -571,49 +592,100 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     }
                 }
                 MF_STAMP_FINE(2);
-                if (!MF_ABL_NOBAR) __syncthreads();   // B2(k): panel k complete; every wave has left update phase k-1
+                MF_TRACE_AT(8 * k + 1);
+                // panel k complete?  (also: every wave has left update phase k-1, so panel buffer (k+1)&1 may be rewritten)
+                if (lane == 0) __hip_atomic_fetch_add(pan_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                timed_out |= !mf_wait_ge(pan_cnt_addr, MF_WAVES * (k + 1));
                 MF_STAMP_FINE(3);
-                // the next diagonal tile: T_(k+1)(k+1) -= L_(k+1)k L_(k+1)k^T, then straight to the factor wave
-                if (k + 1 < nt) {
-                    const int idx1 = __builtin_amdgcn_readfirstlane(mf_cs(k + 1, NT));
-                    if (wave == idx1 % MF_WORKERS) {
-                        const unsigned smask = __builtin_amdgcn_readfirstlane(1u << (idx1 / MF_WORKERS));
+                MF_TRACE_AT(8 * k + 2);
+                // the owner of (k+1, k) takes the final L_(k+1)k back into its register slot (backward solve) and builds
+                // G_k = L_kk^-T L_(k+1)k^T: (L_(k+1)k L_kk^-1) in C/D layout is the operand image of its transpose.  It lands
+                // in the image slot of L_(k-1)(k-1)^-1, dead since panel k-1 was complete (k = 0: the tile (0,0) buffer).
+                {
+                    const int idxs = __builtin_amdgcn_readfirstlane(mf_cs(k, NT) + 1);
+                    if (wave == idxs % MF_WORKERS) {
+                        const unsigned smask = __builtin_amdgcn_readfirstlane(1u << (idxs / MF_WORKERS));
                         const int ln = mf_opaque(lane);
-                        const d4 a = mf_img_load(panP + (k + 1) * MF_IMG, ln);
-#define MF_DIAG_CASE(t)                                                                                              \
+                        const d4 Ln = mf_img_load(panP + (k + 1) * MF_IMG, ln);
+                        const d4 lt = mf_img_load(LinvT + k * MF_IMG, ln);
+#define MF_RELOAD_CASE(t)                                                                                            \
+    if constexpr (t < TPW) {                                                                                         \
+        if (smask & (1u << t)) acc[t] = Ln;                                                                          \
+    }
+                        MF_SLOTS(MF_RELOAD_CASE)
+                        const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
+                        const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[0], lt[0], z4, 0, 0, 0);
+                        const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[1], lt[1], z4, 0, 0, 0);
+                        const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[2], lt[2], z4, 0, 0, 0);
+                        const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[3], lt[3], z4, 0, 0, 0);
+                        mf_img_store(k > 0 ? Linv + (k - 1) * MF_IMG : Gzero, ln, (D0 + D1) + (D2 + D3));
+                    }
+                }
+                // next step's chain tiles first: (k+2,k+1) -= L_(k+2)k L_(k+1)k^T and (k+2,k+2) -= L_(k+2)k L_(k+2)k^T,
+                // then straight to the factor wave.
+#define MF_UPD_HAND_CASE(t)                                                                                          \
     if constexpr (t < TPW) {                                                                                         \
         if (smask & (1u << t)) {                                                                                     \
+            const int lnq = mf_opaque(lane);                                                                         \
+            const d4 a = mf_img_load(panP + tj_(t) * MF_IMG, lnq);                                                   \
+            const d4 b = mf_img_load(panP + ti_(t) * MF_IMG, lnq);                                                   \
             /* blgp = 1 on the f64 MFMA is NEG(A): acc - a*b  (tools/probe_mfma_f64.hip) */                          \
-            if (!MF_ABL_PASS1) {                                                                                     \
-                const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};   /* independent products: one MFMA latency on the chain */  \
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc[t], 0, 0, 1);                          \
-                const d4 S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], a[1], z4, 0, 0, 1);                         \
-                const d4 S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], a[2], z4, 0, 0, 1);                         \
-                const d4 S3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], a[3], z4, 0, 0, 1);                         \
-                acc[t] += (S1 + S2) + S3;                                                                            \
-            }                                                                                                        \
-            *reinterpret_cast<d4*>(DS + ln * 4) = acc[t];                                                            \
+            const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};   /* independent products: one MFMA latency on the chain */       \
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc[t], 0, 0, 1);                              \
+            const d4 S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], z4, 0, 0, 1);                             \
+            const d4 S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], z4, 0, 0, 1);                             \
+            const d4 S3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], z4, 0, 0, 1);                             \
+            acc[t] += (S1 + S2) + S3;                                                                                \
+            *reinterpret_cast<d4*>(hand_to + lnq * 4) = acc[t];                                                      \
         }                                                                                                            \
     }
-                        MF_SLOTS(MF_DIAG_CASE)
-                        mf_publish(tile_ready, k + 1);
+                if (k + 2 < nt) {
+                    const int idxs = __builtin_amdgcn_readfirstlane(mf_cs(k + 1, NT) + 1);
+                    if (wave == idxs % MF_WORKERS) {
+                        const unsigned smask = __builtin_amdgcn_readfirstlane(1u << (idxs / MF_WORKERS));
+                        double* hand_to = SubX;
+                        MF_SLOTS(MF_UPD_HAND_CASE)
+                        // this owner also applies panel k to the forward-solve rows of block k+2 (the release of sub_ready
+                        // orders it before the factor wave's own update of that block)
+                        timed_out |= !mf_wait_ge(z_ready_addr, k);
+                        if (lane < 16)
+                            for (int c = 0; c < ny; ++c)
+                                yc[c * MF_NPAD + MF_TS * (k + 2) + lane] -=
+                                    mf_row_dot(panP + (k + 2) * MF_IMG, lane, zv + c * MF_NPAD + MF_TS * k);
+                        mf_publish(sub_ready, k + 2);
+                    }
+                    const int idxd = __builtin_amdgcn_readfirstlane(mf_cs(k + 2, NT));
+                    if (wave == idxd % MF_WORKERS) {
+                        const unsigned smask = __builtin_amdgcn_readfirstlane(1u << (idxd / MF_WORKERS));
+                        double* hand_to = DS;
+                        MF_SLOTS(MF_UPD_HAND_CASE)
+                        mf_publish(tile_ready, k + 2);
                     }
                 }
                 MF_STAMP_FINE(4);
-                // forward solve rows the factor wave does not need first: y_i -= L_ik z_k, i >= k+2, one thread per row
-                if (!MF_ABL_YROWS && tid < MF_TS * (nt - 2 - k)) {
-                    const int i = k + 2 + (tid >> 4), mr = tid & 15;
+                MF_TRACE_AT(8 * k + 3);
+                // forward-solve rows of the blocks nobody on the chain needs yet: y_i -= L_ik z_k, i >= k+3, one thread per row.
+                // Deliberately AFTER the panel barrier and on the low waves only: their SIMD partners (waves 4..6) stream
+                // trailing-update MFMAs meanwhile, so in the MFMA-bound early steps this work is hidden.  (Doing it from the
+                // registers right after the TRSM, before the barrier, was measured 12k cycles slower per patch.)
+                if (tid < MF_TS * (nt - 3 - k)) {
+                    timed_out |= !mf_wait_ge(z_ready_addr, k);
+                    const int i = k + 3 + (tid >> 4), mr = tid & 15;
                     for (int c = 0; c < ny; ++c)
                         yc[c * MF_NPAD + MF_TS * i + mr] -= mf_row_dot(panP + i * 256, mr, zv + c * MF_NPAD + MF_TS * k);
                 }
                 MF_STAMP_FINE(5);
-                // the rest of the trailing matrix, T_ij -= L_jk L_ik^T  (idx > cs(k+1))
+                MF_TRACE_AT(8 * k + 4);
+                // the rest of the trailing matrix, T_ij -= L_jk L_ik^T: idx >= cs(k+1) + 2 except (k+2,k+2) = cs(k+2)
                 {
-                    const int t_first = (mf_cs(k + 1, NT) + 1 - wave + 6) / 7;
-                    const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_first, 30) & live_mask);
+                    const int t_first = (mf_cs(k + 1, NT) + 2 - wave + 6) / 7;
+                    unsigned m_ = mf_range_mask(t_first, 30) & live_mask;
+                    const int idxd = mf_cs(k + 2, NT);
+                    if (wave == idxd % MF_WORKERS) m_ &= ~(1u << (idxd / MF_WORKERS));
+                    const unsigned smask = __builtin_amdgcn_readfirstlane(m_);
 #define MF_UPD_CASE(t)                                                                                               \
     if constexpr (t < TPW) {                                                                                         \
-        if (!MF_ABL_UPD && (smask & (1u << t))) {                                                                    \
+        if (smask & (1u << t)) {                                                                                     \
             const int lnq = mf_opaque(lane);                                                                         \
             const d4 a = mf_img_load(panP + tj_(t) * MF_IMG, lnq);                                                   \
             const d4 b = mf_img_load(panP + ti_(t) * MF_IMG, lnq);                                                   \
@@ -624,57 +696,99 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     MF_SLOTS(MF_UPD_CASE)
                 }
                 MF_STAMP_FINE(6);
+                MF_TRACE_AT(8 * k + 5);
             }
         } else {
             // ================================ FACTOR ROLE ================================
-            // produces L_jj^-1, L_jj^-T, z_j for j = 0 .. nt-1 and the forward-solve rows of block j; joins B2(k).
-            // It is the critical path of every late step and shares its SIMD (and that SIMD's FP64 pipe) with a worker
-            // that streams MFMAs: static priority lets its short dependent FP64 chain win the arbitration
-            // (MI355X_MICROARCH.md, 'Two waves per SIMD', item 4).
+            // The critical chain of the factorisation, inside one wave: for j = 0 .. nt-1
+            //   W = tile (j,j)  ->  L_jj^-1, L_jj^-T (15 rank-1 MFMAs)  ->  z_j  ->  publish ready = j
+            //   tiles (j+1,j), (j+1,j+1) arrive from their owners (updated through panel j-1)
+            //   L_(j+1)j = TRSM (4 MFMAs) -> panel buffer, pan_cnt++  ->  (j+1,j+1) -= L L^T (4 MFMAs) = next W
+            //   y_(j+1) -= L_(j+1)j z_j  in the shadow of those MFMAs.
+            // It shares its SIMD (and that SIMD's FP64 pipe) with a worker that streams MFMAs: static priority lets its
+            // short dependent chain win the arbitration (MI355X_MICROARCH.md, 'Two waves per SIMD', item 4).
             __builtin_amdgcn_s_setprio(3);
             MF_STAMP(0);
+            timed_out |= !mf_wait_ge(t00_ready_addr, 1);
+            d4 W = *reinterpret_cast<const d4*>(Gzero + mf_opaque(lane) * 4);
             for (int j = 0; j < nt; ++j) {
-                const int k = j - 1;                                  // the panel this tile was last updated with
-                if (k >= 0) {
-                    MF_STAMP_FINE(1);
-                    if (!MF_ABL_NOBAR) __syncthreads();               // B2(k)
-                    MF_STAMP_FINE(3);
-                    const double* panP = panBase + (k & 1) * (16 * 256);
-                    // y_j -= L_jk z_k (rows of block j; the workers do blocks >= j+1)
-                    if (!MF_ABL_FWD && lane < 16) {
-                        for (int c = 0; c < ny; ++c)
-                            yc[c * MF_NPAD + MF_TS * j + lane] -= mf_row_dot(panP + j * 256, lane, zv + c * MF_NPAD + MF_TS * k);
-                    }
-                    // backward-solve shortcut: G_k = L_kk^-T L_jk^T (j = k+1) folds the sub-diagonal tile into the factor
-                    // wave's own recurrence, alpha_k = L_kk^-T (z_k - w_k) - G_k alpha_(k+1).  (L_jk L_kk^-1) in C/D layout is
-                    // the operand image of its transpose G_k; it lands in the image slot of L_(k-1)(k-1)^-1, dead since B2(k-1).
-                    {
-                        const int ln = mf_opaque(lane);
-                        const d4 Ln = mf_img_load(panP + j * MF_IMG, ln);
-                        const d4 lt = mf_img_load(LinvT + k * MF_IMG, ln);
-                        const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
-                        const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[0], lt[0], z4, 0, 0, 0);
-                        const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[1], lt[1], z4, 0, 0, 0);
-                        const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[2], lt[2], z4, 0, 0, 0);
-                        const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[3], lt[3], z4, 0, 0, 0);
-                        mf_img_store(k > 0 ? Linv + (k - 1) * MF_IMG : Gzero, ln, (D0 + D1) + (D2 + D3));
+                MF_STAMP_FINE(4);
+                MF_TRACE_AT(8 * j + 0);
+                const bool ok = mf_diag_factor(W, DS + 256, Linv + j * 256, LinvT + j * 256, g.pivot_tol);
+                MF_STAMP_FINE(5);
+                MF_TRACE_AT(8 * j + 1);
+                if (!ok && lane == 0) flag[0] = 1;
+                mf_publish(ready, j);            // L_jj^-1 is all the workers need to start their TRSMs; z_j follows
+                MF_TRACE_AT(8 * j + 2);
+                const int ln = mf_opaque(lane);
+                double* panP = panBase + (j & 1) * (16 * 256);
+                const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
+                d4 D0 = z4, D1 = z4, D2 = z4, D3 = z4;
+                const d4 lv = mf_img_load(Linv + j * MF_IMG, ln);
+                // right-hand sides of block j as MFMA B operand: column n < ny carries channel n
+                d4 yb = z4;
+                {
+                    const int lr = ln & 15, lg = ln >> 4;
+                    if (lr < ny) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) yb[q4] = yc[lr * MF_NPAD + MF_TS * j + lg + 4 * q4];
                     }
                 }
-                if (!MF_ABL_NOWAIT) timed_out |= !mf_wait_ge(tile_ready_addr, j);
-                MF_STAMP_FINE(4);
-                const bool ok = MF_ABL_DIAG ? true : mf_diag_factor(DS, DS + 256, Linv + j * 256, LinvT + j * 256, g.pivot_tol);
-                MF_STAMP_FINE(5);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                // z_j = L_jj^-1 y_j  (y_j already carries -sum_{i<j} L_ji z_i): 16 row-threads
-                if (!MF_ABL_FWD && lane < 16)
-                    for (int c = 0; c < ny; ++c)
-                        zv[c * MF_NPAD + MF_TS * j + lane] = mf_row_dot(Linv + j * 256, lane, yc + c * MF_NPAD + MF_TS * j);
-                if (!ok && lane == 0) flag[0] = 1;
-                mf_publish(ready, j);
+                if (ok && j + 1 < nt) {
+                    // TRSM of the sub-diagonal tile: L_(j+1)j^T = L_jj^-1 A^T
+                    timed_out |= !mf_wait_ge(sub_ready_addr, j + 1);
+                    MF_TRACE_AT(8 * j + 3);
+                    const d4 B = *reinterpret_cast<const d4*>(SubX + ln * 4);
+                    D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], B[0], z4, 0, 0, 0);
+                    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], B[1], z4, 0, 0, 0);
+                    D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], B[2], z4, 0, 0, 0);
+                    D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], B[3], z4, 0, 0, 0);
+                }
+                // behind them on the pipe: z_j = L_jj^-1 y_j (y_j already carries -sum_{i<j} L_ji z_i) as one more 16x16x16 product
+                const d4 Z0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], yb[0], z4, 0, 0, 0);
+                const d4 Z1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], yb[1], z4, 0, 0, 0);
+                const d4 Z2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], yb[2], z4, 0, 0, 0);
+                const d4 Z3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], yb[3], z4, 0, 0, 0);
+                d4 Ln = z4, S1 = z4, S2 = z4, S3 = z4;
+                if (ok && j + 1 < nt) {
+                    Ln = (D0 + D1) + (D2 + D3);                       // operand image of L_(j+1)j
+                    mf_img_store(panP + (j + 1) * MF_IMG, ln, Ln);
+                    timed_out |= !mf_wait_ge(tile_ready_addr, j + 1);
+                    MF_TRACE_AT(8 * j + 4);
+                    W = *reinterpret_cast<const d4*>(DS + ln * 4);
+                    // (j+1,j+1) -= L_(j+1)j L_(j+1)j^T: independent products, one MFMA latency on the chain
+                    W = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[0], Ln[0], W, 0, 0, 1);      // blgp = 1: NEG(A)
+                    S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[1], Ln[1], z4, 0, 0, 1);
+                    S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[2], Ln[2], z4, 0, 0, 1);
+                    S3 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[3], Ln[3], z4, 0, 0, 1);
+                }
+                // in the shadow of those MFMAs: publish z_j, count up the panel, y_(j+1) -= L_(j+1)j z_j from the registers
+                {
+                    const d4 zj = (Z0 + Z1) + (Z2 + Z3);   // lanes lr = n < ny: z_n[16 j + (l>>4) + 4 r]
+                    const int lr = ln & 15, lg = ln >> 4;
+                    if (lr < ny) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zv[lr * MF_NPAD + MF_TS * j + lg + 4 * r] = zj[r];
+                    }
+                }
+                mf_publish(z_ready, j);
                 MF_STAMP_FINE(2);
                 if (!ok) break;                                       // the workers leave at step j as well
+                if (j + 1 < nt) {
+                    if (lane == 0) __hip_atomic_fetch_add(pan_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    MF_STAMP_FINE(3);
+                    {
+                        const int lr = ln & 15, lg = ln >> 4;
+                        for (int c = 0; c < ny; ++c) {
+                            const double* zq = zv + c * MF_NPAD + MF_TS * j + lg;
+                            atomicAdd(yc + c * MF_NPAD + MF_TS * (j + 1) + lr,
+                                      -((Ln[0] * zq[0] + Ln[1] * zq[4]) + (Ln[2] * zq[8] + Ln[3] * zq[12])));
+                        }
+                    }
+                    W += (S1 + S2) + S3;
+                    MF_TRACE_AT(8 * j + 5);
+                }
             }
-            if (!MF_ABL_NOBAR && !__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) __syncthreads();   // B2(nt-1)
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
@@ -964,6 +1078,44 @@ int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a)
             fprintf(stderr, "\n");
         }
     } dump{ctx, g.stamps, grid};
+#endif
+#ifdef MF_TRACE
+    GPC_HIP(ctx, hipMalloc(&g.stamps, sizeof(unsigned long long) * (size_t)grid * MF_WAVES * MF_NTR));
+    GPC_HIP(ctx, hipMemsetAsync(g.stamps, 0, sizeof(unsigned long long) * (size_t)grid * MF_WAVES * MF_NTR, ctx->stream));
+    struct TraceDump {
+        gpc_ctx* ctx; unsigned long long* d; int grid;
+        ~TraceDump()
+        {
+            std::vector<unsigned long long> h((size_t)grid * MF_WAVES * MF_NTR);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            (void)hipFree(d);
+            std::vector<double> sum((size_t)MF_WAVES * MF_NTR, 0.0), cnt((size_t)MF_WAVES * MF_NTR, 0.0);
+            for (int b = 0; b < grid; ++b) {
+                unsigned long long t0 = ~0ull;
+                for (int q = 0; q < MF_WAVES * MF_NTR; ++q) {
+                    const unsigned long long v = h[(size_t)b * MF_WAVES * MF_NTR + q];
+                    if (v && v < t0) t0 = v;
+                }
+                for (int q = 0; q < MF_WAVES * MF_NTR; ++q) {
+                    const unsigned long long v = h[(size_t)b * MF_WAVES * MF_NTR + q];
+                    if (v) { sum[q] += (double)(v - t0); cnt[q] += 1.0; }
+                }
+            }
+            auto at = [&](int w, int slot) { const size_t q = (size_t)w * MF_NTR + slot; return cnt[q] > 0 ? sum[q] / cnt[q] : -1.0; };
+            fprintf(stderr, "[MF_TRACE] mean s_memtime ticks since the first trace point of the patch\n");
+            fprintf(stderr, "step | factor: diag0 diag1 ready  sub   tile  end  | wave0: ready trsm  pan   prio  yrow  bulk | wave3: ready trsm  pan   prio  yrow  bulk | wave6: ...\n");
+            for (int k = 0; k < 16; ++k) {
+                fprintf(stderr, "%4d |", k);
+                for (int p = 0; p < 6; ++p) fprintf(stderr, " %6.0f", at(7, 8 * k + p));
+                for (int w : {0, 3, 6}) {
+                    fprintf(stderr, " |");
+                    for (int p = 0; p < 6; ++p) fprintf(stderr, " %6.0f", at(w, 8 * k + p));
+                }
+                fprintf(stderr, "\n");
+            }
+        }
+    } tdump{ctx, g.stamps, grid};
 #endif
     if (a.n_max <= 64) return launch_nt<4>(ctx, g, grid, "dense_mfma_nt4");
     if (a.n_max <= 128) return launch_nt<8>(ctx, g, grid, "dense_mfma_nt8");
