@@ -15,12 +15,18 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: keep only the most recent run of each pass"""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] if fs else []
+
+
+stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
-    for f in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(src, d, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
             pmc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
