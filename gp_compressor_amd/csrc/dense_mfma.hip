@@ -77,7 +77,7 @@ struct MfmaParams {
 
 // Diagnostic timeline (-DMF_TRACE, tools/stamp_mfma.py --trace): lane 0 of every wave drops s_memtime at fixed points of
 // every factorisation step into global memory; the host prints the mean timeline of factor wave and workers.
-#define MF_NTR 160
+#define MF_NTR 168
 #ifdef MF_TRACE
 #define MF_TRACE_AT(slot)                                                                                            \
     do {                                                                                                             \
@@ -557,24 +557,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             // ---- right-looking tiled Cholesky, worker side ----
             // The factor wave owns the whole critical chain of a tile column: diag factor (k,k) -> TRSM of the sub-diagonal
             // tile (k+1,k) -> update and factor of (k+1,k+1).  It gets both tiles one step AHEAD (updated through panel k-1)
-            // from their owners, who update and hand them over first thing after panel k-1 is complete.  A worker's step k:
-            //   wait for L_kk^-1 | TRSM of its tiles (i,k), i >= k+2 -> panel buffer k&1 | count up pan_cnt, wait for
-            //   8 (k+1) | owner of (k+1,k): take the final tile back from the panel, build G_k | owners of (k+2,k+1) and
-            //   (k+2,k+2): update with panel k, hand over | forward-solve rows | the rest of the trailing update.
-            // No workgroup barrier: the factor wave only counts up pan_cnt, it never waits for the workers' TRSMs.
-            for (int k = 0; k + 1 < nt; ++k) {
-                double* panP = panBase + (k & 1) * (16 * 256);
-                timed_out |= !mf_wait_ge(ready_addr, k);
-                MF_STAMP_FINE(1);
-                MF_TRACE_AT(8 * k + 0);
-                if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                {
-                    const int lo_ = mf_cs(k, NT) + 2 - wave, hi_ = mf_cs(k + 1, NT) - 1 - wave;
-                    const int t_lo = __builtin_amdgcn_readfirstlane((lo_ + 6) / 7);
-                    const int t_hi = __builtin_amdgcn_readfirstlane((hi_ + 7) / 7 - 1);
-                    const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_lo, t_hi) & live_mask);
-                    if (smask) {
-                        const d4 lv = mf_img_load(Linv + k * MF_IMG, mf_opaque(lane));
+            // from their owners, who update and hand them over first thing after panel k-1 is complete.
+            // A worker's step k starts when panel k is complete (pan_cnt == 8 (k+1): 7 workers + the factor wave; the
+            // factor wave only counts up, it never waits for the workers, and there is no s_barrier in the loop):
+            //   owner of (k+1,k): take the final tile back from the panel, build G_k | owners of (k+2,k+1), (k+2,k+2):
+            //   update with panel k, hand over | forward-solve rows | trailing update of the columns >= k+2 | LOOK-AHEAD:
+            //   its tiles of column k+1 are updated with panel k and solved with L_(k+1)(k+1)^-1 straight away -> panel k+1.
+            // The TRSMs of panel k+1 thus run inside update k, interleaved with the SIMD partner's MFMAs, instead of in a
+            // phase of their own between two synchronisation points.
 #define MF_TRSM_CASE(t)                                                                                              \
     if constexpr (t < TPW) {                                                                                         \
         if (smask & (1u << t)) {                                                                                     \
@@ -585,19 +575,63 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], acc[t][2], z4, 0, 0, 0);                       \
             const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], acc[t][3], z4, 0, 0, 0);                       \
             acc[t] = (D0 + D1) + (D2 + D3); /* = L_ik[l & 15][(l>>4) + 4 r] */                                       \
-            mf_img_store(panP + ti_(t) * MF_IMG, mf_opaque(lane), acc[t]);                                          \
+            mf_img_store(panN + ti_(t) * MF_IMG, mf_opaque(lane), acc[t]);                                          \
         }                                                                                                            \
     }
-                        MF_SLOTS(MF_TRSM_CASE)
-                    }
+#define MF_UPD_CASE(t)                                                                                               \
+    if constexpr (t < TPW) {                                                                                         \
+        if (smask & (1u << t)) {                                                                                     \
+            const int lnq = mf_opaque(lane);                                                                         \
+            const d4 a = mf_img_load(panP + tj_(t) * MF_IMG, lnq);                                                   \
+            const d4 b = mf_img_load(panP + ti_(t) * MF_IMG, lnq);                                                   \
+            /* blgp = 1 on the f64 MFMA is NEG(A): acc - a*b  (tools/probe_mfma_f64.hip) */                          \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                            \
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc[t], 0, 0, 1);                          \
+        }                                                                                                            \
+    }
+#define MF_UPD_TRSM_CASE(t) MF_UPD_CASE(t) MF_TRSM_CASE(t)
+#define MF_UPD_HAND_CASE(t)                                                                                          \
+    if constexpr (t < TPW) {                                                                                         \
+        if (smask & (1u << t)) {                                                                                     \
+            const int lnq = mf_opaque(lane);                                                                         \
+            const d4 a = mf_img_load(panP + tj_(t) * MF_IMG, lnq);                                                   \
+            const d4 b = mf_img_load(panP + ti_(t) * MF_IMG, lnq);                                                   \
+            const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};   /* independent products: one MFMA latency on the chain */       \
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc[t], 0, 0, 1);                              \
+            const d4 S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], z4, 0, 0, 1);                             \
+            const d4 S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], z4, 0, 0, 1);                             \
+            const d4 S3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], z4, 0, 0, 1);                             \
+            acc[t] += (S1 + S2) + S3;                                                                                \
+            *reinterpret_cast<d4*>(hand_to + lnq * 4) = acc[t];                                                      \
+        }                                                                                                            \
+    }
+#define MF_RELOAD_CASE(t)                                                                                            \
+    if constexpr (t < TPW) {                                                                                         \
+        if (smask & (1u << t)) acc[t] = Ln;                                                                          \
+    }
+            bool dead = false;
+            // prologue: panel 0 = TRSM of column 0 with L_00^-1
+            timed_out |= !mf_wait_ge(ready_addr, 0);
+            dead = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+            if (!dead && nt > 1) {
+                double* panN = panBase;
+                const int lo_ = mf_cs(0, NT) + 2 - wave, hi_ = mf_cs(1, NT) - 1 - wave;
+                const int t_lo = __builtin_amdgcn_readfirstlane((lo_ + 6) / 7);
+                const int t_hi = __builtin_amdgcn_readfirstlane((hi_ + 7) / 7 - 1);
+                const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_lo, t_hi) & live_mask);
+                if (smask) {
+                    const d4 lv = mf_img_load(Linv, mf_opaque(lane));
+                    MF_SLOTS(MF_TRSM_CASE)
                 }
-                MF_STAMP_FINE(2);
-                MF_TRACE_AT(8 * k + 1);
-                // panel k complete?  (also: every wave has left update phase k-1, so panel buffer (k+1)&1 may be rewritten)
                 if (lane == 0) __hip_atomic_fetch_add(pan_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            for (int k = 0; k + 1 < nt && !dead; ++k) {
+                double* panP = panBase + (k & 1) * (16 * 256);
+                double* panN = panBase + ((k + 1) & 1) * (16 * 256);
+                // panel k complete?  (also: every wave has finished step k-1, so panel buffer (k+1)&1 may be rewritten)
                 timed_out |= !mf_wait_ge(pan_cnt_addr, MF_WAVES * (k + 1));
-                MF_STAMP_FINE(3);
-                MF_TRACE_AT(8 * k + 2);
+                MF_STAMP_FINE(1);
+                MF_TRACE_AT(8 * k + 0);
                 // the owner of (k+1, k) takes the final L_(k+1)k back into its register slot (backward solve) and builds
                 // G_k = L_kk^-T L_(k+1)k^T: (L_(k+1)k L_kk^-1) in C/D layout is the operand image of its transpose.  It lands
                 // in the image slot of L_(k-1)(k-1)^-1, dead since panel k-1 was complete (k = 0: the tile (0,0) buffer).
@@ -608,10 +642,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         const int ln = mf_opaque(lane);
                         const d4 Ln = mf_img_load(panP + (k + 1) * MF_IMG, ln);
                         const d4 lt = mf_img_load(LinvT + k * MF_IMG, ln);
-#define MF_RELOAD_CASE(t)                                                                                            \
-    if constexpr (t < TPW) {                                                                                         \
-        if (smask & (1u << t)) acc[t] = Ln;                                                                          \
-    }
                         MF_SLOTS(MF_RELOAD_CASE)
                         const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
                         const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[0], lt[0], z4, 0, 0, 0);
@@ -623,22 +653,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 }
                 // next step's chain tiles first: (k+2,k+1) -= L_(k+2)k L_(k+1)k^T and (k+2,k+2) -= L_(k+2)k L_(k+2)k^T,
                 // then straight to the factor wave.
-#define MF_UPD_HAND_CASE(t)                                                                                          \
-    if constexpr (t < TPW) {                                                                                         \
-        if (smask & (1u << t)) {                                                                                     \
-            const int lnq = mf_opaque(lane);                                                                         \
-            const d4 a = mf_img_load(panP + tj_(t) * MF_IMG, lnq);                                                   \
-            const d4 b = mf_img_load(panP + ti_(t) * MF_IMG, lnq);                                                   \
-            /* blgp = 1 on the f64 MFMA is NEG(A): acc - a*b  (tools/probe_mfma_f64.hip) */                          \
-            const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};   /* independent products: one MFMA latency on the chain */       \
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc[t], 0, 0, 1);                              \
-            const d4 S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], z4, 0, 0, 1);                             \
-            const d4 S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], z4, 0, 0, 1);                             \
-            const d4 S3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], z4, 0, 0, 1);                             \
-            acc[t] += (S1 + S2) + S3;                                                                                \
-            *reinterpret_cast<d4*>(hand_to + lnq * 4) = acc[t];                                                      \
-        }                                                                                                            \
-    }
                 if (k + 2 < nt) {
                     const int idxs = __builtin_amdgcn_readfirstlane(mf_cs(k + 1, NT) + 1);
                     if (wave == idxs % MF_WORKERS) {
@@ -663,11 +677,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     }
                 }
                 MF_STAMP_FINE(4);
-                MF_TRACE_AT(8 * k + 3);
+                MF_TRACE_AT(8 * k + 1);
                 // forward-solve rows of the blocks nobody on the chain needs yet: y_i -= L_ik z_k, i >= k+3, one thread per row.
-                // Deliberately AFTER the panel barrier and on the low waves only: their SIMD partners (waves 4..6) stream
-                // trailing-update MFMAs meanwhile, so in the MFMA-bound early steps this work is hidden.  (Doing it from the
-                // registers right after the TRSM, before the barrier, was measured 12k cycles slower per patch.)
+                // On the low waves only: their SIMD partners (waves 4..6) stream trailing-update MFMAs meanwhile, so in the
+                // MFMA-bound early steps this work is hidden.  (Doing it from the registers right after the TRSM, before the
+                // synchronisation point, was measured 12k cycles slower per patch.)
                 if (tid < MF_TS * (nt - 3 - k)) {
                     timed_out |= !mf_wait_ge(z_ready_addr, k);
                     const int i = k + 3 + (tid >> 4), mr = tid & 15;
@@ -675,27 +689,31 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         yc[c * MF_NPAD + MF_TS * i + mr] -= mf_row_dot(panP + i * 256, mr, zv + c * MF_NPAD + MF_TS * k);
                 }
                 MF_STAMP_FINE(5);
-                MF_TRACE_AT(8 * k + 4);
-                // the rest of the trailing matrix, T_ij -= L_jk L_ik^T: idx >= cs(k+1) + 2 except (k+2,k+2) = cs(k+2)
+                MF_TRACE_AT(8 * k + 2);
+                // trailing update of the columns >= k+2, T_ij -= L_jk L_ik^T: idx >= cs(k+2) + 1 ((k+2,k+2) went to the factor wave)
                 {
-                    const int t_first = (mf_cs(k + 1, NT) + 2 - wave + 6) / 7;
-                    unsigned m_ = mf_range_mask(t_first, 30) & live_mask;
-                    const int idxd = mf_cs(k + 2, NT);
-                    if (wave == idxd % MF_WORKERS) m_ &= ~(1u << (idxd / MF_WORKERS));
-                    const unsigned smask = __builtin_amdgcn_readfirstlane(m_);
-#define MF_UPD_CASE(t)                                                                                               \
-    if constexpr (t < TPW) {                                                                                         \
-        if (smask & (1u << t)) {                                                                                     \
-            const int lnq = mf_opaque(lane);                                                                         \
-            const d4 a = mf_img_load(panP + tj_(t) * MF_IMG, lnq);                                                   \
-            const d4 b = mf_img_load(panP + ti_(t) * MF_IMG, lnq);                                                   \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                            \
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc[t], 0, 0, 1);                          \
-        }                                                                                                            \
-    }
+                    const int t_first = (mf_cs(k + 2, NT) + 1 - wave + 6) / 7;
+                    const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_first, 30) & live_mask);
                     MF_SLOTS(MF_UPD_CASE)
                 }
                 MF_STAMP_FINE(6);
+                MF_TRACE_AT(8 * k + 3);
+                // look-ahead: column k+1 -- update with panel k, TRSM with L_(k+1)(k+1)^-1, store into panel k+1.
+                // Every worker polls `ready` here, with or without tiles: that is where a not-SPD verdict reaches it.
+                timed_out |= !mf_wait_ge(ready_addr, k + 1);
+                MF_TRACE_AT(8 * k + 4);
+                if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                if (k + 2 < nt) {
+                    const int lo_ = mf_cs(k + 1, NT) + 2 - wave, hi_ = mf_cs(k + 2, NT) - 1 - wave;
+                    const int t_lo = __builtin_amdgcn_readfirstlane((lo_ + 6) / 7);
+                    const int t_hi = __builtin_amdgcn_readfirstlane((hi_ + 7) / 7 - 1);
+                    const unsigned smask = __builtin_amdgcn_readfirstlane(mf_range_mask(t_lo, t_hi) & live_mask);
+                    if (smask) {
+                        const d4 lv = mf_img_load(Linv + (k + 1) * MF_IMG, mf_opaque(lane));
+                        MF_SLOTS(MF_UPD_TRSM_CASE)
+                    }
+                    if (lane == 0) __hip_atomic_fetch_add(pan_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 MF_TRACE_AT(8 * k + 5);
             }
         } else {
@@ -1105,6 +1123,12 @@ int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a)
             auto at = [&](int w, int slot) { const size_t q = (size_t)w * MF_NTR + slot; return cnt[q] > 0 ? sum[q] / cnt[q] : -1.0; };
             fprintf(stderr, "[MF_TRACE] mean s_memtime ticks since the first trace point of the patch\n");
             fprintf(stderr, "step | factor: diag0 diag1 ready  sub   tile  end  | wave0: ready trsm  pan   prio  yrow  bulk | wave3: ready trsm  pan   prio  yrow  bulk | wave6: ...\n");
+            fprintf(stderr, "step | end of the step's last phase, waves 0..6 | panel complete seen by wave 0\n");
+            for (int k = 0; k < 16; ++k) {
+                fprintf(stderr, "%4d |", k);
+                for (int w = 0; w < 7; ++w) fprintf(stderr, " %6.0f", at(w, 8 * k + 5));
+                fprintf(stderr, " | %6.0f\n", at(0, 8 * (k + 1)));
+            }
             for (int k = 0; k < 16; ++k) {
                 fprintf(stderr, "%4d |", k);
                 for (int p = 0; p < 6; ++p) fprintf(stderr, " %6.0f", at(7, 8 * k + p));
