@@ -192,6 +192,15 @@ def main():
                          "kernel_ms": kern_ms, "flops_per_patch": algorithmic_flops(n, m)},
         }
         if world == 1 and not args.no_cpu_baseline:
+            # the host-pointer entry of the C-ABI (H2D of the patch buffers + kernel + D2H of f*), for the record: this
+            # PCIe-inclusive rate is NOT `value` (inputs are HBM-resident in the timed region above)
+            ctx.dense_fit_predict_grid(prm, off, x0, x1, y, res, sz)
+            th = time.perf_counter()
+            for _ in range(3):
+                ctx.dense_fit_predict_grid(prm, off, x0, x1, y, res, sz)
+            th = (time.perf_counter() - th) / 3
+            out["host_pointer_entry"] = {"value": P / th, "unit": "patches/s", "ms_per_call": 1e3 * th,
+                                         "what": "gpc_dense_fit_predict_grid with host buffers: H2D + kernel + D2H, synchronous"}
             rec, rmse, maxabs, frms = cpu_baseline(off, x0, x1, y, res, sz, f_host)
             out["cpu_baseline"] = rec
             out["rmse_vs_ref"] = {"rmse": rmse, "max_abs": maxabs, "f_rms": frms,

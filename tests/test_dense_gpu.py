@@ -63,7 +63,8 @@ def kernel_choice(request, monkeypatch):
 
 @pytest.mark.parametrize("P,n,ny,ragged,seed", [(37, 64, 1, True, 1), (9, 200, 3, True, 2), (5, 256, 1, False, 3),
                                                 (3, 300, 1, True, 4), (2, 515, 3, True, 5), (40, 17, 1, True, 6),
-                                                (11, 128, 1, True, 7), (6, 192, 1, True, 8), (300, 256, 1, True, 9)])
+                                                (11, 128, 1, True, 7), (6, 192, 1, True, 8), (300, 256, 1, True, 9),
+                                                (3, 512, 1, False, 10), (1, 1024, 1, False, 11)])   # C3 / C5 patch sizes
 def test_dense_vs_oracle(gp, oracle, kernel_choice, P, n, ny, ragged, seed):
     capi, ctx = gp
     off, x0, x1, y = synth.make_patches(P, n, seed=seed, ragged=ragged, ny=ny)
