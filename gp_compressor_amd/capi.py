@@ -59,6 +59,8 @@ PROTOTYPES = {
     "gpc_sparse_add_dev": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_predict": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "gpc_sparse_predict_dev": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "gpc_sparse_likelihood": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gpc_sparse_likelihood_dev": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_sizes": (C.c_int, [_vp, _vp]),
     "gpc_sparse_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_ld": (C.c_int, [_vp]),
@@ -255,6 +257,23 @@ class Sparse:
     def predict_dev(self, m, xs0, xs1, f_star, sigma=None, conf=False, status=None):
         self.ctx._check(self.lib.gpc_sparse_predict_dev(self.h, m, _ptr(xs0), _ptr(xs1), _ptr(f_star), _ptr(sigma),
                                                         int(conf), _ptr(status)))
+
+    def likelihood(self, off, x0, x1, y, want_dx=True, want_l=True):
+        """compute_derivatives + compute_likelihoods (src/sparse_gp.h:44-45) on a ragged batch: dX (N, 3), l (N)"""
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.float64)
+        N = int(off[-1])
+        assert y.shape == (self.ny, N) and off.shape[0] == self.P + 1
+        dX = np.full((N, 3), np.nan) if want_dx else None
+        l = np.full(N, np.nan) if want_l else None
+        self.ctx._check(self.lib.gpc_sparse_likelihood(self.h, _ptr(off), _ptr(x0), _ptr(x1), _ptr(y), _ptr(dX), _ptr(l)))
+        return dX, l
+
+    def likelihood_dev(self, off, n_total, x0, x1, y, dX=None, l=None):
+        self.ctx._check(self.lib.gpc_sparse_likelihood_dev(self.h, _ptr(off), int(n_total), _ptr(x0), _ptr(x1), _ptr(y),
+                                                           _ptr(dX), _ptr(l)))
 
     def sizes(self):
         b = np.zeros(self.P, dtype=np.int32)

@@ -444,9 +444,127 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_predict_kernel(SpPredParams
     }
 }
 
+// ---- registration inner loop: likelihoods and their derivatives on ragged point sets ----
+// sparse_gp::compute_likelihoods -> likelihood (/root/reference/src/sparse_gp.hpp:387-427) and compute_derivatives ->
+// likelihood_dx (:463-508) with rbf_kernel::kernel_dx (src/rbf_kernel.cpp:33-41); field variants
+// src/sparse_gp_field.hpp:322-392.  Per point: k (b), v = C k (the O(b^2) part), then
+//   sigma = s20 + k^T v + k**,  off = y - alpha^T k,  sigma_dx = 2 k_dx^T v,  k_dx row j = -(p0/p1) (x - BV_j) exp(..) = -(x - BV_j) k_j / p1
+//   l = exp(-|off|^2 / (2 sigma)) / sqrt((2 pi)^ny sigma)
+//   dX = exppart * (-sigma_dx + 2 (k_dx^T alpha) off + sigma_dx / sigma |off|^2),  exppart = exp(-|off|^2/(2 sigma)) / (2 sigma^1.5)
+// Same work distribution as the sigma path of sparse_predict_kernel: chunks of SP_PC points, thread = (point, one of 8
+// row groups of C), partial sums reduced through LDS.
+struct SpLikParams {
+    gpc_params prm;
+    double c_exp;
+    int P, ny, ld, n_total;
+    const int32_t* off;
+    const double *x0, *x1, *y;
+    const double *alpha, *C, *BV;
+    const int32_t* b;
+    double *dX, *l;
+};
+#define SP_NQ 12   // partial sums per thread: kCk, 2 x (k_dx^T v), ny x mu, 2 x ny x (k_dx^T alpha)
+
+__global__ __launch_bounds__(SP_THREADS) void sparse_likelihood_kernel(SpLikParams A)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int ld = A.ld, ny = A.ny;
+    double* T = reinterpret_cast<double*>(smem);   // 64
+    double* bv = T + 64;                           // 2*ld
+    double* al = bv + 2 * ld;                      // 3*ld
+    double* racc = al + 3 * ld;                    // [SP_NQ][8][SP_PC]
+    double* Kc = racc + SP_NQ * 8 * SP_PC;         // [ld][SP_PC]
+    gpc_exp_table_init(T);
+    const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, inv_l = 1.0 / A.prm.l_sq;
+
+    for (int patch = blockIdx.x; patch < A.P; patch += gridDim.x) {
+        const int b = A.b[patch];
+        const int o = A.off[patch], n = A.off[patch + 1] - o;
+        const double* Cg = A.C + (size_t)patch * ld * ld;
+        __syncthreads();
+        for (int i = tid; i < b; i += SP_THREADS) {
+            bv[2 * i] = A.BV[(size_t)patch * ld * 2 + 2 * i];
+            bv[2 * i + 1] = A.BV[(size_t)patch * ld * 2 + 2 * i + 1];
+            for (int c = 0; c < ny; ++c) al[c * ld + i] = A.alpha[((size_t)patch * ny + c) * ld + i];
+        }
+        for (int p0 = 0; p0 < n; p0 += SP_PC) {
+            const int pc = min(SP_PC, n - p0);
+            __syncthreads();
+            for (int e = tid; e < b * SP_PC; e += SP_THREADS) {
+                const int pp = e & (SP_PC - 1), i = e / SP_PC;
+                Kc[i * SP_PC + pp] = (pp < pc) ? gpc_rbf(sf, A.c_exp, A.x0[o + p0 + pp], A.x1[o + p0 + pp], bv[2 * i], bv[2 * i + 1], T) : 0.0;
+            }
+            __syncthreads();
+            const int pp = tid & (SP_PC - 1), ig = tid / SP_PC;   // 8 row groups
+            const bool live = pp < pc;
+            const double q0 = live ? A.x0[o + p0 + pp] : 0.0, q1 = live ? A.x1[o + p0 + pp] : 0.0;
+            double acc[SP_NQ];
+#pragma unroll
+            for (int q = 0; q < SP_NQ; ++q) acc[q] = 0.0;
+            for (int j = ig; j < b; j += SP_THREADS / SP_PC) {
+                double t = 0.0;                                   // v_j = (C k)_j, C symmetric
+                for (int i = 0; i < b; ++i) t += Kc[i * SP_PC + pp] * Cg[i + (size_t)j * ld];
+                const double kj = Kc[j * SP_PC + pp];
+                const double g0 = -(q0 - bv[2 * j]) * kj * inv_l, g1 = -(q1 - bv[2 * j + 1]) * kj * inv_l;   // k_dx row j
+                acc[0] += t * kj;
+                acc[1] += g0 * t;
+                acc[2] += g1 * t;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (c < ny) {
+                        const double a = al[c * ld + j];
+                        acc[3 + c] += a * kj;
+                        acc[6 + c] += g0 * a;
+                        acc[9 + c] += g1 * a;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SP_NQ; ++q) racc[(q * 8 + ig) * SP_PC + pp] = acc[q];
+            __syncthreads();
+            if (tid < pc) {
+                double r[SP_NQ];
+#pragma unroll
+                for (int q = 0; q < SP_NQ; ++q) {
+                    double s_ = 0.0;
+                    for (int w = 0; w < SP_THREADS / SP_PC; ++w) s_ += racc[(q * 8 + w) * SP_PC + tid];
+                    r[q] = s_;
+                }
+                const double kstar = sf;
+                double offv[3] = {0.0, 0.0, 0.0}, sq = 0.0;
+                for (int c = 0; c < ny; ++c) {
+                    offv[c] = A.y[(size_t)c * A.n_total + o + p0 + tid] - r[3 + c];
+                    sq += offv[c] * offv[c];
+                }
+                if (A.l) {
+                    const double sigma = s20 + kstar + r[0];                                    // :420-425
+                    const double two_pi = (double)2.0f * 3.14159265358979323846;
+                    const double norm = (ny == 1) ? two_pi * sigma : two_pi * two_pi * two_pi * sigma;
+                    A.l[o + p0 + tid] = (double)1.0f / sqrt(norm) * exp((double)(-0.5f) / sigma * sq);
+                }
+                if (A.dX) {
+                    const double sigma = s20 + r[0] + kstar;                                    // :485
+                    const double sqrtsigma = sqrt(sigma);
+                    const double exppart = (double)0.5f / (sigma * sqrtsigma) * exp((double)(-0.5f) / sigma * sq);
+                    double* d = A.dX + (size_t)(o + p0 + tid) * 3;
+                    for (int dd = 0; dd < 2; ++dd) {
+                        const double sigma_dx = (double)2.0f * r[1 + dd];
+                        double ko = 0.0;
+                        for (int c = 0; c < ny; ++c) ko += r[6 + 3 * dd + c] * offv[c];
+                        d[1 + dd] = exppart * (-sigma_dx + (double)2.0f * ko + sigma_dx / sigma * sq);
+                    }
+                    d[0] = (ny == 1) ? (double)(-1.0f) / (sigma * sqrtsigma) * offv[0] * exppart : 0.0;   // field: dx(0) = 0
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 
 static size_t sp_add_lds(int ld) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (ld + 1) + 8 * ld); }
+static size_t sp_lik_lds(int ld) { return sizeof(double) * (size_t)(64 + 5 * ld + SP_NQ * 8 * SP_PC + (size_t)ld * SP_PC); }
 static size_t sp_pred_lds(int ld, bool sigma)
 {
     return sizeof(double) * (size_t)(64 + 5 * ld + (sigma ? (size_t)ld * SP_PC : 0) + 8 * SP_PC + 2);
@@ -576,6 +694,87 @@ int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double
     int grid = std::min(g->P, ctx->num_cus * per_cu);
     hipLaunchKernelGGL(sparse_predict_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());
+    return GPC_OK;
+}
+
+int gpc_sparse_likelihood_dev(gpc_sparse* g, const int32_t* off, int n_total, const double* x0, const double* x1,
+                              const double* y, double* dX, double* l)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    if (g->P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    if (n_total < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
+    if (n_total > 0 && (!x0 || !x1 || !y)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/y is NULL");
+    if (g->prm.noise_model != 0) return gpc_fail(ctx, GPC_EINVAL, "likelihoods are defined for the Gaussian noise model");
+    if (g->P == 0 || n_total == 0 || (!dX && !l)) return GPC_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    SpLikParams A;
+    A.prm = g->prm;
+    A.c_exp = (double)(-0.5f) / g->prm.l_sq;
+    A.P = g->P; A.ny = g->ny; A.ld = g->ld; A.n_total = n_total;
+    A.off = off; A.x0 = x0; A.x1 = x1; A.y = y;
+    A.alpha = g->alpha; A.C = g->C; A.BV = g->BV; A.b = g->b;
+    A.dX = dX; A.l = l;
+    const size_t lds = sp_lik_lds(g->ld);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_likelihood_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int per_cu = (int)((160u * 1024u) / lds);
+    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    int grid = std::min(g->P, ctx->num_cus * per_cu);
+    hipLaunchKernelGGL(sparse_likelihood_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
+    GPC_HIP(ctx, hipGetLastError());
+    return GPC_OK;
+}
+
+int gpc_sparse_likelihood(gpc_sparse* g, const int32_t* off, const double* x0, const double* x1, const double* y,
+                          double* dX, double* l)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    const int P = g->P;
+    if (P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    if (P == 0) return GPC_OK;
+    if (off[0] != 0) return gpc_fail(ctx, GPC_EINVAL, "off[0] must be 0");
+    for (int i = 0; i < P; ++i)
+        if (off[i + 1] < off[i]) return gpc_fail(ctx, GPC_EINVAL, "off must be non-decreasing (patch %d)", i);
+    const size_t N = (size_t)off[P];
+    if (N > 0 && (!x0 || !x1 || !y)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/y is NULL");
+    if (N == 0 || (!dX && !l)) return GPC_OK;
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    void *d_off = nullptr, *d_x0 = nullptr, *d_x1 = nullptr, *d_y = nullptr, *d_dX = nullptr, *d_l = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {d_off, d_x0, d_x1, d_y, d_dX, d_l})
+            if (p) (void)hipFree(p);
+    };
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMalloc(&d_off, 4 * (size_t)(P + 1));
+    if (e == hipSuccess) e = hipMalloc(&d_x0, 8 * N);
+    if (e == hipSuccess) e = hipMalloc(&d_x1, 8 * N);
+    if (e == hipSuccess) e = hipMalloc(&d_y, 8 * N * g->ny);
+    if (e == hipSuccess && dX) e = hipMalloc(&d_dX, 8 * N * 3);
+    if (e == hipSuccess && l) e = hipMalloc(&d_l, 8 * N);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off, 4 * (size_t)(P + 1), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_x0, x0, 8 * N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_x1, x1, 8 * N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_y, y, 8 * N * g->ny, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+        cleanup();
+        return gpc_fail(ctx, e == hipErrorOutOfMemory ? GPC_ENOMEM : GPC_EHIP, "gpc_sparse_likelihood: %s", hipGetErrorString(e));
+    }
+    int rc = gpc_sparse_likelihood_dev(g, (const int32_t*)d_off, (int)N, (const double*)d_x0, (const double*)d_x1,
+                                       (const double*)d_y, (double*)d_dX, (double*)d_l);
+    if (rc == GPC_OK && dX) e = hipMemcpyAsync(dX, d_dX, 8 * N * 3, hipMemcpyDeviceToHost, s);
+    if (rc == GPC_OK && e == hipSuccess && l) e = hipMemcpyAsync(l, d_l, 8 * N, hipMemcpyDeviceToHost, s);
+    hipError_t e2 = hipStreamSynchronize(s);
+    cleanup();
+    if (rc != GPC_OK) return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return gpc_fail(ctx, GPC_EHIP, "gpc_sparse_likelihood: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return GPC_OK;
 }
 

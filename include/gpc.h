@@ -138,6 +138,15 @@ int gpc_sparse_predict(gpc_sparse* g, int m, const double* xs0, const double* xs
                        int conf, int32_t* status);
 int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double* xs1, double* f_star, double* sigma,
                            int conf, int32_t* status);
+/* Registration inner loop: sparse_gp::compute_derivatives + compute_likelihoods
+ * (src/sparse_gp.h:44-45 -> src/sparse_gp.hpp:387-427, 463-508; field: src/sparse_gp_field.h:40-41 -> .hpp:322-392; call site
+ * src/gp_registration.cpp:175-195), batched over patches: patch i evaluates its own rows off[i]..off[i+1]-1 of x0, x1 and
+ * the ny planes of y against its current state.  dX is [N][3], row = point, columns as the reference fills them
+ * (d/dy -- 0 in the field variant --, d/dx0, d/dx1); l is [N].  Either output may be NULL.  Gaussian noise model only. */
+int gpc_sparse_likelihood(gpc_sparse* g, const int32_t* off, const double* x0, const double* x1, const double* y,
+                          double* dX, double* l);
+int gpc_sparse_likelihood_dev(gpc_sparse* g, const int32_t* off, int n_total, const double* x0, const double* x1,
+                              const double* y, double* dX, double* l);
 /* size() of every patch GP (src/sparse_gp.hpp:35-39) -- host pointer */
 int gpc_sparse_sizes(gpc_sparse* g, int32_t* bv_count);
 /* state read-back for tests (host pointers; each may be NULL): alpha [P][ny][cap1], C,Q [P][cap1][cap1] column-major,

@@ -552,6 +552,73 @@ void orc_sparse_predict(const orc_sparse* g, int m, const double* xs0, const dou
     free(k);
 }
 
+/* ---- registration inner loop ("next" row f1 of SURVEY section 8) --------------------------------------------------
+ * sparse_gp::compute_likelihoods -> likelihood (sparse_gp.hpp:387-427), compute_derivatives -> likelihood_dx
+ * (:463-508), kernel derivative rbf_kernel::kernel_dx (rbf_kernel.cpp:33-41); field variants
+ * sparse_gp_field.hpp:322-349 and :353-392.  y holds ny planes of n.  l[n]; dX[n][3] row = point, columns as the
+ * reference fills them (d/dy, d/dx0, d/dx1; the field variant writes 0 into column 0).  Float literals as written. */
+void orc_sparse_likelihood(const orc_sparse* g, int n, const double* x0, const double* x1, const double* y,
+                           double* dX, double* l)
+{
+    const size_t ld = (size_t)g->ld;
+    const orc_sparse_params* P = &g->p;
+    const int b = g->b, ny = P->ny;
+    double* k = (double*)malloc(sizeof(double) * (size_t)(b > 0 ? b : 1));
+    double* v = (double*)malloc(sizeof(double) * (size_t)(b > 0 ? b : 1));
+    for (int p = 0; p < n; ++p) {
+        const double kstar = orc_rbf_kernel(P->p0, P->p1, x0[p], x1[p], x0[p], x1[p]);
+        for (int i = 0; i < b; ++i) k[i] = orc_rbf_kernel(P->p0, P->p1, x0[p], x1[p], g->BV[2 * i], g->BV[2 * i + 1]);
+        /* v = C k;  kCk = k^T C k */
+        double kCk = 0.0;
+        for (int i = 0; i < b; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < b; ++j) s += Cm(i, j) * k[j];
+            v[i] = s;
+            kCk += k[i] * s;
+        }
+        double mu[3] = {0, 0, 0}, off[3], sq = 0.0;
+        for (int c = 0; c < ny; ++c) {
+            for (int i = 0; i < b; ++i) mu[c] += Al(c, i) * k[i];
+            off[c] = y[(size_t)c * n + p] - mu[c];
+            sq += off[c] * off[c];
+        }
+        /* likelihood: b == 0 -> prior around 0 (the same expression, empty sums) */
+        const double sigma = P->s20 + kstar + kCk;
+        if (l) {
+            double norm = (ny == 1) ? (double)2.0f * M_PI * sigma : pow((double)2.0f * M_PI, (double)ny) * sigma;
+            l[p] = (double)1.0f / sqrt(norm) * exp((double)(-0.5f) / sigma * sq);
+        }
+        if (dX) {
+            /* kernel_dx row i: -p0/p1 * (x - BV_i) * exp(-0.5f/p1 |x - BV_i|^2)  (rbf_kernel.cpp:38-40); k_star_dx = 0 */
+            double sdx[2] = {0, 0}, kda[2][3] = {{0, 0, 0}, {0, 0, 0}};
+            for (int i = 0; i < b; ++i) {
+                const double d0 = x0[p] - g->BV[2 * i], d1 = x1[p] - g->BV[2 * i + 1];
+                const double e = exp((double)(-0.5f) / P->p1 * (d0 * d0 + d1 * d1));
+                const double g0 = -P->p0 / P->p1 * d0 * e, g1 = -P->p0 / P->p1 * d1 * e;
+                sdx[0] += g0 * v[i];                   /* k_dx^T (C k) */
+                sdx[1] += g1 * v[i];
+                for (int c = 0; c < ny; ++c) {         /* k_dx^T alpha  (2 x ny) */
+                    kda[0][c] += g0 * Al(c, i);
+                    kda[1][c] += g1 * Al(c, i);
+                }
+            }
+            const double sigma_d = P->s20 + kCk + kstar;      /* likelihood_dx associates differently from likelihood (:485) */
+            const double sqrtsigma = sqrt(sigma_d);
+            const double exppart = (double)0.5f / (sigma_d * sqrtsigma) * exp((double)(-0.5f) / sigma_d * sq);
+            for (int d = 0; d < 2; ++d) {
+                const double sigma_dx = (double)2.0f * sdx[d];
+                double ko = 0.0;
+                for (int c = 0; c < ny; ++c) ko += kda[d][c] * off[c];
+                const double first = -sigma_dx, second = (double)2.0f * ko, third = sigma_dx / sigma_d * sq;
+                dX[(size_t)p * 3 + 1 + d] = exppart * (first + second + third);
+            }
+            dX[(size_t)p * 3] = (ny == 1) ? (double)(-1.0f) / (sigma_d * sqrtsigma) * off[0] * exppart : 0.0;
+        }
+    }
+    free(k);
+    free(v);
+}
+
 void orc_sparse_get_state(const orc_sparse* g, double* alpha, double* C, double* Q, double* BV)
 {
     const size_t ld = (size_t)g->ld;

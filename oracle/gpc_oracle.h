@@ -104,6 +104,9 @@ void orc_sparse_delete_bv(orc_sparse* g, int loc);          /* sparse_gp.hpp:252
 void orc_sparse_predict(const orc_sparse* g, int m, const double* xs0, const double* xs1,
                         double* f_star, double* sigconf, int conf);
 /* state access for tests: alpha (ny planes of b), C, Q (b x b col-major ld=b), BV (2 x b interleaved) */
+/* compute_likelihoods / compute_derivatives (sparse_gp.hpp:387-427, 463-508; field: sparse_gp_field.hpp:322-392) */
+void orc_sparse_likelihood(const orc_sparse* g, int n, const double* x0, const double* x1, const double* y,
+                           double* dX, double* l);
 void orc_sparse_get_state(const orc_sparse* g, double* alpha, double* C, double* Q, double* BV);
 /* statistics: how many full / sparse updates and deletions happened (for BV-count agreement reports) */
 void orc_sparse_get_counters(const orc_sparse* g, int32_t* n_full, int32_t* n_sparse, int32_t* n_deleted);

@@ -116,6 +116,7 @@ def _bind(L):
     L.orc_sparse_add_measurements.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_ip]
     L.orc_sparse_delete_bv.argtypes = [C.c_void_p, C.c_int]
     L.orc_sparse_predict.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_dp, C.c_int]
+    L.orc_sparse_likelihood.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.orc_sparse_get_state.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp]
     L.orc_sparse_get_counters.argtypes = [C.c_void_p, c_ip, c_ip, c_ip]
     L.orc_shuffle_libc.argtypes = [C.c_int, c_ip]
@@ -240,6 +241,17 @@ class Sparse:
         self.L.orc_sparse_predict(self.h, m, _dp(np.ascontiguousarray(xs0)), _dp(np.ascontiguousarray(xs1)),
                                   _dp(f), _dp(s), int(conf))
         return f, s
+
+    def likelihood(self, x0, x1, y):
+        """compute_derivatives + compute_likelihoods on one point set: returns dX (n, 3), l (n)"""
+        y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.float64)
+        assert y.shape[0] == self.ny
+        n = y.shape[1]
+        dX = np.zeros((n, 3))
+        l = np.zeros(n)
+        self.L.orc_sparse_likelihood(self.h, n, _dp(np.ascontiguousarray(x0)), _dp(np.ascontiguousarray(x1)), _dp(y),
+                                     _dp(dX), _dp(l))
+        return dX, l
 
     def state(self):
         b = self.size()

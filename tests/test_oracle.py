@@ -272,6 +272,64 @@ def test_sparse_exact_gp_identity(oracle, seed):
     assert np.max(np.abs(s ** 2 - var)) <= 1e-9
 
 
+@pytest.mark.parametrize("ny", [1, 3])
+def test_sparse_likelihood_and_derivatives(oracle, ny):
+    """Row f1 (registration inner loop): likelihood (sparse_gp.hpp:387-427) and likelihood_dx (:463-508) restated in the
+    oracle, pinned by (i) the same closed forms written with NumPy from the oracle's own state, (ii) what the reference's
+    expression is -- columns 1,2 of dX are the x-gradient of exp(-|off|^2 / (2 sigma)) / sqrt(sigma), checked by finite
+    differences, (iii) b == 0 -> the prior around 0 with no gradient in x."""
+    res, n = 0.15, 40
+    off, x0, x1, y = synth.make_patches(1, n, res=res, seed=70 + ny, ny=ny)
+    p0, p1, s20 = 1.0, (res / 3) ** 2, 1e-2
+    g = oracle.Sparse(oracle.sparse_params(ny, capacity=25, p0=p0, p1=p1, s20=s20, eps_tol=1e-6), 27)
+    g.add_measurements(x0, x1, y)
+    alpha, C, Q, BV = g.state()
+    b = g.size()
+    assert 5 < b <= 25
+    rng = np.random.default_rng(3)
+    q0, q1 = rng.uniform(-res / 2, res / 2, 50), rng.uniform(-res / 2, res / 2, 50)
+    yq = rng.normal(0, 0.01, (ny, 50))
+    dX, l = g.likelihood(q0, q1, yq)
+
+    def closed(q0, q1):
+        Xq = np.stack([q0, q1], 1)
+        K = R.rbf(p0, p1, BV, Xq)                                   # b x m
+        mu = alpha @ K                                              # ny x m
+        kCk = np.sum(K * (C @ K), axis=0)
+        sigma = s20 + p0 + kCk
+        offs = yq - mu
+        sq = np.sum(offs * offs, axis=0)
+        lik = 1.0 / np.sqrt((2 * np.pi) ** ny * sigma) * np.exp(-0.5 / sigma * sq)
+        D = Xq[None, :, :] - BV[:, None, :]                         # b x m x 2
+        Kdx = -(p0 / p1) * D * np.exp(-0.5 / p1 * np.sum(D * D, axis=2))[:, :, None]
+        sdx = 2.0 * np.einsum("imd,im->md", Kdx, C @ K)
+        exppart = 0.5 / sigma ** 1.5 * np.exp(-0.5 / sigma * sq)
+        second = 2.0 * np.einsum("imd,ci,cm->md", Kdx, alpha, offs)
+        d12 = exppart[:, None] * (-sdx + second + sdx / sigma[:, None] * sq[:, None])
+        d0 = -1.0 / sigma ** 1.5 * offs[0] * exppart if ny == 1 else np.zeros_like(sigma)
+        return lik, np.concatenate([d0[:, None], d12], axis=1), sigma, sq
+
+    lik, dref, sigma, sq = closed(q0, q1)
+    # k^T C k cancels against k** (sigma ~ s20 << |C| |k|^2): summation order shows at 1e-11
+    assert np.max(np.abs(l - lik)) <= 1e-9 * np.max(np.abs(lik))
+    assert np.max(np.abs(dX - dref)) <= 1e-8 * np.max(np.abs(dref))
+    # what the formula is: exppart (-sigma_dx + 2 k_dx^T alpha off + sigma_dx/sigma off^2) = d/dx [ exp(-sq/(2 sigma)) / sqrt(sigma) ]
+    h = 1e-6
+    def gfun(a0, a1):
+        _, _, sg, s2 = closed(a0, a1)
+        return np.exp(-0.5 / sg * s2) / np.sqrt(sg)
+    fd0 = (gfun(q0 + h, q1) - gfun(q0 - h, q1)) / (2 * h)
+    fd1 = (gfun(q0, q1 + h) - gfun(q0, q1 - h)) / (2 * h)
+    scale = np.max(np.abs(dX[:, 1:]))
+    assert np.max(np.abs(dX[:, 1] - fd0)) <= 1e-5 * scale and np.max(np.abs(dX[:, 2] - fd1)) <= 1e-5 * scale
+    # b == 0: prior around 0, no gradient in x
+    g0 = oracle.Sparse(oracle.sparse_params(ny, p0=p0, p1=p1, s20=s20), 4)
+    dX0, l0 = g0.likelihood(q0[:3], q1[:3], yq[:, :3])
+    sq0 = np.sum(yq[:, :3] ** 2, axis=0)
+    assert np.allclose(l0, 1.0 / np.sqrt((2 * np.pi) ** ny * (p0 + s20)) * np.exp(-0.5 / (p0 + s20) * sq0), rtol=1e-14)
+    assert np.all(dX0[:, 1:] == 0.0)
+
+
 def test_sparse_delete_invariants(oracle):
     """After any delete: C = C^T, Q = Q^T, Q*K_BV = I, BV swap-with-last order (src/sparse_gp.hpp:252-295)."""
     res, n = 0.15, 10

@@ -178,3 +178,86 @@ def test_sparse_defaults_regime_batch(gp, oracle):
     rms = lambda a: float(np.sqrt(np.mean(a * a)))
     assert rms(f - fo) <= 2e-2 * max(rms(fo), 1e-6)
     g.close()
+
+
+def _closed_form_likelihood(p0, p1, s20, alpha, Cm, BV, q0, q1, yq):
+    """likelihood / likelihood_dx (src/sparse_gp.hpp:387-427, 463-508; field .hpp:322-392) written with NumPy on a given state"""
+    ny = alpha.shape[0]
+    Xq = np.stack([q0, q1], 1)
+    D = Xq[None, :, :] - BV[:, None, :]
+    K = p0 * np.exp(-0.5 / p1 * np.sum(D * D, axis=2))
+    mu = alpha @ K
+    CK = Cm @ K
+    sigma = s20 + p0 + np.sum(K * CK, axis=0)
+    offs = yq - mu
+    sq = np.sum(offs * offs, axis=0)
+    lik = 1.0 / np.sqrt((2 * np.pi) ** ny * sigma) * np.exp(-0.5 / sigma * sq)
+    Kdx = -(1.0 / p1) * D * K[:, :, None]
+    sdx = 2.0 * np.einsum("imd,im->md", Kdx, CK)
+    exppart = 0.5 / sigma ** 1.5 * np.exp(-0.5 / sigma * sq)
+    second = 2.0 * np.einsum("imd,ci,cm->md", Kdx, alpha, offs)
+    d12 = exppart[:, None] * (-sdx + second + sdx / sigma[:, None] * sq[:, None])
+    d0 = -1.0 / sigma ** 1.5 * offs[0] * exppart if ny == 1 else np.zeros_like(sigma)
+    return np.concatenate([d0[:, None], d12], axis=1), lik
+
+
+@pytest.mark.parametrize("ny,cap", [(1, 24), (3, 12)])
+def test_sparse_likelihood_and_derivatives(gp, oracle, ny, cap):
+    """gpc_sparse_likelihood = compute_derivatives + compute_likelihoods, batched and ragged.
+    (i) against the closed form evaluated on the GPU's OWN state: 1e-8 (isolates this kernel from the 1e-6-level
+    differences two fp64 implementations of the training recursion show, see the module docstring);
+    (ii) against the oracle end to end: the loose tolerance of the state;  (iii) empty patches, empty point sets."""
+    capi, ctx = gp
+    res = 0.15
+    P, n = 9, 90
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=60 + cap, ragged=True, ny=ny)
+    perm = synth.sattolo_perms(off, seed=6)
+    kw = dict(sigmaf_sq=1.0, l_sq=(res / 5) ** 2, noise=1e-3 if ny == 1 else 1.0, capacity=cap)
+    p = capi.default_params_sparse(ny, **kw)
+    g = capi.Sparse(ctx, p, P, ny)
+    # patch 3 stays untrained (b = 0): feed it an empty point set
+    off_t = off.copy()
+    n3 = off[4] - off[3]
+    off_t[4:] -= n3
+    keep = np.r_[0:off[3], off[4]:off[-1]]
+    st = g.add(off_t, x0[keep], x1[keep], y[:, keep], perm[keep])
+    assert np.all(st == 0) and g.sizes()[3] == 0
+    # query sets: ragged, patch 5 empty
+    rng = np.random.default_rng(9)
+    cnt = rng.integers(1, 70, P)
+    cnt[5] = 0
+    qoff = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    N = int(qoff[-1])
+    q0, q1 = rng.uniform(-res / 2, res / 2, N), rng.uniform(-res / 2, res / 2, N)
+    yq = rng.normal(0, 0.02 if ny == 1 else 30.0, (ny, N))
+    dX, l = g.likelihood(qoff, q0, q1, yq)
+    assert np.all(np.isfinite(dX)) and np.all(np.isfinite(l))
+    alpha, Cm, Q, BV = g.state()
+    sizes = g.sizes()
+    for i in range(P):
+        sl = slice(qoff[i], qoff[i + 1])
+        if sl.stop == sl.start:
+            continue
+        b = int(sizes[i])
+        dref, lref = _closed_form_likelihood(kw["sigmaf_sq"], kw["l_sq"], kw["noise"], alpha[i][:, :b], Cm[i][:b, :b], BV[i][:b],
+                                             q0[sl], q1[sl], yq[:, sl])
+        # sigma = s20 + k** + k^T C k cancels to ~s20 (1e-3 of its terms) and dX goes like sigma^-3
+        assert np.max(np.abs(l[sl] - lref)) <= 1e-8 * np.max(np.abs(lref)), i
+        assert np.max(np.abs(dX[sl] - dref)) <= 1e-8 * max(np.max(np.abs(dref)), 1e-300), i
+        if b == 0:
+            assert np.all(dX[sl, 1:] == 0.0)
+    # end to end against the oracle (same insertion order)
+    op = oracle.sparse_params(ny, p0=kw["sigmaf_sq"], p1=kw["l_sq"], s20=kw["noise"], capacity=cap)
+    for i in (0, 3, 7):
+        go = oracle.Sparse(op, cap + 2)
+        a, b_ = off_t[i], off_t[i + 1]
+        if b_ > a:
+            go.add_measurements(x0[keep][a:b_], x1[keep][a:b_], y[:, keep][:, a:b_], perm[keep][a:b_])
+        sl = slice(qoff[i], qoff[i + 1])
+        do, lo = go.likelihood(q0[sl], q1[sl], yq[:, sl])
+        assert np.max(np.abs(l[sl] - lo)) <= 1e-4 * np.max(np.abs(lo))
+        assert np.max(np.abs(dX[sl] - do)) <= 1e-4 * np.max(np.abs(do))
+    # only one of the outputs
+    d2, none = g.likelihood(qoff, q0, q1, yq, want_l=False)
+    assert none is None and np.array_equal(d2, dX)
+    g.close()

@@ -43,6 +43,23 @@ g.predict_dev(sz * sz, d_xs0, d_xs1, f)
 torch.cuda.synchronize()
 t_pred = time.perf_counter() - t0
 b = g.sizes()
+# row f1: registration inner loop on the trained state -- likelihoods + derivatives at 256 points per patch
+doff = t(off.astype(np.int32))
+d_q0, d_q1, d_yq = t(x0), t(x1), t(np.ascontiguousarray(y))
+dX = torch.empty((P * n, 3), dtype=torch.float64, device=dev)
+lik = torch.empty((P * n,), dtype=torch.float64, device=dev)
+g.likelihood_dev(doff, P * n, d_q0, d_q1, d_yq, dX, lik)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+g.likelihood_dev(doff, P * n, d_q0, d_q1, d_yq, dX, lik)
+torch.cuda.synchronize()
+t_lik = time.perf_counter() - t0
+bm = float(b.mean())
+lik_flops = P * n * (2.0 * bm * bm + 30.0 * bm)
+lik_bytes = P * (n / 32.0) * 8.0 * bm * bm          # C streamed once per 32-point chunk
 print(json.dumps({"workload": f"C4-shape: {P} patches x {n} pts in {chunks} chunks, capacity {cap}", "add_s": t_add, "predict_s": t_pred,
                   "patches_per_s": P / (t_add + t_pred), "bv_mean": float(b.mean()), "bv_max": int(b.max()),
-                  "finite": bool(torch.isfinite(f).all().item())}))
+                  "finite": bool(torch.isfinite(f).all().item()),
+                  "likelihood": {"s": t_lik, "points_per_s": P * n / t_lik, "gflops": lik_flops / t_lik / 1e9,
+                                 "c_stream_GBps": lik_bytes / t_lik / 1e9, "nonfinite_frac": float((~torch.isfinite(dX).all(dim=1)).double().mean().item()),
+                                 "note": "non-finite rows = sigma <= 0 after cancellation; the reference's likelihood_dx does not clamp either"}}))
