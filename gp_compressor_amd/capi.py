@@ -64,6 +64,9 @@ PROTOTYPES = {
     "gpc_sparse_sizes": (C.c_int, [_vp, _vp]),
     "gpc_sparse_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_ld": (C.c_int, [_vp]),
+    "gpc_sparse_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "gpc_reproject": (C.c_int, [_vp, _i, _i] + [_vp] * 10),
+    "gpc_reproject_dev": (C.c_int, [_vp, _i, _i] + [_vp] * 10),
     "gpc_partition_patches": (C.c_int, [_i, _vp, _i, _i, _vp]),
     "gpc_test_exp_host": (None, [_vp, _vp, _i]),
     "gpc_test_exp_small_host": (None, [_vp, _vp, _i]),
@@ -195,6 +198,31 @@ class Context:
                                                         ny, float(res), int(sz), _ptr(f), _ptr(al), _ptr(st)))
         return (f, st, al) if want_alpha else (f, st)
 
+    # ---- reprojection + colour clamp (row f3): predicted grids -> pcl::PointXYZRGB records ------------------------------
+    POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"),
+                            ("a", "u1"), ("pad", "<f4", (3,))])
+
+    def reproject(self, xs0, xs1, f_star, rotations, means, c_star=None, rgb_means=None, bv_count=None):
+        """gpc_reproject: f_star (P, m) [+ c_star (P, 3, m)] -> structured array of 32-byte points, compacted over trained patches"""
+        f_star = np.ascontiguousarray(f_star, dtype=np.float64)
+        P, m = f_star.shape
+        xs0 = np.ascontiguousarray(xs0, dtype=np.float64)
+        xs1 = np.ascontiguousarray(xs1, dtype=np.float64)
+        R = np.ascontiguousarray(rotations, dtype=np.float64).reshape(P, 9)
+        mu = np.ascontiguousarray(means, dtype=np.float64).reshape(P, 3)
+        cs = None if c_star is None else np.ascontiguousarray(c_star, dtype=np.float64).reshape(P, 3, m)
+        cm = None if rgb_means is None else np.ascontiguousarray(rgb_means, dtype=np.float64).reshape(P, 3)
+        bv = None if bv_count is None else np.ascontiguousarray(bv_count, dtype=np.int32)
+        cloud = np.zeros(max(P * m, 1), dtype=self.POINT_DTYPE)
+        npts = np.zeros(1, dtype=np.int32)
+        self._check(self.lib.gpc_reproject(self.h, P, m, _ptr(bv), _ptr(xs0), _ptr(xs1), _ptr(f_star), _ptr(cs), _ptr(R), _ptr(mu),
+                                           _ptr(cm), _ptr(cloud), _ptr(npts)))
+        return cloud[:int(npts[0])]
+
+    def reproject_dev(self, P, m, bv_count, xs0, xs1, f_star, c_star, rotations, means, rgb_means, cloud, n_points):
+        self._check(self.lib.gpc_reproject_dev(self.h, P, m, _ptr(bv_count), _ptr(xs0), _ptr(xs1), _ptr(f_star), _ptr(c_star),
+                                               _ptr(rotations), _ptr(means), _ptr(rgb_means), _ptr(cloud), _ptr(n_points)))
+
     # ---- dense, device buffers (torch tensors or raw addresses), asynchronous on the context's stream ---------
     def dense_fit_predict_dev(self, params, P, off, n_max, n_total, x0, x1, y, ny, m, xs0, xs1, f_star,
                               v_star=None, alpha_out=None, status=None):
@@ -292,6 +320,20 @@ class Sparse:
         self.ctx._check(self.lib.gpc_sparse_get_state(self.h, _ptr(alpha), _ptr(Cc), _ptr(Q), _ptr(BV)))
         # C, Q are column-major per patch: [p][j][i] = M(i, j)
         return alpha, np.transpose(Cc, (0, 2, 1)).copy(), np.transpose(Q, (0, 2, 1)).copy(), BV
+
+
+def _sparse_set_state(self, bv_count, alpha, BV, C_=None, Q=None):
+    """gpc_sparse_set_state: alpha (P, ny, ld), BV (P, ld, 2), optional C/Q (P, ld, ld) as returned by state() (row-major views)"""
+    ld = self.ld()
+    bv = np.ascontiguousarray(bv_count, dtype=np.int32)
+    al = np.ascontiguousarray(alpha, dtype=np.float64).reshape(self.P, self.ny, ld)
+    bvv = np.ascontiguousarray(BV, dtype=np.float64).reshape(self.P, ld, 2)
+    cc = None if C_ is None else np.ascontiguousarray(np.transpose(C_, (0, 2, 1)))
+    qq = None if Q is None else np.ascontiguousarray(np.transpose(Q, (0, 2, 1)))
+    self.ctx._check(self.lib.gpc_sparse_set_state(self.h, _ptr(bv), _ptr(al), _ptr(cc), _ptr(qq), _ptr(bvv)))
+
+
+Sparse.set_state = _sparse_set_state
 
 
 def partition_patches(off, world, sparse_capacity=0):

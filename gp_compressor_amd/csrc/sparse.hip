@@ -902,4 +902,33 @@ int gpc_sparse_get_state(gpc_sparse* g, double* alpha, double* C, double* Q, dou
     return GPC_OK;
 }
 
+// Inverse of gpc_sparse_get_state: loads a stored model (the compressed representation of row f3).  alpha and BV are
+// required, C and Q may be NULL (zeroed: the mean prediction of the decompressor needs neither; sigma, likelihoods and
+// further online growth do).
+int gpc_sparse_set_state(gpc_sparse* g, const int32_t* bv_count, const double* alpha, const double* C, const double* Q,
+                         const double* BV)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    if (g->P == 0) return GPC_OK;
+    if (!bv_count || !alpha || !BV) return gpc_fail(ctx, GPC_EINVAL, "bv_count/alpha/BV is NULL");
+    for (int i = 0; i < g->P; ++i)
+        if (bv_count[i] < 0 || bv_count[i] > g->ld) return gpc_fail(ctx, GPC_ERANGE, "bv_count[%d] = %d outside [0, %d]", i, bv_count[i], g->ld);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ld = (size_t)g->ld, P = (size_t)g->P;
+    hipStream_t s = ctx->stream;
+    GPC_HIP(ctx, hipMemcpyAsync(g->b, bv_count, 4 * P, hipMemcpyHostToDevice, s));
+    GPC_HIP(ctx, hipMemcpyAsync(g->count, bv_count, 4 * P, hipMemcpyHostToDevice, s));
+    GPC_HIP(ctx, hipMemsetAsync(g->stat, 0, 4 * P, s));
+    GPC_HIP(ctx, hipMemcpyAsync(g->alpha, alpha, 8 * P * g->ny * ld, hipMemcpyHostToDevice, s));
+    GPC_HIP(ctx, hipMemcpyAsync(g->BV, BV, 8 * P * ld * 2, hipMemcpyHostToDevice, s));
+    if (C) GPC_HIP(ctx, hipMemcpyAsync(g->C, C, 8 * P * ld * ld, hipMemcpyHostToDevice, s));
+    else GPC_HIP(ctx, hipMemsetAsync(g->C, 0, 8 * P * ld * ld, s));
+    if (Q) GPC_HIP(ctx, hipMemcpyAsync(g->Q, Q, 8 * P * ld * ld, hipMemcpyHostToDevice, s));
+    else GPC_HIP(ctx, hipMemsetAsync(g->Q, 0, 8 * P * ld * ld, s));
+    GPC_HIP(ctx, hipStreamSynchronize(s));
+    return GPC_OK;
+}
+
 }  // extern "C"

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -375,25 +376,130 @@ pointcloud gp_compressor::load_compressed()
         check(gpc_sparse_predict(gps_, m, xs0.data(), xs1.data(), f_star.data(), nullptr, 0, nullptr), ctx_, "gpc_sparse_predict(depth)");
         check(gpc_sparse_predict(rgb_gps_, m, xs0.data(), xs1.data(), c_star.data(), nullptr, 0, nullptr), ctx_, "gpc_sparse_predict(rgb)");
     }
-    out.reserve((size_t)P * m);
+    // reprojection + colour clamp (:335-373) fused on the GPU: the predicted grids become pcl::PointXYZRGB records
+    std::vector<double> R((size_t)P * 9), mu((size_t)P * 3), cm((size_t)P * 3);
     for (int i = 0; i < P; ++i) {
-        if (bv[i] == 0) continue;                     // gps[i].size() == 0 (:299-301)
-        const auto& R = batch_.rotations[i];
-        const auto& mean = batch_.means[i];
-        for (int q = 0; q < m; ++q) {
-            const double pt[3] = {f_star[(size_t)i * m + q], xs0[q], xs1[q]};          // :336-338
-            point p;
-            float* xyz[3] = {&p.x, &p.y, &p.z};
-            for (int a = 0; a < 3; ++a) *xyz[a] = (float)(R[a] * pt[0] + R[3 + a] * pt[1] + R[6 + a] * pt[2] + mean[a]);   // :339
-            double c[3];
-            for (int a = 0; a < 3; ++a) c[a] = c_star[((size_t)i * 3 + a) * m + q] + batch_.rgb_means[i][a];           // :367
-            uint8_t rgb[3];
-            flatten_colors(rgb, c);
-            p.r = rgb[0]; p.g = rgb[1]; p.b = rgb[2];
-            out.push_back(p);
+        std::memcpy(&R[(size_t)i * 9], batch_.rotations[i].data(), 9 * sizeof(double));
+        std::memcpy(&mu[(size_t)i * 3], batch_.means[i].data(), 3 * sizeof(double));
+        std::memcpy(&cm[(size_t)i * 3], batch_.rgb_means[i].data(), 3 * sizeof(double));
+    }
+    std::vector<gpc_point_xyzrgb> recs((size_t)P * m);
+    int32_t npts = 0;
+    check(gpc_reproject(ctx_, P, m, bv.data(), xs0.data(), xs1.data(), f_star.data(), c_star.data(), R.data(), mu.data(), cm.data(),
+                        recs.data(), &npts), ctx_, "gpc_reproject");
+    out.resize((size_t)npts);
+    for (int q = 0; q < npts; ++q) out[q] = point{recs[q].x, recs[q].y, recs[q].z, recs[q].r, recs[q].g, recs[q].b};
+    return out;
+}
+
+// ---- model file (row f3) ---------------------------------------------------------------------------------------------
+// little-endian; header: "GPCM", u32 version = 1, f64 res, i32 sz, i32 P, gpc_params depth, gpc_params rgb (raw structs, with their
+// size in front); per patch: f64 R[9], mean[3], rgb_mean[3]; i32 b_depth, b_rgb; f64 BV_depth[b][2], alpha_depth[b],
+// BV_rgb[b'][2], alpha_rgb[3][b'].
+namespace {
+struct file_closer { void operator()(FILE* f) const { if (f) std::fclose(f); } };
+template <class T> void wr(FILE* f, const T* p, size_t n) { if (n && std::fwrite(p, sizeof(T), n, f) != n) throw std::runtime_error("model file: write failed"); }
+template <class T> void rd(FILE* f, T* p, size_t n) { if (n && std::fread(p, sizeof(T), n, f) != n) throw std::runtime_error("model file: truncated"); }
+}  // namespace
+
+gp_compressor::gp_compressor(double res, int sz, int device)
+    : rng([] { return std::rand(); }), res_(res), sz_(sz), model_(gp_model::sparse), device_(device)
+{
+    gpc_default_params_sparse(&depth_params, 1);
+    gpc_default_params_sparse(&rgb_params, 3);
+    gpc_default_params_dense(&dense_params);
+}
+
+size_t gp_compressor::save_model(const std::string& path)
+{
+    if (model_ != gp_model::sparse) throw std::runtime_error("save_model: the sparse model only");
+    if (!trained_) { project_cloud(); train_processes(); }
+    const int P = batch_.patches();
+    std::unique_ptr<FILE, file_closer> f(std::fopen(path.c_str(), "wb"));
+    if (!f) throw std::runtime_error("save_model: cannot open " + path);
+    const uint32_t version = 1, psz = (uint32_t)sizeof(gpc_params);
+    wr(f.get(), "GPCM", 4);
+    wr(f.get(), &version, 1);
+    wr(f.get(), &res_, 1);
+    const int32_t hdr[2] = {sz_, P};
+    wr(f.get(), hdr, 2);
+    wr(f.get(), &psz, 1);
+    wr(f.get(), &depth_params, 1);
+    wr(f.get(), &rgb_params, 1);
+    if (P > 0) {
+        const int ldd = gpc_sparse_ld(gps_), ldc = gpc_sparse_ld(rgb_gps_);
+        std::vector<int32_t> bd(P), bc(P);
+        check(gpc_sparse_sizes(gps_, bd.data()), ctx_, "gpc_sparse_sizes");
+        check(gpc_sparse_sizes(rgb_gps_, bc.data()), ctx_, "gpc_sparse_sizes");
+        std::vector<double> ad((size_t)P * ldd), bvd((size_t)P * ldd * 2), ac((size_t)P * 3 * ldc), bvc((size_t)P * ldc * 2);
+        check(gpc_sparse_get_state(gps_, ad.data(), nullptr, nullptr, bvd.data()), ctx_, "gpc_sparse_get_state");
+        check(gpc_sparse_get_state(rgb_gps_, ac.data(), nullptr, nullptr, bvc.data()), ctx_, "gpc_sparse_get_state");
+        for (int i = 0; i < P; ++i) {
+            wr(f.get(), batch_.rotations[i].data(), 9);
+            wr(f.get(), batch_.means[i].data(), 3);
+            wr(f.get(), batch_.rgb_means[i].data(), 3);
+            const int32_t b2[2] = {bd[i], bc[i]};
+            wr(f.get(), b2, 2);
+            wr(f.get(), &bvd[(size_t)i * ldd * 2], (size_t)2 * bd[i]);
+            wr(f.get(), &ad[(size_t)i * ldd], (size_t)bd[i]);
+            wr(f.get(), &bvc[(size_t)i * ldc * 2], (size_t)2 * bc[i]);
+            for (int c = 0; c < 3; ++c) wr(f.get(), &ac[((size_t)i * 3 + c) * ldc], (size_t)bc[i]);
         }
     }
-    return out;
+    const long pos = std::ftell(f.get());
+    return pos < 0 ? 0 : (size_t)pos;
+}
+
+gp_compressor* gp_compressor::load_model(const std::string& path, int device)
+{
+    std::unique_ptr<FILE, file_closer> f(std::fopen(path.c_str(), "rb"));
+    if (!f) throw std::runtime_error("load_model: cannot open " + path);
+    char magic[4];
+    uint32_t version = 0, psz = 0;
+    double res = 0;
+    int32_t hdr[2] = {0, 0};
+    rd(f.get(), magic, 4);
+    rd(f.get(), &version, 1);
+    if (std::memcmp(magic, "GPCM", 4) != 0 || version != 1) throw std::runtime_error("load_model: not a GPCM v1 file");
+    rd(f.get(), &res, 1);
+    rd(f.get(), hdr, 2);
+    rd(f.get(), &psz, 1);
+    if (psz != sizeof(gpc_params) || hdr[0] <= 0 || hdr[1] < 0) throw std::runtime_error("load_model: bad header");
+    std::unique_ptr<gp_compressor> g(new gp_compressor(res, hdr[0], device));
+    rd(f.get(), &g->depth_params, 1);
+    rd(f.get(), &g->rgb_params, 1);
+    const int P = hdr[1];
+    g->batch_.off.assign((size_t)P + 1, 0);
+    g->batch_.rotations.resize(P);
+    g->batch_.means.resize(P);
+    g->batch_.rgb_means.resize(P);
+    g->projected_ = true;
+    if (P > 0) {
+        check(gpc_ctx_create(&g->ctx_, device), nullptr, "gpc_ctx_create");
+        check(gpc_sparse_create(g->ctx_, &g->depth_params, P, 1, &g->gps_), g->ctx_, "gpc_sparse_create(depth)");
+        check(gpc_sparse_create(g->ctx_, &g->rgb_params, P, 3, &g->rgb_gps_), g->ctx_, "gpc_sparse_create(rgb)");
+        const int ldd = gpc_sparse_ld(g->gps_), ldc = gpc_sparse_ld(g->rgb_gps_);
+        std::vector<int32_t> bd(P), bc(P);
+        std::vector<double> ad((size_t)P * ldd, 0.0), bvd((size_t)P * ldd * 2, 0.0), ac((size_t)P * 3 * ldc, 0.0), bvc((size_t)P * ldc * 2, 0.0);
+        for (int i = 0; i < P; ++i) {
+            rd(f.get(), g->batch_.rotations[i].data(), 9);
+            rd(f.get(), g->batch_.means[i].data(), 3);
+            rd(f.get(), g->batch_.rgb_means[i].data(), 3);
+            int32_t b2[2];
+            rd(f.get(), b2, 2);
+            if (b2[0] < 0 || b2[0] > ldd || b2[1] < 0 || b2[1] > ldc) throw std::runtime_error("load_model: basis-vector count out of range");
+            bd[i] = b2[0];
+            bc[i] = b2[1];
+            rd(f.get(), &bvd[(size_t)i * ldd * 2], (size_t)2 * bd[i]);
+            rd(f.get(), &ad[(size_t)i * ldd], (size_t)bd[i]);
+            rd(f.get(), &bvc[(size_t)i * ldc * 2], (size_t)2 * bc[i]);
+            for (int c = 0; c < 3; ++c) rd(f.get(), &ac[((size_t)i * 3 + c) * ldc], (size_t)bc[i]);
+        }
+        check(gpc_sparse_set_state(g->gps_, bd.data(), ad.data(), nullptr, nullptr, bvd.data()), g->ctx_, "gpc_sparse_set_state(depth)");
+        check(gpc_sparse_set_state(g->rgb_gps_, bc.data(), ac.data(), nullptr, nullptr, bvc.data()), g->ctx_, "gpc_sparse_set_state(rgb)");
+    }
+    g->trained_ = true;
+    return g.release();
 }
 
 }  // namespace gpc
@@ -466,6 +572,33 @@ int gpc_host_roundtrip(void* h, float* out_xyz, uint8_t* out_rgb, int capacity_p
         }
         if (mean_added) *mean_added = g->mean_added();
         if (max_added) *max_added = g->max_added();
+        return (int)c.size();
+    } catch (const std::exception& e) {
+        if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+        return -1;
+    }
+}
+
+// model file: write the trained sparse model / reconstruct a cloud from a file alone.  Return bytes / point count, < 0 on error.
+long long gpc_host_save_model(void* h, const char* path, char* err, int errlen)
+{
+    try {
+        return (long long)static_cast<gpc::gp_compressor*>(h)->save_model(path);
+    } catch (const std::exception& e) {
+        if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+        return -1;
+    }
+}
+int gpc_host_decompress_file(const char* path, int device, float* out_xyz, uint8_t* out_rgb, int capacity_pts, char* err, int errlen)
+{
+    try {
+        std::unique_ptr<gpc::gp_compressor> g(gpc::gp_compressor::load_model(path, device));
+        gpc::pointcloud c = g->load_compressed();
+        if ((int)c.size() > capacity_pts) return -2;
+        for (size_t i = 0; i < c.size(); ++i) {
+            out_xyz[3 * i] = c[i].x; out_xyz[3 * i + 1] = c[i].y; out_xyz[3 * i + 2] = c[i].z;
+            out_rgb[3 * i] = c[i].r; out_rgb[3 * i + 1] = c[i].g; out_rgb[3 * i + 2] = c[i].b;
+        }
         return (int)c.size();
     } catch (const std::exception& e) {
         if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }

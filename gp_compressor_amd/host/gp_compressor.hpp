@@ -73,6 +73,13 @@ public:
     void save_compressed(const std::string& name);   // src/gp_compressor.cpp:21-27 (name unused upstream as well)
     pointcloud load_compressed();                    // src/gp_compressor.cpp:267-386
 
+    // The wire format the reference never wrote (save_compressed ignores `name`): per patch the
+    // frame (R_i, mean_i, RGB mean) and the two sparse GPs as (BV, alpha) -- all the decompressor's mean prediction needs.
+    // C and Q are not stored: a loaded model reconstructs the same cloud bit for bit, but cannot be trained further.
+    // Sparse model only.  Returns the number of bytes written.
+    size_t save_model(const std::string& path);
+    static gp_compressor* load_model(const std::string& path, int device = 0);
+
     // host-only part, usable without a GPU
     void project_cloud();                            // src/gp_compressor.cpp:177-249
     const patch_batch& patches() const { return batch_; }
@@ -90,6 +97,7 @@ protected:
     static void flatten_colors(uint8_t out[3], const double c[3]);                      // :251-265
     void shuffle(std::vector<int32_t>& perm, int n);
 
+    gp_compressor(double res, int sz, int device);   // empty shell for load_model
     pointcloud cloud_;
     double res_;
     int sz_;

@@ -38,6 +38,9 @@ def load():
         L.gpc_host_point_count.argtypes = [vp]
         L.gpc_host_get_batch.argtypes = [vp] * 9
         L.gpc_host_roundtrip.argtypes = [vp, vp, vp, i, vp, vp, vp, i]
+        L.gpc_host_save_model.restype = C.c_longlong
+        L.gpc_host_save_model.argtypes = [vp, C.c_char_p, vp, i]
+        L.gpc_host_decompress_file.argtypes = [C.c_char_p, i, vp, vp, i, vp, i]
         _lib = L
     return _lib
 
@@ -88,6 +91,27 @@ class GpCompressor:
         if n < 0:
             raise RuntimeError(f"gp_compressor round trip failed ({n}): {err.value.decode()}")
         return oxyz[:n], orgb[:n], mean_added.value, max_added.value
+
+
+    def save_model(self, path):
+        """write the trained sparse model (frames + (BV, alpha) per patch); returns the file size in bytes"""
+        err = C.create_string_buffer(512)
+        n = self.L.gpc_host_save_model(self.h, os.fsencode(path), C.addressof(err), 512)
+        if n < 0:
+            raise RuntimeError(f"save_model failed: {err.value.decode()}")
+        return int(n)
+
+
+def decompress_file(path, capacity_pts, device=0):
+    """reconstruct the cloud from a model file alone: returns (xyz float32 (M,3), rgb uint8 (M,3))"""
+    L = load()
+    oxyz = np.zeros((max(capacity_pts, 1), 3), dtype=np.float32)
+    orgb = np.zeros((max(capacity_pts, 1), 3), dtype=np.uint8)
+    err = C.create_string_buffer(512)
+    n = L.gpc_host_decompress_file(os.fsencode(path), device, oxyz.ctypes.data, orgb.ctypes.data, capacity_pts, C.addressof(err), 512)
+    if n < 0:
+        raise RuntimeError(f"decompress_file failed ({n}): {err.value.decode()}")
+    return oxyz[:n], orgb[:n]
 
 
 def synthetic_plane_cloud(n=10000, seed=1, extent=1.2):

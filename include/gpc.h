@@ -153,6 +153,29 @@ int gpc_sparse_sizes(gpc_sparse* g, int32_t* bv_count);
  * BV [P][cap1][2], with cap1 = gpc_sparse_ld(g) */
 int gpc_sparse_get_state(gpc_sparse* g, double* alpha, double* C, double* Q, double* BV);
 int gpc_sparse_ld(const gpc_sparse* g);
+/* inverse of gpc_sparse_get_state, for loading a stored model (row f3; the reference's save_compressed writes nothing,
+ * src/gp_compressor.cpp:21-27): same layouts, host pointers; C and Q may be NULL (zeroed -- enough for the mean prediction) */
+int gpc_sparse_set_state(gpc_sparse* g, const int32_t* bv_count, const double* alpha, const double* C, const double* Q,
+                         const double* BV);
+
+/* ---- the step after the path: reprojection + colour clamp, fused ------------------------ */
+/* The tail of the patch loop of gp_compressor::load_compressed (src/gp_compressor.cpp:335-373, flatten_colors :251-265):
+ * pt = R_i (f*, x*_0, x*_1) + mean_i as float, rgb = clamp(short(C* + RGB_mean_i)), written as pcl::PointXYZRGB records.
+ * Patches with bv_count[i] == 0 are skipped and the output is compacted in patch order (the reference's `counter`,
+ * :299-301); bv_count == NULL means every patch is trained.  f_star [P][m]; c_star [P][3][m] or NULL (colours 0);
+ * rotations [P][9] column-major (columns = normal, u, v); means, rgb_means [P][3].  cloud must hold P*m records;
+ * n_points receives the number written (device pointer in the _dev variant).  Bit-identical to the CPU oracle. */
+typedef struct gpc_point_xyzrgb {   /* memory layout of pcl::PointXYZRGB: 32 bytes */
+    float x, y, z, w;               /* w = 1.0f (PCL_ADD_POINT4D) */
+    uint8_t b, g, r, a;             /* PCL_ADD_RGB; a = 255 */
+    float pad[3];
+} gpc_point_xyzrgb;
+int gpc_reproject(gpc_ctx* ctx, int P, int m, const int32_t* bv_count, const double* xs0, const double* xs1, const double* f_star,
+                  const double* c_star, const double* rotations, const double* means, const double* rgb_means,
+                  gpc_point_xyzrgb* cloud, int32_t* n_points);
+int gpc_reproject_dev(gpc_ctx* ctx, int P, int m, const int32_t* bv_count, const double* xs0, const double* xs1,
+                      const double* f_star, const double* c_star, const double* rotations, const double* means,
+                      const double* rgb_means, gpc_point_xyzrgb* cloud, int32_t* n_points);
 
 /* ---- patch -> rank partition for one process per GPU (src/gp_compressor.cpp:146-163: patches are independent) ----- */
 /* Longest-processing-time assignment of P patches with per-patch cost n_i^3 (dense) or n_i*cap^2 (sparse) onto

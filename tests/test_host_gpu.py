@@ -41,3 +41,29 @@ def test_compress_roundtrip_c1(H, model):
         assert 1 <= mean_added <= 40 and max_added <= 40     # "Mean added" / "Max added" (src/gp_compressor.cpp:173-174)
     else:
         assert max_added <= 400
+
+
+def test_model_file_roundtrip_c1(H, tmp_path):
+    """Row f3, the wire format the reference never wrote: save_model -> load_model -> load_compressed reconstructs the
+    SAME cloud bit for bit from the file alone (frames + (BV, alpha) per patch), and the file is smaller than the cloud."""
+    res, sz = 0.15, 20
+    xyz, rgb = H.synthetic_plane_cloud(10000, seed=1)
+    g = H.GpCompressor(xyz, rgb, res=res, sz=sz, model="sparse", seed=7)
+    g.set_sparse_kernel(1.0, (res / 2) ** 2, 1e-2, 25.0, 40)
+    oxyz, orgb, mean_added, max_added = g.roundtrip()
+    path = str(tmp_path / "c1.gpcm")
+    nbytes = g.save_model(path)
+    import os
+    assert nbytes == os.path.getsize(path) > 0
+    xyz2, rgb2 = H.decompress_file(path, 64 * sz * sz)
+    assert np.array_equal(xyz2.view(np.uint32), oxyz.view(np.uint32)) and np.array_equal(rgb2, orgb)
+    raw = len(xyz) * 16                                      # x, y, z float + packed rgb, as PCL stores a PointXYZRGB compactly
+    assert nbytes < raw, (nbytes, raw)
+    # a truncated file is an error, not a crash
+    with open(path, "rb") as f:
+        blob = f.read()
+    bad = str(tmp_path / "bad.gpcm")
+    with open(bad, "wb") as f:
+        f.write(blob[: len(blob) // 2])
+    with pytest.raises(RuntimeError):
+        H.decompress_file(bad, 64 * sz * sz)
