@@ -843,37 +843,32 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 const d4 lt = mf_img_load(LinvT + k * MF_IMG, ln);
                 d4 gk = d4{0.0, 0.0, 0.0, 0.0};
                 if (k + 1 < nt) gk = mf_img_load(k > 0 ? Linv + (k - 1) * MF_IMG : Gzero, ln);
-                // L_kk^-T z_k - G_k alpha_(k+1) does not depend on the workers: issued before the wait.  16x16x16 MFMA
-                // products, column n < ny of the B operand carries channel n; alpha_(k+1) is still in this wave's
-                // registers from the previous iteration, in exactly the B operand layout.
-                d4 zb = d4{0.0, 0.0, 0.0, 0.0};
-                if (lr < ny) {
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) zb[q4] = zv[lr * MF_NPAD + MF_TS * k + lg + 4 * q4];
-                }
+                // -G_k alpha_(k+1) does not depend on the workers: issued before the wait.  16x16x16 MFMA products, column
+                // n < ny of the B operand carries channel n; alpha_(k+1) is still in this wave's registers from the previous
+                // iteration, in exactly the B operand layout.
                 const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
                 d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[0], al[0], z4, 0, 0, 1);   // blgp = 1: NEG(A)
                 d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[1], al[1], z4, 0, 0, 1);
                 d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[2], al[2], z4, 0, 0, 1);
                 d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(gk[3], al[3], z4, 0, 0, 1);
-                D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], zb[0], D0, 0, 0, 0);
-                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], zb[1], D1, 0, 0, 0);
-                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], zb[2], D2, 0, 0, 0);
-                D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], zb[3], D3, 0, 0, 0);
+                d4 ub = d4{0.0, 0.0, 0.0, 0.0};
+                if (lr < ny) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[lr * MF_NPAD + MF_TS * k + lg + 4 * q4];
+                }
                 const int expect = nt - k - 2;
                 if (expect > 0) {
                     timed_out |= !mf_wait_ge(pre_cnt_addr + 4u * (unsigned)k, expect);
                     MF_STAMP_FINE(10);
-                    d4 wb = d4{0.0, 0.0, 0.0, 0.0};
                     if (lr < ny) {
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) wb[q4] = wsum[lr * MF_NPAD + MF_TS * k + lg + 4 * q4];
+                        for (int q4 = 0; q4 < 4; ++q4) ub[q4] -= wsum[lr * MF_NPAD + MF_TS * k + lg + 4 * q4];
                     }
-                    D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], wb[0], D0, 0, 0, 1);
-                    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], wb[1], D1, 0, 0, 1);
-                    D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], wb[2], D2, 0, 0, 1);
-                    D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], wb[3], D3, 0, 0, 1);
                 }
+                D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], ub[0], D0, 0, 0, 0);       // + L_kk^-T (z_k - w_k)
+                D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], ub[1], D1, 0, 0, 0);
+                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], ub[2], D2, 0, 0, 0);
+                D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], ub[3], D3, 0, 0, 0);
                 al = (D0 + D1) + (D2 + D3);   // lanes lr = n < ny: alpha_n[16 k + (l>>4) + 4 r]; zero elsewhere
                 if (lr < ny) {
 #pragma unroll
