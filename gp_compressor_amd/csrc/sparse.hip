@@ -13,6 +13,7 @@
 // trained GPs):  alpha [P][ny][ld], C [P][ld][ld], Q [P][ld][ld] column-major like Eigen, BV [P][ld][2] (AoS,
 // = Eigen 2 x b column-major), b [P], total_count [P];  ld = capacity + 1 (a full update may hold capacity+1
 // basis vectors until the deletion that follows it), or GPC_MAX_BV when capacity == -1.
+#include <cstdlib>
 #include <vector>
 
 #include "gpc_device.h"
@@ -660,6 +661,7 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     const size_t lds = sp_add_lds(g->ld);
     int per_cu = (int)((160u * 1024u) / lds);
     per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    if (const char* e = getenv("GPC_SPARSE_PER_CU")) per_cu = std::max(1, atoi(e));   // diagnostic: resident-state experiments
     int grid = std::min(g->P, ctx->num_cus * per_cu);
     hipLaunchKernelGGL(sparse_add_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());

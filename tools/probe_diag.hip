@@ -18,7 +18,8 @@ __global__ __launch_bounds__(512) void probe_kernel(const double* tile, double* 
         unsigned long long t0 = __builtin_amdgcn_s_memtime();
         bool ok = true;
         for (int i = 0; i < reps; ++i) {
-            ok &= mf_diag_factor(sm, sm + 256, sm + 288, sm + 544, 1e-300);
+            const d4 W = *reinterpret_cast<const d4*>(sm + lane * 4);
+            ok &= mf_diag_factor(W, sm + 256, sm + 288, sm + 544, 1e-300);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
         unsigned long long t1 = __builtin_amdgcn_s_memtime();
