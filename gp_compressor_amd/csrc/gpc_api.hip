@@ -156,6 +156,12 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     if (!a.prm.want_variance) a.v_star = nullptr;
     if (dense_mfma_supported(a) && !getenv("GPC_FORCE_GENERIC")) return dense_mfma_launch(ctx, a);
+    if (dense_big_supported(a) && !getenv("GPC_FORCE_GENERIC")) {
+        int grid_b = 0;
+        int rcb = gpc_ws_reserve(ctx, dense_big_ws_bytes(ctx, a, &grid_b));
+        if (rcb != GPC_OK) return rcb;
+        return dense_big_launch(ctx, a, grid_b);
+    }
     int grid = 0;
     size_t bytes = dense_generic_ws_bytes(ctx, a, &grid);
     int rc = gpc_ws_reserve(ctx, bytes);

@@ -87,3 +87,8 @@ int dense_generic_launch(gpc_ctx* ctx, const DenseArgs& a, int grid);
 // register-tile MFMA kernel: n <= 256, trailing matrix resident in VGPRs (see dense_mfma.hip)
 bool dense_mfma_supported(const DenseArgs& a);
 int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a);
+
+// tiled left-looking MFMA kernel: 256 < n <= 1024, factor in a global-memory workspace slot per workgroup (see dense_mfma_big.hip)
+bool dense_big_supported(const DenseArgs& a);
+size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out);
+int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid);

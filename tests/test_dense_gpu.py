@@ -78,11 +78,12 @@ def test_dense_vs_oracle(gp, oracle, kernel_choice, P, n, ny, ragged, seed):
         _close(f, fo, FTOL)
         _close(al, ao, ATOL)
         assert np.max(np.abs(v - vo)) <= VTOL
-    # mean-only call: this is what dispatches to the register-tile kernel when n <= 256
+    # mean-only call: this is what dispatches to the register-tile kernel (n <= 256) or the tiled left-looking MFMA kernel (n <= 1024)
     p = capi.default_params_dense()
     f, _, st, al = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
     fo, _, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, want_alpha=True)
-    want_kernel = "dense_generic" if (kernel_choice == "generic" or n > 256) else "dense_mfma"
+    n_max = int(np.max(np.diff(off)))
+    want_kernel = "dense_generic" if kernel_choice == "generic" else ("dense_mfma_big" if n_max > 256 else "dense_mfma_nt")
     assert ctx.last_dense_kernel().startswith(want_kernel), ctx.last_dense_kernel()
     assert np.array_equal(st, so)
     _close(f, fo, FTOL)
