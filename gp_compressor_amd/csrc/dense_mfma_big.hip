@@ -28,7 +28,7 @@
 #define BG_THREADS 512
 #define BG_WAVES 8
 #define BG_NPAD 1024
-#define BG_RMAX 5   // tile rows a wave updates per pass (5 x 8 accumulator + 2 x 5 x 8 operand VGPRs)
+#define BG_RMAX 3   // tile rows a wave updates per pass, two columns each (3 x 16 accumulator + 2 x 3 x 8 operand VGPRs)
 
 struct BigParams {
     DenseArgs a;
@@ -48,10 +48,10 @@ struct BigParams {
 #define B_AV (B_WV + 3 * BG_NPAD)
 #define B_RS (B_AV + 3 * BG_NPAD)      // 32: rsqrt row of mf_diag_factor
 #define B_FLAG (B_RS + 32)             // 8:  ints [0] bad, [1] ready
-#define B_LINV (B_FLAG + 8)            // 256 L_kk^-1 image of the current column
-#define B_LINVT (B_LINV + 256)         // 256 L_kk^-T image
-#define B_RED (B_LINVT + 256)          // 8192 predict reduction buffer
-#define B_TOTAL (B_RED + 8192)         // 20072 doubles = 156.8 KB
+#define B_LINV (B_FLAG + 8)            // 2 x 256 L_kk^-1 images of the current column pair
+#define B_L10 (B_LINV + 512)           // 256 image of the pair's sub-diagonal tile L_(k+1)k
+#define B_RED (B_L10 + 256)            // 8192 predict reduction buffer
+#define B_TOTAL (B_RED + 8192)         // 20328 doubles = 158.8 KB
 
 __device__ static __forceinline__ d4 bg_mfma4_neg(d4 a, d4 b, d4 acc)
 {
@@ -73,11 +73,11 @@ __global__ __launch_bounds__(BG_THREADS, 2) void dense_big_kernel(BigParams g)
     double* rsbuf = lds + B_RS;
     int* flag = reinterpret_cast<int*>(lds + B_FLAG);
     int* ready = flag + 1;
-    double* LinvC = lds + B_LINV;
-    double* LinvTC = lds + B_LINVT;
+    double* LinvC = lds + B_LINV;      // [2][256]
+    double* L10 = lds + B_L10;
     double* red = lds + B_RED;
     const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
-    const unsigned ready_addr = lds0 + (unsigned)(B_FLAG * 8 + 4);
+    const unsigned ready_addr = lds0 + (unsigned)(B_FLAG * 8 + 4);     // highest tile column whose L_kk^-1 is published
 
     const DenseArgs& A = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -116,95 +116,166 @@ __global__ __launch_bounds__(BG_THREADS, 2) void dense_big_kernel(BigParams g)
         bool timed_out = false;
         bool bad = false;
 
-        // ---- tiled left-looking Cholesky; tile row nt carries the right-hand sides ----
-        for (int k = 0; k < nt; ++k) {
-            const int rows_w = (nt - k - wave + BG_WAVES) / BG_WAVES;     // rows k + wave + 8 t <= nt owned by this wave
-            for (int p0 = 0; p0 < rows_w || (p0 == 0); p0 += BG_RMAX) {
-                const int np = min(BG_RMAX, rows_w - p0);                 // rows in this pass (may be <= 0 for idle waves)
-                d4 acc[BG_RMAX];
-                // A_rk straight into the accumulators (transposed storage: lane l, register q = A[16 r + (l&15)][16 k + (l>>4) + 4 q])
-#pragma unroll
-                for (int t = 0; t < BG_RMAX; ++t) {
-                    acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-                    if (t < np) {
-                        const int r = k + wave + BG_WAVES * (p0 + t);
-                        if (r < nt) {
-                            const int pi = MF_TS * r + lr;
-                            const double xi0 = px0[pi], xi1 = px1[pi];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int pj = MF_TS * k + lg + 4 * q;
-                                double v = gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T);
-                                if (pi == pj) {
-                                    v += noise;                              // covariance_matrix(..., training)  :59-61
-                                    if (A.prm.ref_double_noise) v += noise;  // C.diagonal() += sigman_sq        :21
-                                }
-                                if (pi >= n || pj >= n) v = (pi == pj) ? 1.0 : 0.0;     // identity padding
-                                acc[t][q] = v;
-                            }
-                        } else {
-                            // right-hand sides: row c = channel, columns = the points of tile column k
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int pj = MF_TS * k + lg + 4 * q;
-                                acc[t][q] = (lr < ny && pj < n) ? A.y[(size_t)lr * A.n_total + o + pj] : 0.0;
-                            }
+        // ---- tiled left-looking Cholesky, two tile columns (k, k+1) per step; tile row nt carries the right-hand sides ----
+        // Two columns per step halve the dominant HBM stream: every tile L_rj fetched for the update of row r feeds the
+        // accumulators of both columns (8 MFMAs per 2 KB instead of 4; measured 5.8 TB/s with one column per step).
+        // Wave 0 owns the 2 x 2 diagonal block (tiles (k,k), (k+1,k), (k+1,k+1)): update -> factor (k,k) -> TRSM (k+1,k) ->
+        // update and factor (k+1,k+1), publishing each L^-1 as it appears.  The rows r >= k+2 (and the right-hand-side row
+        // nt) are dealt to the waves 1, 2, .., 7, 0, 1, ..: update both accumulators, L_rk = TRSM(acc0), acc1 -= L_rk L_(k+1)k^T,
+        // L_r(k+1) = TRSM(acc1).
+#define BG_INIT_TILE(dst, r_, kc_)                                                                                   \
+    do {                                                                                                             \
+        if ((r_) < nt) {                                                                                             \
+            const int pi_ = MF_TS * (r_) + lr;                                                                       \
+            const double xi0_ = px0[pi_], xi1_ = px1[pi_];                                                           \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
+                const int pj_ = MF_TS * (kc_) + lg + 4 * q_;                                                         \
+                double v_ = gpc_rbf_neg(sf, cexp, xi0_, xi1_, px0[pj_], px1[pj_], T);                                \
+                if (pi_ == pj_) {                                                                                    \
+                    v_ += noise;                              /* covariance_matrix(..., training)  :59-61 */         \
+                    if (A.prm.ref_double_noise) v_ += noise;  /* C.diagonal() += sigman_sq        :21 */             \
+                }                                                                                                    \
+                if (pi_ >= n || pj_ >= n) v_ = (pi_ == pj_) ? 1.0 : 0.0;     /* identity padding */                  \
+                (dst)[q_] = v_;                                                                                      \
+            }                                                                                                        \
+        } else {   /* right-hand sides: row c = channel, columns = the points of tile column kc_ */                  \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
+                const int pj_ = MF_TS * (kc_) + lg + 4 * q_;                                                         \
+                (dst)[q_] = (lr < ny && pj_ < n) ? A.y[(size_t)lr * A.n_total + o + pj_] : 0.0;                      \
+            }                                                                                                        \
+        }                                                                                                            \
+    } while (0)
+#define BG_TRSM(lv_, src_)                                                                                           \
+    ((__builtin_amdgcn_mfma_f64_16x16x4f64((lv_)[0], (src_)[0], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0) +                   \
+      __builtin_amdgcn_mfma_f64_16x16x4f64((lv_)[1], (src_)[1], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0)) +                  \
+     (__builtin_amdgcn_mfma_f64_16x16x4f64((lv_)[2], (src_)[2], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0) +                   \
+      __builtin_amdgcn_mfma_f64_16x16x4f64((lv_)[3], (src_)[3], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0)))
+        for (int k = 0; k < nt; k += 2) {
+            const bool has2 = k + 1 < nt;
+            const int k1 = has2 ? k + 1 : k;                               // second column of the pair (== k when absent)
+            const double* rowk = Lt + ((size_t)k * ntw) * MF_IMG;          // L_kj, j < k
+            const double* rowk1 = Lt + ((size_t)k1 * ntw) * MF_IMG;
+            if (wave == 0) {
+                // ---- the 2 x 2 diagonal block ----
+                d4 D00, D10 = d4{0.0, 0.0, 0.0, 0.0}, D11 = d4{0.0, 0.0, 0.0, 0.0};
+                BG_INIT_TILE(D00, k, k);
+                if (has2) {
+                    BG_INIT_TILE(D10, k + 1, k);
+                    BG_INIT_TILE(D11, k + 1, k + 1);
+                }
+                if (k > 0) {
+                    d4 a0 = mf_img_load(rowk, lane), a1 = mf_img_load(rowk1, lane), a0n = a0, a1n = a1;
+                    for (int j = 0; j < k; ++j) {
+                        if (j + 1 < k) {
+                            a0n = mf_img_load(rowk + (size_t)(j + 1) * MF_IMG, lane);
+                            a1n = mf_img_load(rowk1 + (size_t)(j + 1) * MF_IMG, lane);
                         }
+                        D00 = bg_mfma4_neg(a0, a0, D00);
+                        if (has2) {
+                            D10 = bg_mfma4_neg(a0, a1, D10);
+                            D11 = bg_mfma4_neg(a1, a1, D11);
+                        }
+                        a0 = a0n;
+                        a1 = a1n;
                     }
                 }
-                // T_rk -= sum_j L_rj L_kj^T; the operand L_kj is loaded once per j for all rows of the pass, j + 1 is prefetched
+                bool ok = mf_diag_factor(D00, rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (!ok && lane == 0) flag[0] = 1;
+                if (ok && has2) {
+                    mf_publish(ready, k);                                  // L_kk^-1 (the others start their first TRSM)
+                    const d4 lv = mf_img_load(LinvC, lane);
+                    const d4 l10 = BG_TRSM(lv, D10);                       // operand image of L_(k+1)k
+                    mf_img_store(Lt + ((size_t)(k + 1) * ntw + k) * MF_IMG, lane, l10);
+                    mf_img_store(L10, lane, l10);
+                    D11 = bg_mfma4_neg(l10, l10, D11);
+                    ok = mf_diag_factor(D11, rsbuf, LinvC + 256, LinvTg + (size_t)(k + 1) * MF_IMG, g.pivot_tol);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (!ok && lane == 0) flag[0] = 1;
+                }
+                mf_publish(ready, k1);
+            }
+            // ---- rows r >= k + 2 (and the right-hand-side row nt), dealt to the waves 1, 2, .., 7, 0, 1, .. ----
+            const int q0 = (wave + BG_WAVES - 1) % BG_WAVES;               // first row of this wave: k + 2 + q0
+            const int span = nt - (k + 2) - q0;
+            const int rows_w = has2 ? (span >= 0 ? span / BG_WAVES + 1 : 0) : 0;
+            // a single trailing column has only the right-hand-side row left (k + 1 == nt): wave 1 takes it
+            const int rows_eff = has2 ? rows_w : ((wave == 1 % BG_WAVES) ? 1 : 0);
+            bool stop = false;
+            for (int p0 = 0; (p0 < rows_eff || p0 == 0) && !stop; p0 += BG_RMAX) {
+                const int np = min(BG_RMAX, rows_eff - p0);
+                d4 acc0[BG_RMAX], acc1[BG_RMAX];
+                int rr[BG_RMAX];
+#pragma unroll
+                for (int t = 0; t < BG_RMAX; ++t) {
+                    rr[t] = has2 ? k + 2 + q0 + BG_WAVES * (p0 + t) : nt;
+                    acc0[t] = d4{0.0, 0.0, 0.0, 0.0};
+                    acc1[t] = d4{0.0, 0.0, 0.0, 0.0};
+                    if (t < np) {
+                        BG_INIT_TILE(acc0[t], rr[t], k);
+                        if (has2) BG_INIT_TILE(acc1[t], rr[t], k + 1);
+                    }
+                }
                 if (np > 0 && k > 0) {
-                    d4 a_cur = mf_img_load(Lt + ((size_t)k * ntw) * MF_IMG, lane), a_nxt = a_cur;
+                    d4 a0 = mf_img_load(rowk, lane), a1 = mf_img_load(rowk1, lane), a0n = a0, a1n = a1;
                     d4 b_cur[BG_RMAX], b_nxt[BG_RMAX];
 #pragma unroll
                     for (int t = 0; t < BG_RMAX; ++t) {
-                        b_cur[t] = a_cur;
-                        if (t < np) b_cur[t] = mf_img_load(Lt + ((size_t)(k + wave + BG_WAVES * (p0 + t)) * ntw) * MF_IMG, lane);
+                        b_cur[t] = a0;
+                        if (t < np) b_cur[t] = mf_img_load(Lt + ((size_t)rr[t] * ntw) * MF_IMG, lane);
                         b_nxt[t] = b_cur[t];
                     }
                     for (int j = 0; j < k; ++j) {
                         if (j + 1 < k) {
-                            a_nxt = mf_img_load(Lt + ((size_t)k * ntw + j + 1) * MF_IMG, lane);
+                            a0n = mf_img_load(rowk + (size_t)(j + 1) * MF_IMG, lane);
+                            a1n = mf_img_load(rowk1 + (size_t)(j + 1) * MF_IMG, lane);
 #pragma unroll
                             for (int t = 0; t < BG_RMAX; ++t)
-                                if (t < np) b_nxt[t] = mf_img_load(Lt + ((size_t)(k + wave + BG_WAVES * (p0 + t)) * ntw + j + 1) * MF_IMG, lane);
+                                if (t < np) b_nxt[t] = mf_img_load(Lt + ((size_t)rr[t] * ntw + j + 1) * MF_IMG, lane);
                         }
 #pragma unroll
-                        for (int t = 0; t < BG_RMAX; ++t)
-                            if (t < np) acc[t] = bg_mfma4_neg(a_cur, b_cur[t], acc[t]);
-                        a_cur = a_nxt;
+                        for (int t = 0; t < BG_RMAX; ++t) {
+                            if (t < np) {
+                                acc0[t] = bg_mfma4_neg(a0, b_cur[t], acc0[t]);
+                                if (has2) acc1[t] = bg_mfma4_neg(a1, b_cur[t], acc1[t]);
+                            }
+                        }
+                        a0 = a0n;
+                        a1 = a1n;
 #pragma unroll
                         for (int t = 0; t < BG_RMAX; ++t) b_cur[t] = b_nxt[t];
                     }
                 }
-                // the diagonal tile is row 0 of wave 0's first pass: factor it at once
-                if (wave == 0 && p0 == 0) {
-                    const bool ok = mf_diag_factor(acc[0], rsbuf, LinvC, LinvTC, g.pivot_tol);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    mf_img_store(LinvTg + (size_t)k * MF_IMG, lane, mf_img_load(LinvTC, lane));    // kept for the backward solve
-                    if (!ok && lane == 0) flag[0] = 1;
-                    mf_publish(ready, k);
-                }
-                // L_rk = T_rk L_kk^-T for the other rows
+                // L_rk = T_rk L_kk^-T;  T_r(k+1) -= L_rk L_(k+1)k^T;  L_r(k+1) = T_r(k+1) L_(k+1)(k+1)^-T
                 timed_out |= !mf_wait_ge(ready_addr, k);
-                if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { stop = true; continue; }
                 if (np > 0) {
-                    const d4 lv = mf_img_load(LinvC, lane);
+                    const d4 lv0 = mf_img_load(LinvC, lane);
 #pragma unroll
                     for (int t = 0; t < BG_RMAX; ++t) {
-                        if (t < np && !(wave == 0 && p0 == 0 && t == 0)) {
-                            const int r = k + wave + BG_WAVES * (p0 + t);
-                            const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
-                            const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], acc[t][0], z4, 0, 0, 0);
-                            const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], acc[t][1], z4, 0, 0, 0);
-                            const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], acc[t][2], z4, 0, 0, 0);
-                            const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], acc[t][3], z4, 0, 0, 0);
-                            mf_img_store(Lt + ((size_t)r * ntw + k) * MF_IMG, lane, (D0 + D1) + (D2 + D3));
+                        if (t < np) {
+                            acc0[t] = BG_TRSM(lv0, acc0[t]);
+                            mf_img_store(Lt + ((size_t)rr[t] * ntw + k) * MF_IMG, lane, acc0[t]);
+                        }
+                    }
+                }
+                if (has2) {
+                    timed_out |= !mf_wait_ge(ready_addr, k + 1);
+                    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { stop = true; continue; }
+                    if (np > 0) {
+                        const d4 lv1 = mf_img_load(LinvC + 256, lane);
+                        const d4 a10 = mf_img_load(L10, lane);
+#pragma unroll
+                        for (int t = 0; t < BG_RMAX; ++t) {
+                            if (t < np) {
+                                acc1[t] = bg_mfma4_neg(a10, acc0[t], acc1[t]);
+                                mf_img_store(Lt + ((size_t)rr[t] * ntw + k + 1) * MF_IMG, lane, BG_TRSM(lv1, acc1[t]));
+                            }
                         }
                     }
                 }
             }
-            __syncthreads();   // column k is in the workspace; L_kk^-1 image may be overwritten
+            __syncthreads();   // the column pair is in the workspace; the L^-1 images may be overwritten
             bad = flag[0] != 0;
             if (bad) break;
         }
