@@ -25,9 +25,6 @@
 #include "gpc_internal.h"
 #include "mfma_tile.h"
 
-#define BG_THREADS 512
-#define BG_WAVES 8
-#define BG_NPAD 1024
 #define BG_RMAX 3   // tile rows a wave updates per pass, two columns each (3 x 16 accumulator + 2 x 3 x 8 operand VGPRs)
 
 struct BigParams {
@@ -39,19 +36,10 @@ struct BigParams {
     int ntw;       // tile columns of a slot = ceil(n_max / 16)
 };
 
-// LDS carve (doubles)
-#define B_EXP 0
-#define B_PX0 64
-#define B_PX1 (B_PX0 + BG_NPAD)
-#define B_ZV (B_PX1 + BG_NPAD)
-#define B_WV (B_ZV + 3 * BG_NPAD)
-#define B_AV (B_WV + 3 * BG_NPAD)
-#define B_RS (B_AV + 3 * BG_NPAD)      // 32: rsqrt row of mf_diag_factor
-#define B_FLAG (B_RS + 32)             // 8:  ints [0] bad, [1] ready
-#define B_LINV (B_FLAG + 8)            // 2 x 256 L_kk^-1 images of the current column pair
-#define B_L10 (B_LINV + 512)           // 256 image of the pair's sub-diagonal tile L_(k+1)k
-#define B_RED (B_L10 + 256)            // 8192 predict reduction buffer
-#define B_TOTAL (B_RED + 8192)         // 20328 doubles = 158.8 KB
+// LDS carve (doubles), for NPAD padded points and WAVES waves per workgroup:
+//   exp table 64 | x0, x1 2 NPAD | z, w, alpha 9 NPAD | rsqrt row 32 | flags 8 | 2 L^-1 images 512 | L_(k+1)k image 256 |
+//   predict reduction WAVES x 4 x 256
+__host__ __device__ constexpr int bg_lds_doubles(int npad, int waves) { return 64 + 11 * npad + 32 + 8 + 512 + 256 + waves * 1024; }
 
 __device__ static __forceinline__ d4 bg_mfma4_neg(d4 a, d4 b, d4 acc)
 {
@@ -60,18 +48,24 @@ __device__ static __forceinline__ d4 bg_mfma4_neg(d4 a, d4 b, d4 acc)
     return acc;
 }
 
-__global__ __launch_bounds__(BG_THREADS, 2) void dense_big_kernel(BigParams g)
+// BG_WAVES waves per workgroup and BG_NPAD padded points: <8, 1024> (one workgroup per CU) for 256 < n <= 1024.
+template <int BG_WAVES, int BG_NPAD>
+__global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g)
 {
+    constexpr int BG_THREADS = BG_WAVES * 64;
+    constexpr int B_PX0 = 64, B_PX1 = B_PX0 + BG_NPAD, B_ZV = B_PX1 + BG_NPAD, B_WV = B_ZV + 3 * BG_NPAD, B_AV = B_WV + 3 * BG_NPAD,
+                  B_RS = B_AV + 3 * BG_NPAD, B_FLAG = B_RS + 32, B_LINV = B_FLAG + 8, B_L10 = B_LINV + 512, B_RED = B_L10 + 256;
+    static_assert(B_RED + BG_WAVES * 1024 == bg_lds_doubles(BG_NPAD, BG_WAVES), "LDS carve");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
-    double* T = lds + B_EXP;
+    double* T = lds;
     double* px0 = lds + B_PX0;
     double* px1 = lds + B_PX1;
     double* zv = lds + B_ZV;
     double* wv = lds + B_WV;
     double* av = lds + B_AV;
     double* rsbuf = lds + B_RS;
-    int* flag = reinterpret_cast<int*>(lds + B_FLAG);
+    int* flag = reinterpret_cast<int*>(lds + B_FLAG);   // ints [0] bad, [1] ready
     int* ready = flag + 1;
     double* LinvC = lds + B_LINV;      // [2][256]
     double* L10 = lds + B_L10;
@@ -434,17 +428,42 @@ __global__ __launch_bounds__(BG_THREADS, 2) void dense_big_kernel(BigParams g)
 
 bool dense_big_supported(const DenseArgs& a)
 {
-    return a.n_max > 256 && a.n_max <= BG_NPAD && a.v_star == nullptr && (a.ny == 1 || a.ny == 3);
+    return a.n_max > 256 && a.n_max <= 1024 && a.v_star == nullptr && (a.ny == 1 || a.ny == 3);
 }
 
 static size_t big_slot_doubles(int ntw) { return ((size_t)(ntw + 1) * ntw + ntw) * MF_IMG; }
 
+// 8 waves x 1024 points: 159 KB of LDS, one workgroup per CU.  (n <= 256: 4 waves x 256 points, 61 KB: two per CU.)
+static void big_shape(const DenseArgs& a, int* waves, int* npad, int* per_cu)
+{
+    if (a.n_max <= 256) { *waves = 4; *npad = 256; *per_cu = 2; }
+    else { *waves = 8; *npad = 1024; *per_cu = 1; }
+}
+
 size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
 {
+    int waves, npad, per_cu;
+    big_shape(a, &waves, &npad, &per_cu);
     const int ntw = (a.n_max + MF_TS - 1) / MF_TS;
-    const int grid = a.P < ctx->num_cus ? a.P : ctx->num_cus;     // 157 KB of LDS: one workgroup per CU
+    const int cap = ctx->num_cus * per_cu;
+    const int grid = a.P < cap ? a.P : cap;
     if (grid_out) *grid_out = grid;
     return sizeof(double) * big_slot_doubles(ntw) * (size_t)grid;
+}
+
+template <int W, int NP>
+static int big_launch_t(gpc_ctx* ctx, const BigParams& g, int grid)
+{
+    const size_t lds = sizeof(double) * (size_t)bg_lds_doubles(NP, W);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_big_kernel<W, NP>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dense_big_kernel<W, NP>), dim3(grid), dim3(W * 64), lds, ctx->stream, g);
+    GPC_HIP(ctx, hipGetLastError());
+    return GPC_OK;
 }
 
 int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
@@ -456,15 +475,12 @@ int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
     g.ws = static_cast<double*>(ctx->ws);
     g.ntw = (a.n_max + MF_TS - 1) / MF_TS;
     g.slot = big_slot_doubles(g.ntw);
-    const size_t lds = sizeof(double) * (size_t)B_TOTAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-        attr_set = true;
+    int waves, npad, per_cu;
+    big_shape(a, &waves, &npad, &per_cu);
+    if (waves == 4) {
+        ctx->last_dense_kernel = "dense_mfma_big_w4";
+        return big_launch_t<4, 256>(ctx, g, grid);
     }
-    hipLaunchKernelGGL(dense_big_kernel, dim3(grid), dim3(BG_THREADS), lds, ctx->stream, g);
-    GPC_HIP(ctx, hipGetLastError());
     ctx->last_dense_kernel = "dense_mfma_big";
-    return GPC_OK;
+    return big_launch_t<8, 1024>(ctx, g, grid);
 }

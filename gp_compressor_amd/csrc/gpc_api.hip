@@ -155,8 +155,8 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
     std::lock_guard<std::mutex> lk(ctx->mu);
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     if (!a.prm.want_variance) a.v_star = nullptr;
-    if (dense_mfma_supported(a) && !getenv("GPC_FORCE_GENERIC")) return dense_mfma_launch(ctx, a);
-    if (dense_big_supported(a) && !getenv("GPC_FORCE_GENERIC")) {
+    if (dense_mfma_supported(a) && !getenv("GPC_FORCE_GENERIC") && !getenv("GPC_FORCE_BIG")) return dense_mfma_launch(ctx, a);
+    if ((dense_big_supported(a) || (getenv("GPC_FORCE_BIG") && a.n_max <= 1024 && !a.v_star)) && !getenv("GPC_FORCE_GENERIC")) {   // GPC_FORCE_BIG: diagnostic
         int grid_b = 0;
         int rcb = gpc_ws_reserve(ctx, dense_big_ws_bytes(ctx, a, &grid_b));
         if (rcb != GPC_OK) return rcb;

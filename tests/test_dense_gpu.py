@@ -50,14 +50,17 @@ def test_dense_golden(gp, name):
     assert np.max(np.abs(v - d["v_star"])) <= VTOL
 
 
-@pytest.fixture(params=["dispatch", "generic"])
+@pytest.fixture(params=["dispatch", "generic", "big"])
 def kernel_choice(request, monkeypatch):
-    """Run a test once with the normal dispatch (register-tile MFMA kernel for n <= 256) and once with the generic
-    global-workspace kernel forced (GPC_FORCE_GENERIC is read at every call)."""
+    """Run a test with the normal dispatch (register-tile MFMA kernel for n <= 256, tiled left-looking MFMA kernel above),
+    with the generic global-workspace kernel forced, and with the left-looking kernel forced for every n (its
+    4-wave / two-workgroups-per-CU shape below 257 points).  The environment is read at every call."""
+    monkeypatch.delenv("GPC_FORCE_GENERIC", raising=False)
+    monkeypatch.delenv("GPC_FORCE_BIG", raising=False)
     if request.param == "generic":
         monkeypatch.setenv("GPC_FORCE_GENERIC", "1")
-    else:
-        monkeypatch.delenv("GPC_FORCE_GENERIC", raising=False)
+    elif request.param == "big":
+        monkeypatch.setenv("GPC_FORCE_BIG", "1")
     return request.param
 
 
@@ -83,7 +86,7 @@ def test_dense_vs_oracle(gp, oracle, kernel_choice, P, n, ny, ragged, seed):
     f, _, st, al = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
     fo, _, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, want_alpha=True)
     n_max = int(np.max(np.diff(off)))
-    want_kernel = "dense_generic" if kernel_choice == "generic" else ("dense_mfma_big" if n_max > 256 else "dense_mfma_nt")
+    want_kernel = {"generic": "dense_generic", "big": "dense_mfma_big"}.get(kernel_choice, "dense_mfma_big" if n_max > 256 else "dense_mfma_nt")
     assert ctx.last_dense_kernel().startswith(want_kernel), ctx.last_dense_kernel()
     assert np.array_equal(st, so)
     _close(f, fo, FTOL)
