@@ -6,26 +6,33 @@
 // 16 x 16 tiles in MFMA *operand image* layout (mfma_tile.h; 2 KB each, read back with two coalesced 16-byte loads per
 // lane) and the factorisation is a tiled LEFT-looking Cholesky:
 //
-//   column k:  T_rk = A_rk - sum_{j<k} L_rj L_kj^T   (4 v_mfma_f64_16x16x4_f64 per (r, j)),   r = k .. nt
+//   columns k, k+1:  T_rc = A_rc - sum_{j<k} L_rj L_cj^T   (4 v_mfma_f64_16x16x4_f64 per (r, c, j)),   r = k .. nt
 //              L_kk^-1 by the in-place Gauss-Jordan on the MFMA pipe (mf_diag_factor),   L_rk = T_rk L_kk^-T (4 MFMAs)
 //
 // * K itself is never stored: A_rk is evaluated (RBF + noise diagonal) straight into the accumulator registers when
 //   column k starts.  HBM/L2 see the factor only: one write per tile, nt/3 reads on average.
-// * Tile rows of a column are dealt round-robin to the 8 waves; a wave keeps up to BG_RMAX row accumulators and loads
-//   the shared operand L_kj once per j for all of them (register blocking), with the next j prefetched.
+// * TWO tile columns per step: every fetched tile L_rj feeds the accumulators of both columns (the kernel streams the
+//   factor from HBM / Infinity Cache: 4 TB/s measured, it was 5.8 TB/s and 25 % slower with one column per step).  Tile
+//   rows are dealt round-robin to the waves; a wave keeps up to BG_RMAX rows (x 2 columns) of accumulators, loads the
+//   shared operands L_kj, L_(k+1)j once per j for all of them, and keeps the loads of the next two j in flight.
 // * The right-hand sides ride along as one more tile row (row nt holds y^T padded to 16 channels): its TRSM result is
 //   z^T, so the forward solve needs no code of its own.
-// * Wave 0 takes the diagonal tile first and factors it while the other waves still stream their updates; they poll an
-//   LDS word for L_kk^-1 (bounded asm poll, mfma_tile.h).  One workgroup barrier per column.
+// * Wave 0 owns the 2 x 2 diagonal block of the step (update, factor, TRSM, update, factor) while the other waves stream
+//   their row updates; they poll an LDS word for each L^-1 (bounded asm poll, mfma_tile.h).  One workgroup barrier per step.
+// * The kernel is a template over waves per workgroup and padded size: <8, 1024> is the production shape (one workgroup
+//   per CU); <4, 256> runs two workgroups per CU and is kept as a cross-check of dense_mfma.hip (GPC_FORCE_BIG=1).
 // * Backward solve: alpha_k = L_kk^-T (z_k - sum_{i>k} L_ik^T alpha_i); the tile products contract over the ROW index,
 //   which the image layout cannot feed to an MFMA, so they run on the VALU with the DPP row reduction of mfma_tile.h
 //   (O(n^2) work against the O(n^3) of the factorisation).  Predictive mean: the separable-grid MFMA form of
 //   dense_mfma.hip, looped over 32-point chunks.
+#include <cstdio>
+#include <cstdlib>
+
 #include "gpc_device.h"
 #include "gpc_internal.h"
 #include "mfma_tile.h"
 
-#define BG_RMAX 3   // tile rows a wave updates per pass, two columns each (3 x 16 accumulator + 2 x 3 x 8 operand VGPRs)
+#define BG_RMAX 2   // tile rows a wave updates per pass, two columns each (2 x 16 accumulator + 3 stages x (16 + 2 x 8) operand VGPRs)
 
 struct BigParams {
     DenseArgs a;
@@ -34,7 +41,17 @@ struct BigParams {
     double* ws;
     size_t slot;   // doubles per workgroup slot
     int ntw;       // tile columns of a slot = ceil(n_max / 16)
+    unsigned long long* stamps;   // diagnostic (GPC_BIG_STAMPS=1): [phase][wave] cycle sums over all patches, else nullptr
 };
+#define BG_NPH 6
+#define BG_STAMP(ph)                                                                                                 \
+    do {                                                                                                             \
+        if (g.stamps) {                                                                                              \
+            const unsigned long long t_now_ = __builtin_amdgcn_s_memtime();                                          \
+            if (lane == 0) atomicAdd(g.stamps + (ph) * 8 + wave, t_now_ - t_prev_);                                  \
+            t_prev_ = t_now_;                                                                                        \
+        }                                                                                                            \
+    } while (0)
 
 // LDS carve (doubles), for NPAD padded points and WAVES waves per workgroup:
 //   exp table 64 | x0, x1 2 NPAD | z, w, alpha 9 NPAD | rsqrt row 32 | flags 8 | 2 L^-1 images 512 | L_(k+1)k image 256 |
@@ -95,6 +112,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
             continue;
         }
         const int nt = __builtin_amdgcn_readfirstlane((n + MF_TS - 1) / MF_TS);
+        unsigned long long t_prev_ = g.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
         for (int i = tid; i < BG_NPAD; i += BG_THREADS) {
             const bool live = i < n;
             px0[i] = live ? A.x0[o + i] : 0.0;
@@ -109,6 +127,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
         __syncthreads();
         bool timed_out = false;
         bool bad = false;
+        BG_STAMP(0);
 
         // ---- tiled left-looking Cholesky, two tile columns (k, k+1) per step; tile row nt carries the right-hand sides ----
         // Two columns per step halve the dominant HBM stream: every tile L_rj fetched for the update of row r feeds the
@@ -158,19 +177,35 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
                     BG_INIT_TILE(D11, k + 1, k + 1);
                 }
                 if (k > 0) {
-                    d4 a0 = mf_img_load(rowk, lane), a1 = mf_img_load(rowk1, lane), a0n = a0, a1n = a1;
-                    for (int j = 0; j < k; ++j) {
+                    d4 da0[3], da1[3];
+#define BG_DLOAD(st, jj)                                                                                             \
+    do {                                                                                                             \
+        da0[st] = mf_img_load(rowk + (size_t)(jj) * MF_IMG, lane);                                                   \
+        da1[st] = mf_img_load(rowk1 + (size_t)(jj) * MF_IMG, lane);                                                  \
+    } while (0)
+#define BG_DUSE(st)                                                                                                  \
+    do {                                                                                                             \
+        D00 = bg_mfma4_neg(da0[st], da0[st], D00);                                                                   \
+        if (has2) {                                                                                                  \
+            D10 = bg_mfma4_neg(da0[st], da1[st], D10);                                                               \
+            D11 = bg_mfma4_neg(da1[st], da1[st], D11);                                                               \
+        }                                                                                                            \
+    } while (0)
+#pragma unroll
+                    for (int st = 0; st < 3; ++st) da0[st] = da1[st] = d4{0.0, 0.0, 0.0, 0.0};
+                    BG_DLOAD(0, 0);
+                    if (k > 1) BG_DLOAD(1, 1);
+                    for (int j = 0; j < k; j += 3) {
+                        if (j + 2 < k) BG_DLOAD(2, j + 2);
+                        BG_DUSE(0);
                         if (j + 1 < k) {
-                            a0n = mf_img_load(rowk + (size_t)(j + 1) * MF_IMG, lane);
-                            a1n = mf_img_load(rowk1 + (size_t)(j + 1) * MF_IMG, lane);
+                            if (j + 3 < k) BG_DLOAD(0, j + 3);
+                            BG_DUSE(1);
                         }
-                        D00 = bg_mfma4_neg(a0, a0, D00);
-                        if (has2) {
-                            D10 = bg_mfma4_neg(a0, a1, D10);
-                            D11 = bg_mfma4_neg(a1, a1, D11);
+                        if (j + 2 < k) {
+                            if (j + 4 < k) BG_DLOAD(1, j + 4);
+                            BG_DUSE(2);
                         }
-                        a0 = a0n;
-                        a1 = a1n;
                     }
                 }
                 bool ok = mf_diag_factor(D00, rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol);
@@ -190,9 +225,13 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
                 mf_publish(ready, k1);
             }
             // ---- rows r >= k + 2 (and the right-hand-side row nt), dealt to the waves 1, 2, .., 7, 0, 1, .. ----
-            const int q0 = (wave + BG_WAVES - 1) % BG_WAVES;               // first row of this wave: k + 2 + q0
-            const int span = nt - (k + 2) - q0;
-            const int rows_w = has2 ? (span >= 0 ? span / BG_WAVES + 1 : 0) : 0;
+            // Wave 0 carries the diagonal block (3 tile updates per j against 2 per row, plus the two serial factorisations):
+            // it takes rows only when there are plenty (>= 3 per wave), otherwise the rows go to the waves 1 .. W-1 alone.
+            const int rows_tot = has2 ? nt - (k + 2) + 1 : 0;              // rows k+2 .. nt
+            const int nwk = (rows_tot >= 3 * BG_WAVES) ? BG_WAVES : BG_WAVES - 1;
+            const int q0 = (wave + BG_WAVES - 1) % BG_WAVES;               // first row of this wave: k + 2 + q0 (wave 0: last slot)
+            const int span = rows_tot - 1 - q0;
+            const int rows_w = (has2 && q0 < nwk) ? (span >= 0 ? span / nwk + 1 : 0) : 0;
             // a single trailing column has only the right-hand-side row left (k + 1 == nt): wave 1 takes it
             const int rows_eff = has2 ? rows_w : ((wave == 1 % BG_WAVES) ? 1 : 0);
             bool stop = false;
@@ -202,7 +241,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
                 int rr[BG_RMAX];
 #pragma unroll
                 for (int t = 0; t < BG_RMAX; ++t) {
-                    rr[t] = has2 ? k + 2 + q0 + BG_WAVES * (p0 + t) : nt;
+                    rr[t] = has2 ? k + 2 + q0 + nwk * (p0 + t) : nt;
                     acc0[t] = d4{0.0, 0.0, 0.0, 0.0};
                     acc1[t] = d4{0.0, 0.0, 0.0, 0.0};
                     if (t < np) {
@@ -211,33 +250,45 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
                     }
                 }
                 if (np > 0 && k > 0) {
-                    d4 a0 = mf_img_load(rowk, lane), a1 = mf_img_load(rowk1, lane), a0n = a0, a1n = a1;
-                    d4 b_cur[BG_RMAX], b_nxt[BG_RMAX];
+                    // three operand stages rotate through the loop (unrolled by 3): while stage s feeds the MFMAs, the loads
+                    // of the next two j are in flight -- the factor tiles come from HBM / the Infinity Cache, ~2k cycles away
+                    d4 sa0[3], sa1[3], sb[3][BG_RMAX];
+#define BG_LOAD_STAGE(st, jj)                                                                                        \
+    do {                                                                                                             \
+        sa0[st] = mf_img_load(rowk + (size_t)(jj) * MF_IMG, lane);                                               \
+        sa1[st] = mf_img_load(rowk1 + (size_t)(jj) * MF_IMG, lane);                                              \
+        _Pragma("unroll") for (int t = 0; t < BG_RMAX; ++t)                                                          \
+            if (t < np) sb[st][t] = mf_img_load(Lt + ((size_t)rr[t] * ntw) * MF_IMG + (size_t)(jj) * MF_IMG, lane); \
+    } while (0)
+#define BG_USE_STAGE(st)                                                                                             \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int t = 0; t < BG_RMAX; ++t) {                                                        \
+            if (t < np) {                                                                                            \
+                acc0[t] = bg_mfma4_neg(sa0[st], sb[st][t], acc0[t]);                                                 \
+                if (has2) acc1[t] = bg_mfma4_neg(sa1[st], sb[st][t], acc1[t]);                                       \
+            }                                                                                                        \
+        }                                                                                                            \
+    } while (0)
 #pragma unroll
-                    for (int t = 0; t < BG_RMAX; ++t) {
-                        b_cur[t] = a0;
-                        if (t < np) b_cur[t] = mf_img_load(Lt + ((size_t)rr[t] * ntw) * MF_IMG, lane);
-                        b_nxt[t] = b_cur[t];
+                    for (int st = 0; st < 3; ++st) {
+                        sa0[st] = d4{0.0, 0.0, 0.0, 0.0};
+                        sa1[st] = sa0[st];
+#pragma unroll
+                        for (int t = 0; t < BG_RMAX; ++t) sb[st][t] = sa0[st];
                     }
-                    for (int j = 0; j < k; ++j) {
+                    BG_LOAD_STAGE(0, 0);
+                    if (k > 1) BG_LOAD_STAGE(1, 1);
+                    for (int j = 0; j < k; j += 3) {
+                        if (j + 2 < k) BG_LOAD_STAGE(2, j + 2);
+                        BG_USE_STAGE(0);
                         if (j + 1 < k) {
-                            a0n = mf_img_load(rowk + (size_t)(j + 1) * MF_IMG, lane);
-                            a1n = mf_img_load(rowk1 + (size_t)(j + 1) * MF_IMG, lane);
-#pragma unroll
-                            for (int t = 0; t < BG_RMAX; ++t)
-                                if (t < np) b_nxt[t] = mf_img_load(Lt + ((size_t)rr[t] * ntw + j + 1) * MF_IMG, lane);
+                            if (j + 3 < k) BG_LOAD_STAGE(0, j + 3);
+                            BG_USE_STAGE(1);
                         }
-#pragma unroll
-                        for (int t = 0; t < BG_RMAX; ++t) {
-                            if (t < np) {
-                                acc0[t] = bg_mfma4_neg(a0, b_cur[t], acc0[t]);
-                                if (has2) acc1[t] = bg_mfma4_neg(a1, b_cur[t], acc1[t]);
-                            }
+                        if (j + 2 < k) {
+                            if (j + 4 < k) BG_LOAD_STAGE(1, j + 4);
+                            BG_USE_STAGE(2);
                         }
-                        a0 = a0n;
-                        a1 = a1n;
-#pragma unroll
-                        for (int t = 0; t < BG_RMAX; ++t) b_cur[t] = b_nxt[t];
                     }
                 }
                 // L_rk = T_rk L_kk^-T;  T_r(k+1) -= L_rk L_(k+1)k^T;  L_r(k+1) = T_r(k+1) L_(k+1)(k+1)^-T
@@ -283,6 +334,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
             continue;
         }
 
+        BG_STAMP(1);
         // z_k^T = tile (nt, k): lane l, slot s = z_(l&15)[16 k + (l>>4) + 4 s]
         for (int k = wave; k < nt; k += BG_WAVES) {
             const d4 zt = mf_img_load(Lt + ((size_t)nt * ntw + k) * MF_IMG, lane);
@@ -293,51 +345,76 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
         }
         __syncthreads();
 
+        BG_STAMP(2);
         // ---- backward solve L^T alpha = z, tile columns from the last to the first ----
-        for (int k = nt - 1; k >= 0; --k) {
-            d4 pa[3];
+        // Column k needs the tiles (i, k), i = k+1+wave+W t, and L_kk^-T: they do not depend on alpha, so the loads of
+        // column k-1 are issued before the products of column k (the factor sits in HBM / Infinity Cache, ~2k cycles away).
+        {
+            constexpr int BT = (BG_NPAD / MF_TS + BG_WAVES - 1) / BG_WAVES;      // tiles per wave and column, at most
+            d4 cur[BT], nxt[BT], lt_cur = d4{0.0, 0.0, 0.0, 0.0}, lt_nxt = lt_cur;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) pa[c] = d4{0.0, 0.0, 0.0, 0.0};
-            bool any = false;
-            for (int i = k + 1 + wave; i < nt; i += BG_WAVES) {
-                const d4 li = mf_img_load(Lt + ((size_t)i * ntw + k) * MF_IMG, lane);   // L_ik[l&15][(l>>4) + 4 s]
+            for (int t = 0; t < BT; ++t) cur[t] = nxt[t] = d4{0.0, 0.0, 0.0, 0.0};
+            if (wave == 0) lt_cur = mf_img_load(LinvTg + (size_t)(nt - 1) * MF_IMG, lane);
+            for (int k = nt - 1; k >= 0; --k) {
+                if (k > 0) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    if (c < ny) pa[c] += li * av[c * BG_NPAD + MF_TS * i + lr];
-                any = true;
-            }
-            if (any) {
+                    for (int t = 0; t < BT; ++t) {
+                        const int i = k + wave + BG_WAVES * t;               // rows of column k-1: i >= k
+                        if (i < nt) nxt[t] = mf_img_load(Lt + ((size_t)i * ntw + (k - 1)) * MF_IMG, lane);
+                    }
+                    if (wave == 0) lt_nxt = mf_img_load(LinvTg + (size_t)(k - 1) * MF_IMG, lane);
+                }
+                d4 pa[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (c < ny) {
-                        const double tot = mf_row_reduce4(pa[c], lr);     // lanes lr = 0, 4, 8, 12 hold components 0..3
-                        if ((lr & 3) == 0) atomicAdd(wv + c * BG_NPAD + MF_TS * k + lg + 4 * (lr >> 2), tot);
+                for (int c = 0; c < 3; ++c) pa[c] = d4{0.0, 0.0, 0.0, 0.0};
+                bool any = false;
+#pragma unroll
+                for (int t = 0; t < BT; ++t) {
+                    const int i = k + 1 + wave + BG_WAVES * t;
+                    if (i < nt) {                                             // cur[t] = L_ik[l&15][(l>>4) + 4 s]
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            if (c < ny) pa[c] += cur[t] * av[c * BG_NPAD + MF_TS * i + lr];
+                        any = true;
                     }
                 }
-            }
-            __syncthreads();
-            if (wave == 0) {
-                const d4 lt = mf_img_load(LinvTg + (size_t)k * MF_IMG, lane);
-                d4 ub = d4{0.0, 0.0, 0.0, 0.0};
-                if (lr < ny) {
+                if (any) {
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const int q = lr * BG_NPAD + MF_TS * k + lg + 4 * q4;
-                        ub[q4] = zv[q] - wv[q];
+                    for (int c = 0; c < 3; ++c) {
+                        if (c < ny) {
+                            const double tot = mf_row_reduce4(pa[c], lr);     // lanes lr = 0, 4, 8, 12 hold components 0..3
+                            if ((lr & 3) == 0) atomicAdd(wv + c * BG_NPAD + MF_TS * k + lg + 4 * (lr >> 2), tot);
+                        }
                     }
                 }
-                const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
-                const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], ub[0], z4, 0, 0, 0);
-                const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[1], ub[1], z4, 0, 0, 0);
-                const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[2], ub[2], z4, 0, 0, 0);
-                const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[3], ub[3], z4, 0, 0, 0);
-                const d4 al = (D0 + D1) + (D2 + D3);   // lanes lr = n < ny: alpha_n[16 k + (l>>4) + 4 r]
-                if (lr < ny) {
+                __syncthreads();
+                if (wave == 0) {
+                    d4 ub = d4{0.0, 0.0, 0.0, 0.0};
+                    if (lr < ny) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) av[lr * BG_NPAD + MF_TS * k + lg + 4 * r] = al[r];
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const int q = lr * BG_NPAD + MF_TS * k + lg + 4 * q4;
+                            ub[q4] = zv[q] - wv[q];
+                        }
+                    }
+                    const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
+                    const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt_cur[0], ub[0], z4, 0, 0, 0);
+                    const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt_cur[1], ub[1], z4, 0, 0, 0);
+                    const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt_cur[2], ub[2], z4, 0, 0, 0);
+                    const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt_cur[3], ub[3], z4, 0, 0, 0);
+                    const d4 al = (D0 + D1) + (D2 + D3);   // lanes lr = n < ny: alpha_n[16 k + (l>>4) + 4 r]
+                    if (lr < ny) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) av[lr * BG_NPAD + MF_TS * k + lg + 4 * r] = al[r];
+                    }
                 }
+                __syncthreads();
+                // rows of column k-1 held in nxt[t] are i = k + wave + W t; as cur[] of the next iteration they must sit at
+                // i = (k-1) + 1 + wave + W t: the same index
+#pragma unroll
+                for (int t = 0; t < BT; ++t) cur[t] = nxt[t];
+                lt_cur = lt_nxt;
             }
-            __syncthreads();
         }
         if (A.alpha_out)
             for (int i = tid; i < n; i += BG_THREADS)
@@ -345,6 +422,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
                 for (int c = 0; c < 3; ++c)
                     if (c < ny) A.alpha_out[(size_t)c * A.n_total + o + i] = av[c * BG_NPAD + i];
 
+        BG_STAMP(3);
         // ---- predictive mean ----
         if (A.xs0 == nullptr && A.grid_sz <= 32) {
             // separable grid: f[py][px] = sum_i Ey[py][i] * (sf alpha_i Ex[px][i]); 32-point chunks dealt to the waves
@@ -420,6 +498,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
                     if (c < ny) fs[(size_t)c * m + p] = s_[c];
             }
         }
+        BG_STAMP(4);
         if (timed_out && lane == 0) flag[0] = 2;
         __syncthreads();
         if (tid == 0 && A.status) A.status[patch] = flag[0] ? GPC_STATUS_NAN : GPC_STATUS_OK;
@@ -477,6 +556,30 @@ int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
     g.slot = big_slot_doubles(g.ntw);
     int waves, npad, per_cu;
     big_shape(a, &waves, &npad, &per_cu);
+    g.stamps = nullptr;
+    struct StampDump {
+        gpc_ctx* ctx; unsigned long long* d; int P, waves;
+        ~StampDump()
+        {
+            if (!d) return;
+            unsigned long long h[BG_NPH * 8];
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+            (void)hipFree(d);
+            static const char* names[BG_NPH] = {"load", "factorisation", "z gather", "backward", "predict", ""};
+            fprintf(stderr, "[GPC_BIG_STAMPS] mean s_memtime ticks per patch, by wave\n");
+            for (int q = 0; q < 5; ++q) {
+                fprintf(stderr, "%-14s", names[q]);
+                for (int w = 0; w < waves; ++w) fprintf(stderr, " %8.0f", (double)h[q * 8 + w] / P);
+                fprintf(stderr, "\n");
+            }
+        }
+    } dump{ctx, nullptr, a.P, waves};
+    if (getenv("GPC_BIG_STAMPS")) {
+        GPC_HIP(ctx, hipMalloc(&g.stamps, sizeof(unsigned long long) * BG_NPH * 8));
+        GPC_HIP(ctx, hipMemsetAsync(g.stamps, 0, sizeof(unsigned long long) * BG_NPH * 8, ctx->stream));
+        dump.d = g.stamps;
+    }
     if (waves == 4) {
         ctx->last_dense_kernel = "dense_mfma_big_w4";
         return big_launch_t<4, 256>(ctx, g, grid);
