@@ -87,8 +87,12 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
     double* LinvC = lds + B_LINV;      // [2][256]
     double* L10 = lds + B_L10;
     double* red = lds + B_RED;
+    double* Hand = red;                // 3 x 256: hand-over of the diagonal-block tiles to wave 0 (the reduction buffer is idle then)
+    int* h0 = flag + 2;                // k + 1 once tile (k, k) of the step is handed over
+    int* h1 = flag + 3;                // k + 1 once tiles (k+1, k), (k+1, k+1) are handed over
     const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
     const unsigned ready_addr = lds0 + (unsigned)(B_FLAG * 8 + 4);     // highest tile column whose L_kk^-1 is published
+    const unsigned h0_addr = lds0 + (unsigned)(B_FLAG * 8 + 8), h1_addr = lds0 + (unsigned)(B_FLAG * 8 + 12);
 
     const DenseArgs& A = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -123,6 +127,8 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
         if (tid == 0) {
             flag[0] = 0;
             flag[1] = -1;
+            flag[2] = 0;
+            flag[3] = 0;
         }
         __syncthreads();
         bool timed_out = false;
@@ -168,51 +174,23 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
             const int k1 = has2 ? k + 1 : k;                               // second column of the pair (== k when absent)
             const double* rowk = Lt + ((size_t)k * ntw) * MF_IMG;          // L_kj, j < k
             const double* rowk1 = Lt + ((size_t)k1 * ntw) * MF_IMG;
+            // Rows k .. nt are dealt round-robin to the WORKER waves 1 .. W-1 (row k + q -> wave 1 + q % (W-1)).  Rows k and
+            // k+1 are the diagonal block: their owners update them like any other row (first pass), then hand the tiles
+            // (k,k), (k+1,k), (k+1,k+1) to wave 0 through LDS instead of solving them.  Wave 0 runs nothing but the serial
+            // chain factor (k,k) -> TRSM (k+1,k) -> update, factor (k+1,k+1), concurrently with the workers' later passes.
+            // (With the diagonal-block updates on wave 0 itself it was the critical path: 3 tile updates per j on one wave.)
+            constexpr int NWK = BG_WAVES - 1;
             if (wave == 0) {
-                // ---- the 2 x 2 diagonal block ----
-                d4 D00, D10 = d4{0.0, 0.0, 0.0, 0.0}, D11 = d4{0.0, 0.0, 0.0, 0.0};
-                BG_INIT_TILE(D00, k, k);
-                if (has2) {
-                    BG_INIT_TILE(D10, k + 1, k);
-                    BG_INIT_TILE(D11, k + 1, k + 1);
-                }
-                if (k > 0) {
-                    d4 da0[3], da1[3];
-#define BG_DLOAD(st, jj)                                                                                             \
-    do {                                                                                                             \
-        da0[st] = mf_img_load(rowk + (size_t)(jj) * MF_IMG, lane);                                                   \
-        da1[st] = mf_img_load(rowk1 + (size_t)(jj) * MF_IMG, lane);                                                  \
-    } while (0)
-#define BG_DUSE(st)                                                                                                  \
-    do {                                                                                                             \
-        D00 = bg_mfma4_neg(da0[st], da0[st], D00);                                                                   \
-        if (has2) {                                                                                                  \
-            D10 = bg_mfma4_neg(da0[st], da1[st], D10);                                                               \
-            D11 = bg_mfma4_neg(da1[st], da1[st], D11);                                                               \
-        }                                                                                                            \
-    } while (0)
-#pragma unroll
-                    for (int st = 0; st < 3; ++st) da0[st] = da1[st] = d4{0.0, 0.0, 0.0, 0.0};
-                    BG_DLOAD(0, 0);
-                    if (k > 1) BG_DLOAD(1, 1);
-                    for (int j = 0; j < k; j += 3) {
-                        if (j + 2 < k) BG_DLOAD(2, j + 2);
-                        BG_DUSE(0);
-                        if (j + 1 < k) {
-                            if (j + 3 < k) BG_DLOAD(0, j + 3);
-                            BG_DUSE(1);
-                        }
-                        if (j + 2 < k) {
-                            if (j + 4 < k) BG_DLOAD(1, j + 4);
-                            BG_DUSE(2);
-                        }
-                    }
-                }
+                timed_out |= !mf_wait_ge(h0_addr, k + 1);
+                const d4 D00 = *reinterpret_cast<const d4*>(Hand + lane * 4);
                 bool ok = mf_diag_factor(D00, rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (!ok && lane == 0) flag[0] = 1;
                 if (ok && has2) {
-                    mf_publish(ready, k);                                  // L_kk^-1 (the others start their first TRSM)
+                    mf_publish(ready, k);                                  // L_kk^-1 (the workers start their first TRSM)
+                    timed_out |= !mf_wait_ge(h1_addr, k + 1);
+                    const d4 D10 = *reinterpret_cast<const d4*>(Hand + 256 + lane * 4);
+                    d4 D11 = *reinterpret_cast<const d4*>(Hand + 512 + lane * 4);
                     const d4 lv = mf_img_load(LinvC, lane);
                     const d4 l10 = BG_TRSM(lv, D10);                       // operand image of L_(k+1)k
                     mf_img_store(Lt + ((size_t)(k + 1) * ntw + k) * MF_IMG, lane, l10);
@@ -223,98 +201,102 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
                     if (!ok && lane == 0) flag[0] = 1;
                 }
                 mf_publish(ready, k1);
-            }
-            // ---- rows r >= k + 2 (and the right-hand-side row nt), dealt to the waves 1, 2, .., 7, 0, 1, .. ----
-            // Wave 0 carries the diagonal block (3 tile updates per j against 2 per row, plus the two serial factorisations):
-            // it takes rows only when there are plenty (>= 3 per wave), otherwise the rows go to the waves 1 .. W-1 alone.
-            const int rows_tot = has2 ? nt - (k + 2) + 1 : 0;              // rows k+2 .. nt
-            const int nwk = (rows_tot >= 3 * BG_WAVES) ? BG_WAVES : BG_WAVES - 1;
-            const int q0 = (wave + BG_WAVES - 1) % BG_WAVES;               // first row of this wave: k + 2 + q0 (wave 0: last slot)
-            const int span = rows_tot - 1 - q0;
-            const int rows_w = (has2 && q0 < nwk) ? (span >= 0 ? span / nwk + 1 : 0) : 0;
-            // a single trailing column has only the right-hand-side row left (k + 1 == nt): wave 1 takes it
-            const int rows_eff = has2 ? rows_w : ((wave == 1 % BG_WAVES) ? 1 : 0);
-            bool stop = false;
-            for (int p0 = 0; (p0 < rows_eff || p0 == 0) && !stop; p0 += BG_RMAX) {
-                const int np = min(BG_RMAX, rows_eff - p0);
-                d4 acc0[BG_RMAX], acc1[BG_RMAX];
-                int rr[BG_RMAX];
+            } else {
+                const int q0 = wave - 1;                                   // first row of this worker: k + q0
+                const int rows_tot = nt - k + 1;                           // rows k .. nt
+                const int rows_w = (rows_tot - 1 - q0 >= 0) ? (rows_tot - 1 - q0) / NWK + 1 : 0;
+                bool stop = false;
+                for (int p0 = 0; (p0 < rows_w || p0 == 0) && !stop; p0 += BG_RMAX) {
+                    const int np = min(BG_RMAX, rows_w - p0);
+                    d4 acc0[BG_RMAX], acc1[BG_RMAX];
+                    int rr[BG_RMAX];
 #pragma unroll
-                for (int t = 0; t < BG_RMAX; ++t) {
-                    rr[t] = has2 ? k + 2 + q0 + nwk * (p0 + t) : nt;
-                    acc0[t] = d4{0.0, 0.0, 0.0, 0.0};
-                    acc1[t] = d4{0.0, 0.0, 0.0, 0.0};
-                    if (t < np) {
-                        BG_INIT_TILE(acc0[t], rr[t], k);
-                        if (has2) BG_INIT_TILE(acc1[t], rr[t], k + 1);
+                    for (int t = 0; t < BG_RMAX; ++t) {
+                        rr[t] = k + q0 + NWK * (p0 + t);
+                        acc0[t] = d4{0.0, 0.0, 0.0, 0.0};
+                        acc1[t] = d4{0.0, 0.0, 0.0, 0.0};
+                        if (t < np) {
+                            BG_INIT_TILE(acc0[t], rr[t], k);
+                            if (has2 && rr[t] != k) BG_INIT_TILE(acc1[t], rr[t], k + 1);     // (k, k+1) is above the diagonal
+                        }
                     }
-                }
-                if (np > 0 && k > 0) {
-                    // three operand stages rotate through the loop (unrolled by 3): while stage s feeds the MFMAs, the loads
-                    // of the next two j are in flight -- the factor tiles come from HBM / the Infinity Cache, ~2k cycles away
-                    d4 sa0[3], sa1[3], sb[3][BG_RMAX];
+                    if (np > 0 && k > 0) {
+                        // three operand stages rotate through the loop (unrolled by 3): while stage s feeds the MFMAs, the
+                        // loads of the next two j are in flight -- the factor tiles come from HBM / Infinity Cache
+                        d4 sa0[3], sa1[3], sb[3][BG_RMAX];
 #define BG_LOAD_STAGE(st, jj)                                                                                        \
     do {                                                                                                             \
-        sa0[st] = mf_img_load(rowk + (size_t)(jj) * MF_IMG, lane);                                               \
-        sa1[st] = mf_img_load(rowk1 + (size_t)(jj) * MF_IMG, lane);                                              \
+        sa0[st] = mf_img_load(rowk + (size_t)(jj) * MF_IMG, lane);                                                   \
+        sa1[st] = mf_img_load(rowk1 + (size_t)(jj) * MF_IMG, lane);                                                  \
         _Pragma("unroll") for (int t = 0; t < BG_RMAX; ++t)                                                          \
-            if (t < np) sb[st][t] = mf_img_load(Lt + ((size_t)rr[t] * ntw) * MF_IMG + (size_t)(jj) * MF_IMG, lane); \
+            if (t < np) sb[st][t] = mf_img_load(Lt + ((size_t)rr[t] * ntw + (jj)) * MF_IMG, lane);                   \
     } while (0)
 #define BG_USE_STAGE(st)                                                                                             \
     do {                                                                                                             \
         _Pragma("unroll") for (int t = 0; t < BG_RMAX; ++t) {                                                        \
             if (t < np) {                                                                                            \
                 acc0[t] = bg_mfma4_neg(sa0[st], sb[st][t], acc0[t]);                                                 \
-                if (has2) acc1[t] = bg_mfma4_neg(sa1[st], sb[st][t], acc1[t]);                                       \
+                if (has2 && rr[t] != k) acc1[t] = bg_mfma4_neg(sa1[st], sb[st][t], acc1[t]);                         \
             }                                                                                                        \
         }                                                                                                            \
     } while (0)
 #pragma unroll
-                    for (int st = 0; st < 3; ++st) {
-                        sa0[st] = d4{0.0, 0.0, 0.0, 0.0};
-                        sa1[st] = sa0[st];
+                        for (int st = 0; st < 3; ++st) {
+                            sa0[st] = d4{0.0, 0.0, 0.0, 0.0};
+                            sa1[st] = sa0[st];
 #pragma unroll
-                        for (int t = 0; t < BG_RMAX; ++t) sb[st][t] = sa0[st];
-                    }
-                    BG_LOAD_STAGE(0, 0);
-                    if (k > 1) BG_LOAD_STAGE(1, 1);
-                    for (int j = 0; j < k; j += 3) {
-                        if (j + 2 < k) BG_LOAD_STAGE(2, j + 2);
-                        BG_USE_STAGE(0);
-                        if (j + 1 < k) {
-                            if (j + 3 < k) BG_LOAD_STAGE(0, j + 3);
-                            BG_USE_STAGE(1);
+                            for (int t = 0; t < BG_RMAX; ++t) sb[st][t] = sa0[st];
                         }
-                        if (j + 2 < k) {
-                            if (j + 4 < k) BG_LOAD_STAGE(1, j + 4);
-                            BG_USE_STAGE(2);
-                        }
-                    }
-                }
-                // L_rk = T_rk L_kk^-T;  T_r(k+1) -= L_rk L_(k+1)k^T;  L_r(k+1) = T_r(k+1) L_(k+1)(k+1)^-T
-                timed_out |= !mf_wait_ge(ready_addr, k);
-                if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { stop = true; continue; }
-                if (np > 0) {
-                    const d4 lv0 = mf_img_load(LinvC, lane);
-#pragma unroll
-                    for (int t = 0; t < BG_RMAX; ++t) {
-                        if (t < np) {
-                            acc0[t] = BG_TRSM(lv0, acc0[t]);
-                            mf_img_store(Lt + ((size_t)rr[t] * ntw + k) * MF_IMG, lane, acc0[t]);
+                        BG_LOAD_STAGE(0, 0);
+                        if (k > 1) BG_LOAD_STAGE(1, 1);
+                        for (int j = 0; j < k; j += 3) {
+                            if (j + 2 < k) BG_LOAD_STAGE(2, j + 2);
+                            BG_USE_STAGE(0);
+                            if (j + 1 < k) {
+                                if (j + 3 < k) BG_LOAD_STAGE(0, j + 3);
+                                BG_USE_STAGE(1);
+                            }
+                            if (j + 2 < k) {
+                                if (j + 4 < k) BG_LOAD_STAGE(1, j + 4);
+                                BG_USE_STAGE(2);
+                            }
                         }
                     }
-                }
-                if (has2) {
-                    timed_out |= !mf_wait_ge(ready_addr, k + 1);
+                    // diagonal-block rows go to wave 0 (first pass only: q = 0 -> wave 1, q = 1 -> wave 2, both t = 0)
+                    if (p0 == 0 && np > 0 && rr[0] == k) {
+                        *reinterpret_cast<d4*>(Hand + lane * 4) = acc0[0];
+                        mf_publish(h0, k + 1);
+                    }
+                    if (p0 == 0 && np > 0 && has2 && rr[0] == k + 1) {
+                        *reinterpret_cast<d4*>(Hand + 256 + lane * 4) = acc0[0];
+                        *reinterpret_cast<d4*>(Hand + 512 + lane * 4) = acc1[0];
+                        mf_publish(h1, k + 1);
+                    }
+                    // L_rk = T_rk L_kk^-T;  T_r(k+1) -= L_rk L_(k+1)k^T;  L_r(k+1) = T_r(k+1) L_(k+1)(k+1)^-T
+                    timed_out |= !mf_wait_ge(ready_addr, k);
                     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { stop = true; continue; }
                     if (np > 0) {
-                        const d4 lv1 = mf_img_load(LinvC + 256, lane);
-                        const d4 a10 = mf_img_load(L10, lane);
+                        const d4 lv0 = mf_img_load(LinvC, lane);
 #pragma unroll
                         for (int t = 0; t < BG_RMAX; ++t) {
-                            if (t < np) {
-                                acc1[t] = bg_mfma4_neg(a10, acc0[t], acc1[t]);
-                                mf_img_store(Lt + ((size_t)rr[t] * ntw + k + 1) * MF_IMG, lane, BG_TRSM(lv1, acc1[t]));
+                            if (t < np && rr[t] > k1) {
+                                acc0[t] = BG_TRSM(lv0, acc0[t]);
+                                mf_img_store(Lt + ((size_t)rr[t] * ntw + k) * MF_IMG, lane, acc0[t]);
+                            }
+                        }
+                    }
+                    if (has2) {
+                        timed_out |= !mf_wait_ge(ready_addr, k + 1);
+                        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { stop = true; continue; }
+                        if (np > 0) {
+                            const d4 lv1 = mf_img_load(LinvC + 256, lane);
+                            const d4 a10 = mf_img_load(L10, lane);
+#pragma unroll
+                            for (int t = 0; t < BG_RMAX; ++t) {
+                                if (t < np && rr[t] > k1) {
+                                    acc1[t] = bg_mfma4_neg(a10, acc0[t], acc1[t]);
+                                    mf_img_store(Lt + ((size_t)rr[t] * ntw + k + 1) * MF_IMG, lane, BG_TRSM(lv1, acc1[t]));
+                                }
                             }
                         }
                     }
