@@ -160,6 +160,38 @@ def test_dense_edge_cases(gp, oracle):
     assert np.all(np.isnan(f[0])) and np.all(np.isnan(al[0, :3])) and np.all(np.isfinite(f[1]))
 
 
+def test_dense_big_kernel_edge_cases(gp, oracle):
+    """The tiled left-looking kernel (n_max > 256) on a batch that mixes an empty patch, a tiny patch, a patch that is not
+    SPD (duplicated point, zero noise: the failing pivot sits in a late tile column) and full-size patches; grid and
+    point-wise entries, ny = 3."""
+    capi, ctx = gp
+    res, sz = 0.15, 8
+    xs0, xs1 = oracle.grid(res, sz)
+    rng = np.random.default_rng(5)
+    counts = [300, 0, 5, 290, 513, 17]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    N = int(off[-1])
+    x0, x1 = rng.uniform(-res / 2, res / 2, N), rng.uniform(-res / 2, res / 2, N)
+    y = rng.normal(0, 0.01, (3, N))
+    # patch 3: point 280 duplicates point 11 -> with zero noise the Gram matrix is singular at pivot 280 (tile column 17)
+    x0[off[3] + 280], x1[off[3] + 280] = x0[off[3] + 11], x1[off[3] + 11]
+    # l = 4 mm against a ~9 mm point spacing: K is far from singular without noise, except for the duplicate
+    p0 = capi.default_params_dense(noise=0.0, sigmaf_sq=1.0, l_sq=0.004 ** 2)
+    po = oracle.dense_params(1.0, 0.004 ** 2, 0.0)
+    f, _, st, al = ctx.dense_fit_predict(p0, off, x0, x1, y, xs0, xs1, want_alpha=True)
+    assert ctx.last_dense_kernel() == "dense_mfma_big"
+    fo, _, so, ao = oracle.dense_fit_predict_batch(po, off, x0, x1, y, xs0, xs1, want_alpha=True)
+    assert st.tolist() == so.tolist() == [0, 0, 0, 1, 0, 0]
+    assert np.all(np.isnan(f[3])) and np.all(f[1] == 0)
+    good = [0, 2, 4, 5]
+    for i in good:
+        assert np.max(np.abs(f[i] - fo[i])) <= 1e-8 * max(np.max(np.abs(fo[i])), 1e-12), i
+    f2, st2 = ctx.dense_fit_predict_grid(p0, off, x0, x1, y, res, sz)
+    assert st2.tolist() == st.tolist()
+    for i in good:
+        assert np.max(np.abs(f2[i] - f[i])) <= 1e-9 * max(np.max(np.abs(f[i])), 1e-12)
+
+
 def test_dense_argument_errors(gp):
     capi, ctx = gp
     xs0, xs1 = synth.grid(0.15, 4)
