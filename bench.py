@@ -112,8 +112,9 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("GPC_BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     P, n, res, sz = args.patches, args.points, 0.15, 20
@@ -123,48 +124,61 @@ def main():
     N = int(off[-1])
     t = lambda a: torch.from_numpy(a).to(dev)
     d_off, d_x0, d_x1, d_y = t(off), t(x0), t(x1), t(y)
-    f_star = torch.empty((P, 1, m), dtype=torch.float64, device=dev)
+    # two output buffers: with N > 1 the all-gather of step k runs on RCCL's stream while the kernel of step k+1 computes
+    use_dist = world > 1 or os.environ.get("GPC_BENCH_FORCE_DIST") == "1"      # the latter: 1-rank rehearsal of the N > 1 path
+    f_bufs = [torch.empty((P, 1, m), dtype=torch.float64, device=dev) for _ in range(2 if use_dist else 1)]
     status = torch.empty((P,), dtype=torch.int32, device=dev)
-    gathered = torch.empty((world * P, 1, m), dtype=torch.float64, device=dev) if world > 1 else None
+    g_bufs = [torch.empty((world * P, 1, m), dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
+    works = [None, None]
 
     ctx = capi.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # kernel, events and collective share one stream
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # kernel and events share torch's current stream
     prm = capi.default_params_dense()                         # gaussian_process defaults, reference double-noise (F5)
 
-    def step(ev=None):
+    def step(k, ev=None):
+        b = k & 1 if use_dist else 0
+        if use_dist and works[b] is not None:
+            works[b].wait()                                   # the gather that still reads this buffer (stream-level wait)
         if ev is not None:
             ev[0].record()
-        ctx.dense_fit_predict_grid_dev(prm, P, d_off, n, N, d_x0, d_x1, d_y, 1, res, sz, f_star, status=status)
+        ctx.dense_fit_predict_grid_dev(prm, P, d_off, n, N, d_x0, d_x1, d_y, 1, res, sz, f_bufs[b], status=status)
         if ev is not None:
             ev[1].record()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, f_star)
+        if use_dist:
+            works[b] = dist.all_gather_into_tensor(g_bufs[b], f_bufs[b], async_op=True)
 
     def fence():
+        if use_dist:
+            for w in works:
+                if w is not None:
+                    w.wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(events[k])
+        step(k, events[k])
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    last = (args.steps - 1) & 1 if use_dist and args.steps > 0 else 0
+    f_star = f_bufs[last]
+    gathered = g_bufs[last] if use_dist else None
 
     st = status.cpu().numpy()
     f_host = f_star.cpu().numpy()
     ok = bool(np.all(st == 0)) and bool(np.all(np.isfinite(f_host)))
-    if world > 1:
+    if gathered is not None:
         mine = gathered[rank * P:(rank + 1) * P].cpu().numpy()
         ok = ok and bool(np.array_equal(mine, f_host))
 
@@ -208,7 +222,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / rec["value"]
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
