@@ -117,20 +117,40 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
         }
         const int nt = __builtin_amdgcn_readfirstlane((n + MF_TS - 1) / MF_TS);
         unsigned long long t_prev_ = g.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-        for (int i = tid; i < BG_NPAD; i += BG_THREADS) {
-            const bool live = i < n;
-            px0[i] = live ? A.x0[o + i] : 0.0;
-            px1[i] = live ? A.x1[o + i] : 0.0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) wv[c * BG_NPAD + i] = 0.0;
-        }
+        unsigned long long* ext_bits = reinterpret_cast<unsigned long long*>(lds + B_FLAG + 3);   // max-norm extent, as bits
         if (tid == 0) {
             flag[0] = 0;
             flag[1] = -1;
             flag[2] = 0;
             flag[3] = 0;
+            *ext_bits = 0ull;
         }
         __syncthreads();
+        // extent of the patch around its first point (max-norm): bounds every kernel argument of this patch, see below
+        const double xo0 = A.x0[o], xo1 = A.x1[o];
+        double dev = 0.0;
+        for (int i = tid; i < BG_NPAD; i += BG_THREADS) {
+            const bool live = i < n;
+            const double q0 = live ? A.x0[o + i] : xo0, q1 = live ? A.x1[o + i] : xo1;
+            dev = __builtin_fmax(dev, __builtin_fmax(__builtin_fabs(q0 - xo0), __builtin_fabs(q1 - xo1)));
+            px0[i] = live ? q0 : 0.0;
+            px1[i] = live ? q1 : 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wv[c * BG_NPAD + i] = 0.0;
+        }
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) dev = __builtin_fmax(dev, __shfl_xor(dev, o_, 64));
+        if (lane == 0) atomicMax(ext_bits, (unsigned long long)__double_as_longlong(dev));   // non-negative doubles order like their bits
+        __syncthreads();
+        // Small-argument regime (see dense_mfma.hip): |c| d^2 <= 2^-5 for every Gram argument / every separable grid factor
+        // -> the degree-7 polynomial instead of the table-driven exponential.  Wave-uniform; false for NaN / inf extents.
+        bool small_gram, small_grid;
+        {
+            const double r = __longlong_as_double((long long)*ext_bits);
+            const double bq = 0.5 * A.grid_res + __builtin_fmax(__builtin_fabs(xo0), __builtin_fabs(xo1)) + r;
+            small_gram = __builtin_amdgcn_readfirstlane((int)(-cexp * (8.0 * r * r) <= GPC_EXP_SMALL_MAX)) != 0;
+            small_grid = __builtin_amdgcn_readfirstlane((int)(-cexp * (bq * bq) <= GPC_EXP_SMALL_MAX)) != 0;
+        }
         bool timed_out = false;
         bool bad = false;
         BG_STAMP(0);
@@ -149,7 +169,8 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
             const double xi0_ = px0[pi_], xi1_ = px1[pi_];                                                           \
             _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
                 const int pj_ = MF_TS * (kc_) + lg + 4 * q_;                                                         \
-                double v_ = gpc_rbf_neg(sf, cexp, xi0_, xi1_, px0[pj_], px1[pj_], T);                                \
+                double v_ = small_gram ? gpc_rbf_small(sf, cexp, xi0_, xi1_, px0[pj_], px1[pj_])                      \
+                                       : gpc_rbf_neg(sf, cexp, xi0_, xi1_, px0[pj_], px1[pj_], T);                   \
                 if (pi_ == pj_) {                                                                                    \
                     v_ += noise;                              /* covariance_matrix(..., training)  :59-61 */         \
                     if (A.prm.ref_double_noise) v_ += noise;  /* C.diagonal() += sigman_sq        :21 */             \
@@ -224,20 +245,36 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
                         // three operand stages rotate through the loop (unrolled by 3): while stage s feeds the MFMAs, the
                         // loads of the next two j are in flight -- the factor tiles come from HBM / Infinity Cache
                         d4 sa0[3], sa1[3], sb[3][BG_RMAX];
-#define BG_LOAD_STAGE(st, jj)                                                                                        \
+                        // NPC (rows in the pass) is a compile-time constant inside each copy of the loop and the loads are
+                        // UNCONDITIONAL (index clamped to k-1, a redundant re-read at the tail): with loads under runtime
+                        // conditions hipcc cannot count the outstanding ones and falls back to s_waitcnt vmcnt(0) in every
+                        // iteration, i.e. no prefetch at all
+#define BG_LOAD_STAGE(st, jj, NPC)                                                                                   \
     do {                                                                                                             \
         sa0[st] = mf_img_load(rowk + (size_t)(jj) * MF_IMG, lane);                                                   \
         sa1[st] = mf_img_load(rowk1 + (size_t)(jj) * MF_IMG, lane);                                                  \
-        _Pragma("unroll") for (int t = 0; t < BG_RMAX; ++t)                                                          \
-            if (t < np) sb[st][t] = mf_img_load(Lt + ((size_t)rr[t] * ntw + (jj)) * MF_IMG, lane);                   \
+        _Pragma("unroll") for (int t = 0; t < NPC; ++t)                                                              \
+            sb[st][t] = mf_img_load(Lt + ((size_t)rr[t] * ntw + (jj)) * MF_IMG, lane);                               \
     } while (0)
-#define BG_USE_STAGE(st)                                                                                             \
+#define BG_USE_STAGE(st, NPC)                                                                                        \
     do {                                                                                                             \
-        _Pragma("unroll") for (int t = 0; t < BG_RMAX; ++t) {                                                        \
-            if (t < np) {                                                                                            \
-                acc0[t] = bg_mfma4_neg(sa0[st], sb[st][t], acc0[t]);                                                 \
-                if (has2 && rr[t] != k) acc1[t] = bg_mfma4_neg(sa1[st], sb[st][t], acc1[t]);                         \
-            }                                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < NPC; ++t) {                                                            \
+            acc0[t] = bg_mfma4_neg(sa0[st], sb[st][t], acc0[t]);                                                     \
+            if (has2 && rr[t] != k) acc1[t] = bg_mfma4_neg(sa1[st], sb[st][t], acc1[t]);                             \
+        }                                                                                                            \
+    } while (0)
+#define BG_UPDATE_LOOP(NPC)                                                                                          \
+    do {                                                                                                             \
+        const int kl = k - 1;                                                                                        \
+        BG_LOAD_STAGE(0, 0, NPC);                                                                                    \
+        BG_LOAD_STAGE(1, min(1, kl), NPC);                                                                           \
+        for (int j = 0; j < k; j += 3) {                                                                             \
+            BG_LOAD_STAGE(2, min(j + 2, kl), NPC);                                                                   \
+            BG_USE_STAGE(0, NPC);                                                                                    \
+            BG_LOAD_STAGE(0, min(j + 3, kl), NPC);                                                                   \
+            if (j + 1 < k) BG_USE_STAGE(1, NPC);                                                                     \
+            BG_LOAD_STAGE(1, min(j + 4, kl), NPC);                                                                   \
+            if (j + 2 < k) BG_USE_STAGE(2, NPC);                                                                     \
         }                                                                                                            \
     } while (0)
 #pragma unroll
@@ -247,20 +284,9 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
 #pragma unroll
                             for (int t = 0; t < BG_RMAX; ++t) sb[st][t] = sa0[st];
                         }
-                        BG_LOAD_STAGE(0, 0);
-                        if (k > 1) BG_LOAD_STAGE(1, 1);
-                        for (int j = 0; j < k; j += 3) {
-                            if (j + 2 < k) BG_LOAD_STAGE(2, j + 2);
-                            BG_USE_STAGE(0);
-                            if (j + 1 < k) {
-                                if (j + 3 < k) BG_LOAD_STAGE(0, j + 3);
-                                BG_USE_STAGE(1);
-                            }
-                            if (j + 2 < k) {
-                                if (j + 4 < k) BG_LOAD_STAGE(1, j + 4);
-                                BG_USE_STAGE(2);
-                            }
-                        }
+                        static_assert(BG_RMAX == 2, "one copy of the update loop per possible row count");
+                        if (np == 2) BG_UPDATE_LOOP(2);
+                        else BG_UPDATE_LOOP(1);
                     }
                     // diagonal-block rows go to wave 0 (first pass only: q = 0 -> wave 1, q = 1 -> wave 2, both t = 0)
                     if (p0 == 0 && np > 0 && rr[0] == k) {
@@ -428,8 +454,13 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
                             const double gq = res * (((double)pq + 0.5) / (double)sz - 0.5);
                             const bool on = (pq < sz) && (i < n);
                             const double dy = gq - px1[i], dx = gq - px0[i];
-                            ea[h] = on ? gpc_exp_neg(cexp * (dy * dy), T) : 0.0;   // Ey[py = pq][i]
-                            eb[h] = on ? gpc_exp_neg(cexp * (dx * dx), T) * al : 0.0;   // Ex[px = pq][i] * sf alpha_i
+                            if (small_grid) {
+                                ea[h] = on ? gpc_exp_small(cexp * (dy * dy)) : 0.0;         // Ey[py = pq][i]
+                                eb[h] = on ? gpc_exp_small(cexp * (dx * dx)) * al : 0.0;    // Ex[px = pq][i] * sf alpha_i
+                            } else {
+                                ea[h] = on ? gpc_exp_neg(cexp * (dy * dy), T) : 0.0;
+                                eb[h] = on ? gpc_exp_neg(cexp * (dx * dx), T) * al : 0.0;
+                            }
                         }
 #pragma unroll
                         for (int nl = 0; nl < 2; ++nl)
