@@ -354,6 +354,7 @@ struct SpPredParams {
     gpc_params prm;
     double c_exp;
     int P, ny, ld, m, conf;
+    int fast;   // LDS holds a second [ld][SP_PC] buffer: V = C K by sp_ck_chunk
     const double *xs0, *xs1;
     const double *alpha, *C, *BV;
     const int32_t* b;
@@ -363,6 +364,75 @@ struct SpPredParams {
 };
 
 #define SP_PC 32   // grid points per chunk of the sigma path
+
+// V = C K for a chunk of SP_PC = 32 points on the MFMA pipe: C (b x b, global, column-major) times K (b x 32, LDS).
+// v_mfma_f64_16x16x4_f64 with M = 16 rows of C, N = 16 points, K = 4 columns of C per instruction: the A operand of lane l
+// is C[i0 + (l & 15)][j0 + (l >> 4)] (one 8-byte global load per lane, 16 contiguous rows per column), the B operand is
+// K[j0 + (l >> 4)][p0 + (l & 15)] (one conflict-free LDS read).  Wave w owns the row tiles w, w+4, w+8, w+12 for both point
+// tiles (8 accumulators); the loads of the next K-step are issued before the MFMAs of the current one, unconditionally
+// (clamped addresses, masked values).  The result goes to LDS as Vc[row][point].  1300 MFMAs per chunk at b = 200.
+// (The first version had every (point, column-group) thread walk its own columns of C with one broadcast global load and one
+// LDS read per FMA: 1 TFLOP/s; a register-tiled VALU version was LDS-latency-bound with one wave per SIMD: 2.5 TFLOP/s.)
+typedef double sp_d4 __attribute__((ext_vector_type(4)));
+#define SP_RT 4   // row tiles per wave (4 waves x 4 x 16 rows = 256 = GPC_MAX_BV)
+__device__ static inline void sp_ck_chunk(const double* __restrict__ Cg, int ld, int b, const double* Kc, double* Vc)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int nrt = (b + 15) >> 4;
+    sp_d4 acc[SP_RT][2];
+#pragma unroll
+    for (int t = 0; t < SP_RT; ++t) acc[t][0] = acc[t][1] = sp_d4{0.0, 0.0, 0.0, 0.0};
+    int rowc[SP_RT];       // clamped row of this lane in tile t
+    bool rowok[SP_RT];
+#pragma unroll
+    for (int t = 0; t < SP_RT; ++t) {
+        const int i = 16 * (wave + 4 * t) + lr;
+        rowok[t] = i < b;
+        rowc[t] = min(i, b - 1);
+    }
+    double an[SP_RT];
+    {
+        const int jc = min(lg, b - 1);
+#pragma unroll
+        for (int t = 0; t < SP_RT; ++t) an[t] = Cg[rowc[t] + (size_t)jc * ld];
+    }
+    for (int j0 = 0; j0 < b; j0 += 4) {
+        const bool jok = j0 + lg < b;
+        double ac[SP_RT];
+#pragma unroll
+        for (int t = 0; t < SP_RT; ++t) ac[t] = (jok && rowok[t]) ? an[t] : 0.0;
+        {
+            const int jn = min(j0 + 4 + lg, b - 1);
+#pragma unroll
+            for (int t = 0; t < SP_RT; ++t) an[t] = Cg[rowc[t] + (size_t)jn * ld];
+        }
+        const int jl = min(j0 + lg, b - 1);
+        const double b0 = jok ? Kc[jl * SP_PC + lr] : 0.0;
+        const double b1 = jok ? Kc[jl * SP_PC + 16 + lr] : 0.0;
+#pragma unroll
+        for (int t = 0; t < SP_RT; ++t) {
+            if (wave + 4 * t < nrt) {     // wave-uniform
+                acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], b0, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], b1, acc[t][1], 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout: lane l, register r = V[i0 + (l >> 4) + 4 r][p0 + (l & 15)]
+#pragma unroll
+    for (int t = 0; t < SP_RT; ++t) {
+        if (wave + 4 * t < nrt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * (wave + 4 * t) + lg + 4 * r;
+                if (i < b) {
+                    Vc[i * SP_PC + lr] = acc[t][0][r];
+                    Vc[i * SP_PC + 16 + lr] = acc[t][1][r];
+                }
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(SP_THREADS) void sparse_predict_kernel(SpPredParams A)
 {
@@ -375,6 +445,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_predict_kernel(SpPredParams
     int* clamp = reinterpret_cast<int*>(al + 3 * ld);   // 2 doubles of room
     double* racc = al + 3 * ld + 2;                // [8][SP_PC]
     double* Kc = racc + 8 * SP_PC;                 // [ld][SP_PC]   (sigma path only; LDS is sized for it only then)
+    double* Vc = Kc + (size_t)ld * SP_PC;          // [ld][SP_PC]   (A.fast only)
     gpc_exp_table_init(T);
     const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise;
 
@@ -411,12 +482,18 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_predict_kernel(SpPredParams
                     Kc[i * SP_PC + pp] = (pp < pc) ? gpc_rbf(sf, A.c_exp, A.xs0[p0 + pp], A.xs1[p0 + pp], bv[2 * i], bv[2 * i + 1], T) : 0.0;
                 }
                 __syncthreads();
+                if (A.fast) {
+                    sp_ck_chunk(Cg, ld, b, Kc, Vc);
+                    __syncthreads();
+                }
                 const int pp = tid & (SP_PC - 1), ig = tid / SP_PC;   // 8 row groups
                 double acc = 0.0;
                 for (int j = ig; j < b; j += SP_THREADS / SP_PC) {
-                    // (k^T C)_j = sum_i k_i C(i,j)   (:330, evaluated as (k^T C) k)
+                    // (C k)_j  (:330; C is symmetric)
                     double t = 0.0;
-                    for (int i = 0; i < b; ++i) t += Kc[i * SP_PC + pp] * Cg[i + (size_t)j * ld];
+                    if (A.fast) t = Vc[j * SP_PC + pp];
+                    else
+                        for (int i = 0; i < b; ++i) t += Kc[i * SP_PC + pp] * Cg[i + (size_t)j * ld];
                     acc += t * Kc[j * SP_PC + pp];
                 }
                 racc[ig * SP_PC + pp] = acc;
@@ -458,6 +535,7 @@ struct SpLikParams {
     gpc_params prm;
     double c_exp;
     int P, ny, ld, n_total;
+    int fast;   // LDS holds a second [ld][SP_PC] buffer: V = C K by sp_ck_chunk
     const int32_t* off;
     const double *x0, *x1, *y;
     const double *alpha, *C, *BV;
@@ -476,6 +554,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_likelihood_kernel(SpLikPara
     double* al = bv + 2 * ld;                      // 3*ld
     double* racc = al + 3 * ld;                    // [SP_NQ][8][SP_PC]
     double* Kc = racc + SP_NQ * 8 * SP_PC;         // [ld][SP_PC]
+    double* Vc = Kc + (size_t)ld * SP_PC;          // [ld][SP_PC]   (A.fast only)
     gpc_exp_table_init(T);
     const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, inv_l = 1.0 / A.prm.l_sq;
 
@@ -497,6 +576,10 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_likelihood_kernel(SpLikPara
                 Kc[i * SP_PC + pp] = (pp < pc) ? gpc_rbf(sf, A.c_exp, A.x0[o + p0 + pp], A.x1[o + p0 + pp], bv[2 * i], bv[2 * i + 1], T) : 0.0;
             }
             __syncthreads();
+            if (A.fast) {
+                sp_ck_chunk(Cg, ld, b, Kc, Vc);
+                __syncthreads();
+            }
             const int pp = tid & (SP_PC - 1), ig = tid / SP_PC;   // 8 row groups
             const bool live = pp < pc;
             const double q0 = live ? A.x0[o + p0 + pp] : 0.0, q1 = live ? A.x1[o + p0 + pp] : 0.0;
@@ -505,7 +588,9 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_likelihood_kernel(SpLikPara
             for (int q = 0; q < SP_NQ; ++q) acc[q] = 0.0;
             for (int j = ig; j < b; j += SP_THREADS / SP_PC) {
                 double t = 0.0;                                   // v_j = (C k)_j, C symmetric
-                for (int i = 0; i < b; ++i) t += Kc[i * SP_PC + pp] * Cg[i + (size_t)j * ld];
+                if (A.fast) t = Vc[j * SP_PC + pp];
+                else
+                    for (int i = 0; i < b; ++i) t += Kc[i * SP_PC + pp] * Cg[i + (size_t)j * ld];
                 const double kj = Kc[j * SP_PC + pp];
                 const double g0 = -(q0 - bv[2 * j]) * kj * inv_l, g1 = -(q1 - bv[2 * j + 1]) * kj * inv_l;   // k_dx row j
                 acc[0] += t * kj;
@@ -565,10 +650,13 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_likelihood_kernel(SpLikPara
 // ------------------------------------------------------------------------------------------------ host side
 
 static size_t sp_add_lds(int ld) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (ld + 1) + 8 * ld); }
-static size_t sp_lik_lds(int ld) { return sizeof(double) * (size_t)(64 + 5 * ld + SP_NQ * 8 * SP_PC + (size_t)ld * SP_PC); }
-static size_t sp_pred_lds(int ld, bool sigma)
+static size_t sp_lik_lds(int ld, bool fast)
 {
-    return sizeof(double) * (size_t)(64 + 5 * ld + (sigma ? (size_t)ld * SP_PC : 0) + 8 * SP_PC + 2);
+    return sizeof(double) * (size_t)(64 + 5 * ld + SP_NQ * 8 * SP_PC + (size_t)ld * SP_PC * (fast ? 2 : 1));
+}
+static size_t sp_pred_lds(int ld, bool sigma, bool fast)
+{
+    return sizeof(double) * (size_t)(64 + 5 * ld + (sigma ? (size_t)ld * SP_PC * (fast ? 2 : 1) : 0) + 8 * SP_PC + 2);
 }
 
 extern "C" {
@@ -684,7 +772,8 @@ int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double
     A.P = g->P; A.ny = g->ny; A.ld = g->ld; A.m = m; A.conf = conf;
     A.xs0 = xs0; A.xs1 = xs1; A.alpha = g->alpha; A.C = g->C; A.BV = g->BV; A.b = g->b;
     A.f_star = f_star; A.sigma = sigma; A.status_out = status; A.stat = g->stat;
-    const size_t lds = sp_pred_lds(g->ld, sigma != nullptr);
+    A.fast = (sigma != nullptr && sp_pred_lds(g->ld, true, true) <= 160u * 1024u) ? 1 : 0;
+    const size_t lds = sp_pred_lds(g->ld, sigma != nullptr, A.fast != 0);
     static bool attr_set = false;
     if (!attr_set) {
         GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_predict_kernel),
@@ -718,7 +807,8 @@ int gpc_sparse_likelihood_dev(gpc_sparse* g, const int32_t* off, int n_total, co
     A.off = off; A.x0 = x0; A.x1 = x1; A.y = y;
     A.alpha = g->alpha; A.C = g->C; A.BV = g->BV; A.b = g->b;
     A.dX = dX; A.l = l;
-    const size_t lds = sp_lik_lds(g->ld);
+    A.fast = (sp_lik_lds(g->ld, true) <= 160u * 1024u) ? 1 : 0;
+    const size_t lds = sp_lik_lds(g->ld, A.fast != 0);
     static bool attr_set = false;
     if (!attr_set) {
         GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_likelihood_kernel),
