@@ -63,6 +63,10 @@ static inline int gpc_ws_reserve(gpc_ctx* ctx, size_t bytes)
     }
     GPC_HIP(ctx, hipMalloc(&ctx->ws, bytes));
     ctx->ws_bytes = bytes;
+    // recycled device memory holds arbitrary bit patterns; the kernels write every workspace element before they use it,
+    // but their (clamped, unconditional) prefetches may touch elements they never consume: keep those reads free of
+    // signalling patterns and the results independent of what ran before
+    GPC_HIP(ctx, hipMemsetAsync(ctx->ws, 0, bytes, ctx->stream));
     return GPC_OK;
 }
 
