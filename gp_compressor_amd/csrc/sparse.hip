@@ -132,6 +132,100 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
     return nb;
 }
 
+// Full update (sparse_gp.hpp:164-203) FUSED with the capacity deletion that must follow it when the basis is full
+// (:206-223 -> delete_bv :252-295): the rank-1 growth C' = [C 0; 0 0] + r s s^T, Q' = [Q 0; 0 0] + e e^T / gamma and the
+// rank-2 downdate of delete_bv touch every element of C and Q; run back to back they read and write both matrices twice
+// (3.2 MB per point at b = 200, and the add path is HBM-bound).  Here the deletion candidate is scored on the updated
+// diagonals, the two columns delete_bv needs (loc and the new last one) are formed from the OLD matrices plus the
+// rank-1 terms, and one pass writes the final C and Q.  Every element goes through the same floating-point operations
+// in the same order as the two-pass form, so the result is the same to the last bit; only the intermediate (b+1) x (b+1)
+// matrices never reach memory.  b == capacity on entry and on return.
+__device__ static int sp_full_update_delete(const SpState& S, int b, double rr, double gamma, const double* qv, double px0, double px1,
+                                            int field_bug, const double* ck, double* eh, double* sv, double* Cstar, double* Qstar,
+                                            double* Crep, double* Qrep, double* anew, double* sval, int* sidx)
+{
+    const int tid = threadIdx.x, ld = S.ld, ny = S.ny, last = b;
+    const double ig = (double)1.0f / gamma;
+    for (int i = tid; i <= b; i += SP_THREADS) {
+        const double si = (i < b) ? ck[i] : (double)1.0f;
+        sv[i] = si;
+        if (i == b) eh[b] = (double)(-1.0f);
+        for (int c = 0; c < ny; ++c) {
+            const double a0 = (i < b) ? S.alpha[c * ld + i] : 0.0;
+            anew[c * ld + i] = a0 + qv[c] * si;
+        }
+    }
+    __syncthreads();
+    // capacity deletion candidate on the updated state (:206-223): argmin |alpha_i|^2 / (Q_ii + C_ii), first index wins ties
+    double best = 0.0;
+    int loc = 0x7fffffff;
+    bool have = false;
+    for (int i = tid; i <= b; i += SP_THREADS) {
+        double a2 = 0.0;
+        for (int c = 0; c < ny; ++c) { const double a = anew[c * ld + i]; a2 += a * a; }
+        const double c0 = (i < b) ? S.C[i + (size_t)i * ld] : 0.0, q0 = (i < b) ? S.Q[i + (size_t)i * ld] : 0.0;
+        const double cd = c0 + (rr * sv[i]) * sv[i], qd = q0 + (ig * eh[i]) * eh[i];
+        const double score = a2 / (qd + cd);
+        if (!have || score < best) { best = score; loc = i; have = true; }
+    }
+    if (!have) best = __builtin_inf();
+    sp_block_argmin(best, loc, sval, sidx);
+    if (loc < 0 || loc > b) loc = 0;          // all-NaN scores: the reference keeps minloc = 0
+    // columns loc and last of the updated matrices (delete_bv :259-278)
+    for (int i = tid; i <= b; i += SP_THREADS) {
+        const bool old = (i < b) && (loc < b);
+        const double c0 = old ? S.C[i + (size_t)loc * ld] : 0.0, q0 = old ? S.Q[i + (size_t)loc * ld] : 0.0;
+        Cstar[i] = c0 + (rr * sv[i]) * sv[loc];
+        Qstar[i] = q0 + (ig * eh[i]) * eh[loc];
+        Crep[i] = 0.0 + (rr * sv[i]) * sv[b];
+        Qrep[i] = 0.0 + (ig * eh[i]) * eh[b];
+    }
+    __syncthreads();
+    const double cstar = Cstar[loc], qstar = Qstar[loc];
+    double alphastar[3];
+    for (int c = 0; c < ny; ++c) alphastar[c] = anew[c * ld + loc];
+    __syncthreads();
+    if (tid == 0) {
+        Cstar[loc] = Cstar[last];   // (:263)
+        Qstar[loc] = Qstar[last];   // (:275)
+        Crep[loc] = Crep[last];     // (:267)
+        Qrep[loc] = Qrep[last];     // (:278)
+    }
+    if (tid == 32 && loc != last) {
+        S.BV[2 * loc] = px0;        // BV.col(loc) = BV.col(last) = the new point (:291)
+        S.BV[2 * loc + 1] = px1;
+    }
+    __syncthreads();
+    const int nb = b;
+    const double qc_den = qstar + cstar;
+    // alpha (:257, :285; field variant :250-253 multiplies when bug-compatible)
+    for (int i = tid; i < nb; i += SP_THREADS) {
+        const double qc = Qstar[i] + Cstar[i];
+        for (int c = 0; c < ny; ++c) {
+            const double asw = (i == loc) ? anew[c * ld + last] : anew[c * ld + i];
+            if (ny == 1) S.alpha[i] = asw - alphastar[0] / qc_den * qc;
+            else S.alpha[c * ld + i] = asw - alphastar[c] * (field_bug ? qc_den * qc : qc / qc_den);
+        }
+    }
+    // the one pass over C and Q
+    for (int e = tid; e < nb * nb; e += SP_THREADS) {
+        const int i = e % nb, j = e / nb;
+        double bc, bq;
+        if (i == loc) { bc = Crep[j]; bq = Qrep[j]; }
+        else if (j == loc) { bc = Crep[i]; bq = Qrep[i]; }
+        else {
+            bc = S.C[i + (size_t)j * ld] + (rr * sv[i]) * sv[j];
+            bq = S.Q[i + (size_t)j * ld] + (ig * eh[i]) * eh[j];
+        }
+        const double qq = (Qstar[i] * Qstar[j]) / qstar;
+        const double cc = ((Qstar[i] + Cstar[i]) * (Qstar[j] + Cstar[j])) / qc_den;
+        S.C[i + (size_t)j * ld] = bc + (qq - cc);
+        S.Q[i + (size_t)j * ld] = bq - qq;
+    }
+    __syncthreads();
+    return nb;
+}
+
 struct SpAddParams {
     gpc_params prm;
     double c_exp;
@@ -270,6 +364,10 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_add_kernel(SpAddParams A)
                 __syncthreads();
             } else if (b >= ld) {
                 st = GPC_STATUS_OVERFLOW;                   // capacity == -1 and GPC_MAX_BV reached: skip the point
+            } else if (capacity > 0 && b + 1 > capacity) {
+                // full update + the capacity deletion it forces, in one pass over C and Q
+                b = sp_full_update_delete(S, b, rr, gamma, qv, px0, px1, A.prm.ref_field_delete_bug, ck, eh, sv, Cstar, Qstar, Crep,
+                                          Qrep, part + 4 * ld, sval, sidx);
             } else {
                 // full update (:164-203)
                 for (int i = tid; i <= b; i += SP_THREADS) {
