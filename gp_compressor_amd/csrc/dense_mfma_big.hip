@@ -32,7 +32,6 @@
 #include "gpc_internal.h"
 #include "mfma_tile.h"
 
-#define BG_RMAX 2   // tile rows a wave updates per pass, two columns each (2 x 16 accumulator + 3 stages x (16 + 2 x 8) operand VGPRs)
 
 struct BigParams {
     DenseArgs a;
@@ -55,8 +54,8 @@ struct BigParams {
 
 // LDS carve (doubles), for NPAD padded points and WAVES waves per workgroup:
 //   exp table 64 | x0, x1 2 NPAD | z, w, alpha 9 NPAD | rsqrt row 32 | flags 8 | 2 L^-1 images 512 | L_(k+1)k image 256 |
-//   predict reduction WAVES x 4 x 256
-__host__ __device__ constexpr int bg_lds_doubles(int npad, int waves) { return 64 + 11 * npad + 32 + 8 + 512 + 256 + waves * 1024; }
+//   predict accumulation buffer 4 x 256 (ds_add_f64 targets; during the factorisation: hand-over of the diagonal-block tiles)
+__host__ __device__ constexpr int bg_lds_doubles(int npad, int waves) { return 64 + 11 * npad + 32 + 8 + 512 + 256 + 1024 + 0 * waves; }
 
 __device__ static __forceinline__ d4 bg_mfma4_neg(d4 a, d4 b, d4 acc)
 {
@@ -66,13 +65,14 @@ __device__ static __forceinline__ d4 bg_mfma4_neg(d4 a, d4 b, d4 acc)
 }
 
 // BG_WAVES waves per workgroup and BG_NPAD padded points: <8, 1024> (one workgroup per CU) for 256 < n <= 1024.
-template <int BG_WAVES, int BG_NPAD>
-__global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g)
+template <int BG_WAVES, int BG_NPAD, int BG_RMAX, int BG_OCC>
+__global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigParams g)
 {
+    static_assert(BG_RMAX == 1 || BG_RMAX == 2, "one copy of the update loop per possible row count");
     constexpr int BG_THREADS = BG_WAVES * 64;
     constexpr int B_PX0 = 64, B_PX1 = B_PX0 + BG_NPAD, B_ZV = B_PX1 + BG_NPAD, B_WV = B_ZV + 3 * BG_NPAD, B_AV = B_WV + 3 * BG_NPAD,
                   B_RS = B_AV + 3 * BG_NPAD, B_FLAG = B_RS + 32, B_LINV = B_FLAG + 8, B_L10 = B_LINV + 512, B_RED = B_L10 + 256;
-    static_assert(B_RED + BG_WAVES * 1024 == bg_lds_doubles(BG_NPAD, BG_WAVES), "LDS carve");
+    static_assert(B_RED + 1024 == bg_lds_doubles(BG_NPAD, BG_WAVES), "LDS carve");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     double* T = lds;
@@ -284,9 +284,12 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
 #pragma unroll
                             for (int t = 0; t < BG_RMAX; ++t) sb[st][t] = sa0[st];
                         }
-                        static_assert(BG_RMAX == 2, "one copy of the update loop per possible row count");
-                        if (np == 2) BG_UPDATE_LOOP(2);
-                        else BG_UPDATE_LOOP(1);
+                        if constexpr (BG_RMAX == 2) {
+                            if (np == 2) BG_UPDATE_LOOP(2);
+                            else BG_UPDATE_LOOP(1);
+                        } else {
+                            BG_UPDATE_LOOP(1);
+                        }
                     }
                     // diagonal-block rows go to wave 0 (first pass only: q = 0 -> wave 1, q = 1 -> wave 2, both t = 0)
                     if (p0 == 0 && np > 0 && rr[0] == k) {
@@ -469,22 +472,21 @@ __global__ __launch_bounds__(BG_WAVES * 64, 2) void dense_big_kernel(BigParams g
                                 P[mt][nl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ea[mt], eb[nl], P[mt][nl], 0, 0, 0);
                     }
                 }
-                __syncthreads();   // previous channel's reduction finished reading `red`
+                // cross-wave sum of the four 16 x 16 output tiles with ds_add_f64 into one 8 KB buffer
+                __syncthreads();   // previous channel's outputs are read; the hand-over scratch of the factorisation is dead
+                for (int oo = tid; oo < 1024; oo += BG_THREADS) red[oo] = 0.0;
+                __syncthreads();
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nl = 0; nl < 2; ++nl)
-                        *reinterpret_cast<d4*>(red + ((wave * 4 + mt * 2 + nl) * 256) + lane * 4) = P[mt][nl];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(red + (mt * 2 + nl) * 256 + lane * 4 + r, P[mt][nl][r]);
                 __syncthreads();
                 for (int oo = tid; oo < 1024; oo += BG_THREADS) {
                     const int tile = oo >> 8, e = oo & 255, l2 = e >> 2, r = e & 3;
                     const int py = 16 * (tile >> 1) + (l2 >> 4) + 4 * r, pxx = 16 * (tile & 1) + (l2 & 15);
-                    if (py < sz && pxx < sz) {
-                        double s_ = 0.0;
-#pragma unroll
-                        for (int w = 0; w < BG_WAVES; ++w) s_ += red[(w * 4 + tile) * 256 + e];
-                        fs[(size_t)c * m + py * sz + pxx] = s_;
-                    }
+                    if (py < sz && pxx < sz) fs[(size_t)c * m + py * sz + pxx] = red[oo];
                 }
             }
         } else {
@@ -525,7 +527,10 @@ bool dense_big_supported(const DenseArgs& a)
 
 static size_t big_slot_doubles(int ntw) { return ((size_t)(ntw + 1) * ntw + ntw) * MF_IMG; }
 
-// 8 waves x 1024 points: 159 KB of LDS, one workgroup per CU.  (n <= 256: 4 waves x 256 points, 61 KB: two per CU.)
+// <8 waves, 1024 points, 2 rows per pass, 2 waves/SIMD>: 103 KB of LDS, one workgroup per CU: 256 < n <= 1024.
+// <4 waves, 256 points, 2 rows per pass, 2 waves/SIMD>: 37 KB of LDS, two workgroups = two patches per CU: the cross-check
+// shape for n <= 256 (GPC_FORCE_BIG=1).  (A 1-row, <= 128-VGPR variant with FOUR patches per CU was measured slower, 2.45 M
+// against 2.68 M patches/s on C2: each workgroup runs 2.2x longer -- the shape is bound by the factor stream, not by latency.)
 static void big_shape(const DenseArgs& a, int* waves, int* npad, int* per_cu)
 {
     if (a.n_max <= 256) { *waves = 4; *npad = 256; *per_cu = 2; }
@@ -543,17 +548,17 @@ size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
     return sizeof(double) * big_slot_doubles(ntw) * (size_t)grid;
 }
 
-template <int W, int NP>
+template <int W, int NP, int RM, int OC>
 static int big_launch_t(gpc_ctx* ctx, const BigParams& g, int grid)
 {
     const size_t lds = sizeof(double) * (size_t)bg_lds_doubles(NP, W);
     static bool attr_set = false;
     if (!attr_set) {
-        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_big_kernel<W, NP>),
+        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_big_kernel<W, NP, RM, OC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dense_big_kernel<W, NP>), dim3(grid), dim3(W * 64), lds, ctx->stream, g);
+    hipLaunchKernelGGL((dense_big_kernel<W, NP, RM, OC>), dim3(grid), dim3(W * 64), lds, ctx->stream, g);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;
 }
@@ -595,8 +600,8 @@ int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
     }
     if (waves == 4) {
         ctx->last_dense_kernel = "dense_mfma_big_w4";
-        return big_launch_t<4, 256>(ctx, g, grid);
+        return big_launch_t<4, 256, 2, 2>(ctx, g, grid);
     }
     ctx->last_dense_kernel = "dense_mfma_big";
-    return big_launch_t<8, 1024>(ctx, g, grid);
+    return big_launch_t<8, 1024, 2, 2>(ctx, g, grid);
 }
