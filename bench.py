@@ -196,7 +196,7 @@ def main():
             "metric": "patches/sec (compress+predict)", "value": world * P * args.steps / elapsed, "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2 room scan: {P} patches x {n} pts per GPU, RBF + Gaussian noise, dense Cholesky "
+            "config": {"workload": f"{'C2 room scan' if (P, n) == (8192, 256) else 'room scan (non-default size)'}: {P} patches x {n} pts per GPU, RBF + Gaussian noise, dense Cholesky "
                                    f"fit + predictive mean on the {sz}x{sz} grid (m={m})",
                        "patches_per_gpu": P, "points_per_patch": n, "grid_points": m,
                        "parallelism": f"patches sharded over {world} rank(s), 1 all-gather of f_star" if world > 1 else "1 GPU",
