@@ -251,16 +251,18 @@ def test_dense_device_pointers_on_torch_stream(gp, oracle):
     _close(f.cpu().numpy(), fo, FTOL)
 
 
-def test_dense_full_size_c2_properties(gp, oracle):
-    """BASELINE config 2 (8192 patches x 256 points, m = 400) at full size: size-independent properties
-    (linearity in y, interpolation residual through alpha) plus the oracle on a random sample of patches."""
+@pytest.mark.parametrize("P,n,label", [(8192, 256, "C2"), (8192, 512, "C3 (one GPU's share of 65536 patches)"), (4096, 1024, "C5")])
+def test_dense_full_size_properties(gp, oracle, P, n, label):
+    """BASELINE configs 2, 3 and 5 at their full per-GPU size (m = 400): size-independent properties (linearity in y,
+    the normal equations through alpha on a sample) plus the oracle on a random sample of patches."""
     capi, ctx = gp
-    P, n, res, sz = 8192, 256, 0.15, 20
+    res, sz = 0.15, 20
     off, x0, x1, y = synth.make_patches(P, n, res=res, seed=2)
     rng = np.random.default_rng(99)
     y2 = rng.normal(0, 0.01, size=y.shape)
     p = capi.default_params_dense()
     fa, sta, ala = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz, want_alpha=True)
+    assert ctx.last_dense_kernel().startswith("dense_mfma_nt16" if n <= 256 else "dense_mfma_big")
     fb, stb = ctx.dense_fit_predict_grid(p, off, x0, x1, y2, res, sz)
     fc, stc = ctx.dense_fit_predict_grid(p, off, x0, x1, y + 2.0 * y2, res, sz)
     assert np.all(sta == 0) and np.all(stb == 0) and np.all(stc == 0)
@@ -269,7 +271,7 @@ def test_dense_full_size_c2_properties(gp, oracle):
     _close(fc, fa + 2.0 * fb, 1e-10)
     # (K + 2 sn^2 I) alpha = y, checked per patch with an independent NumPy Gram matrix on a sample
     xs0, xs1 = oracle.grid(res, sz)
-    sample = rng.choice(P, size=24, replace=False)
+    sample = rng.choice(P, size=24 if n <= 256 else 6, replace=False)
     for i in sample:
         sl = slice(off[i], off[i + 1])
         X = np.stack([x0[sl], x1[sl]], 1)
