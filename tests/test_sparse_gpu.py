@@ -261,3 +261,44 @@ def test_sparse_likelihood_and_derivatives(gp, oracle, ny, cap):
     d2, none = g.likelihood(qoff, q0, q1, yq, want_l=False)
     assert none is None and np.array_equal(d2, dX)
     g.close()
+
+
+def test_sparse_full_size_c4(gp, oracle):
+    """BASELINE config 4 at full size: 32768 patches, capacity 200 (21 GB of per-patch state), 256 points per patch
+    streamed in 4 online chunks.  Size-independent properties (basis grows monotonically up to capacity, predictions finite) plus the oracle on a sample of patches (same explicit insertion order)."""
+    capi, ctx = gp
+    res, sz, P, n, cap, chunks = 0.15, 20, 32768, 256, 200, 4
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=4)
+    kw = dict(sigmaf_sq=1.0, l_sq=(res / 8) ** 2, noise=1e-4, capacity=cap)
+    g = capi.Sparse(ctx, capi.default_params_sparse(1, **kw), P, 1)
+    cn = n // chunks
+    coff = (np.arange(P + 1) * cn).astype(np.int32)
+    prev = np.zeros(P, np.int32)
+    for c in range(chunks):
+        idx = (off[:-1, None] + np.arange(c * cn, (c + 1) * cn)[None, :]).reshape(-1)
+        st = g.add(coff, x0[idx], x1[idx], y[:, idx])
+        assert np.all(st == 0)
+        b = g.sizes()
+        want = min((c + 1) * cn, cap)                       # most points are full updates; the rest are projected
+        assert np.all(b <= want) and np.all(b >= prev) and b.mean() >= 0.85 * want
+        prev = b.copy()
+    xs0, xs1 = synth.grid(res, sz)
+    f, _, st2 = g.predict(xs0, xs1, want_sigma=False)
+    assert np.all(st2 == 0) and np.all(np.isfinite(f))
+    op = oracle.sparse_params(1, p0=kw["sigmaf_sq"], p1=kw["l_sq"], s20=kw["noise"], capacity=cap)
+    # 200 basis vectors on a patch 8 length-scales wide make C and Q nearly singular: the reference arithmetic itself
+    # moves by 1e-3..1e-2 of the output scale when the inputs move by one ulp, so the bound on each sampled patch is
+    # the oracle's own sensitivity to a +-1e-15 relative input perturbation (floor 2e-5, the well-conditioned bound).
+    for i in (0, 12345, P - 1):
+        sl = slice(off[i], off[i + 1])
+        outs = []
+        for eps in (0.0, 1e-15, -1e-15):
+            go = oracle.Sparse(op, cap + 2, fast=True)
+            go.add_measurements(x0[sl] * (1 + eps), x1[sl] * (1 - eps), y[:, sl])   # identity order = the chunked order
+            outs.append(go.predict(xs0, xs1)[0])
+            if eps == 0.0:
+                assert go.size() == int(g.sizes()[i])
+        scale = np.max(np.abs(outs[0]))
+        sens = max(np.max(np.abs(o - outs[0])) for o in outs[1:])
+        assert np.max(np.abs(f[i] - outs[0])) <= max(2e-5 * scale, 5.0 * sens), (i, sens / scale)
+    g.close()
