@@ -28,6 +28,12 @@ class Params(C.Structure):
                 ("ref_field_delete_bug", C.c_int32), ("want_variance", C.c_int32), ("reserved", C.c_int32)]
 
 
+class PatchesView(C.Structure):
+    """struct gpc_patches_view (include/gpc.h): sizes + device addresses of a patch batch."""
+    _fields_ = [("P", C.c_int32), ("n_total", C.c_int32), ("n_max", C.c_int32), ("m", C.c_int32)] + \
+               [(k, C.c_void_p) for k in ("off", "x0", "x1", "y", "rgb", "rotations", "means", "rgb_means", "W", "src")]
+
+
 class GpcError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"gpc error {code}: {msg}")
@@ -67,6 +73,11 @@ PROTOTYPES = {
     "gpc_sparse_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gpc_reproject": (C.c_int, [_vp, _i, _i] + [_vp] * 10),
     "gpc_reproject_dev": (C.c_int, [_vp, _i, _i] + [_vp] * 10),
+    "gpc_project_cloud": (C.c_int, [_vp, _vp, _i, _d, _i, C.POINTER(_vp)]),
+    "gpc_project_cloud_dev": (C.c_int, [_vp, _vp, _i, _d, _i, C.POINTER(_vp)]),
+    "gpc_patches_view_dev": (C.c_int, [_vp, _vp]),
+    "gpc_patches_fetch": (C.c_int, [_vp] * 11),
+    "gpc_patches_destroy": (None, [_vp]),
     "gpc_partition_patches": (C.c_int, [_i, _vp, _i, _i, _vp]),
     "gpc_test_exp_host": (None, [_vp, _vp, _i]),
     "gpc_test_exp_small_host": (None, [_vp, _vp, _i]),
@@ -219,6 +230,27 @@ class Context:
                                            _ptr(cm), _ptr(cloud), _ptr(npts)))
         return cloud[:int(npts[0])]
 
+    def make_cloud(self, xyz, rgb):
+        """(n, 3) float32 + (n, 3) uint8 -> array of pcl::PointXYZRGB records"""
+        xyz = np.asarray(xyz, dtype=np.float32).reshape(-1, 3)
+        rgb = np.asarray(rgb, dtype=np.uint8).reshape(-1, 3)
+        c = np.zeros(len(xyz), dtype=self.POINT_DTYPE)
+        c["x"], c["y"], c["z"], c["w"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], 1.0
+        c["r"], c["g"], c["b"], c["a"] = rgb[:, 0], rgb[:, 1], rgb[:, 2], 255
+        return c
+
+    def project_cloud(self, cloud, res, sz, n=None):
+        """gpc_project_cloud[_dev]: a host record array (make_cloud) or a device buffer of n records -> Patches"""
+        h = _vp()
+        if isinstance(cloud, np.ndarray):
+            assert cloud.dtype == self.POINT_DTYPE
+            cloud = np.ascontiguousarray(cloud)
+            self._check(self.lib.gpc_project_cloud(self.h, _ptr(cloud) if len(cloud) else None, len(cloud), float(res), int(sz),
+                                                   C.byref(h)))
+        else:
+            self._check(self.lib.gpc_project_cloud_dev(self.h, _ptr(cloud), int(n), float(res), int(sz), C.byref(h)))
+        return Patches(self, h)
+
     def reproject_dev(self, P, m, bv_count, xs0, xs1, f_star, c_star, rotations, means, rgb_means, cloud, n_points):
         self._check(self.lib.gpc_reproject_dev(self.h, P, m, _ptr(bv_count), _ptr(xs0), _ptr(xs1), _ptr(f_star), _ptr(c_star),
                                                _ptr(rotations), _ptr(means), _ptr(rgb_means), _ptr(cloud), _ptr(n_points)))
@@ -235,6 +267,35 @@ class Context:
         self._check(self.lib.gpc_dense_fit_predict_grid_dev(self.h, C.byref(params), P, _ptr(off), n_max, n_total,
                                                             _ptr(x0), _ptr(x1), _ptr(y), ny, float(res), int(sz),
                                                             _ptr(f_star), _ptr(alpha_out), _ptr(status)))
+
+
+class Patches:
+    """gpc_patches: the batch gp_compressor::project_cloud produces, resident on the device."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.lib, self.h = ctx, ctx.lib, h
+        self.view = PatchesView()
+        ctx._check(self.lib.gpc_patches_view_dev(h, C.byref(self.view)))
+        ctx._children.add(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gpc_patches_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def fetch(self):
+        """host copy as a dict of arrays; R[i] is the 3x3 matrix (columns normal, u, v)"""
+        v = self.view
+        P, N, m = v.P, v.n_total, v.m
+        o = dict(off=np.zeros(P + 1, np.int32), x0=np.zeros(N), x1=np.zeros(N), y=np.zeros(N), rgb=np.zeros((3, N)),
+                 R=np.zeros((P, 9)), mean=np.zeros((P, 3)), rgb_mean=np.zeros((P, 3)), W=np.zeros((P, m), np.uint8),
+                 src=np.zeros(N, np.int32))
+        self.ctx._check(self.lib.gpc_patches_fetch(self.h, *[_ptr(o[k]) for k in ("off", "x0", "x1", "y", "rgb", "R", "mean",
+                                                                                  "rgb_mean", "W", "src")]))
+        o["R"] = o["R"].reshape(P, 3, 3).transpose(0, 2, 1).copy()
+        return o
 
 
 class Sparse:

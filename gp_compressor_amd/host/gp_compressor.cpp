@@ -112,8 +112,35 @@ gp_compressor::~gp_compressor()
 // src/gp_compressor.cpp:21-27
 void gp_compressor::save_compressed(const std::string& /*name: ignored by the reference too*/)
 {
-    project_cloud();
+    if (gpu_producer) project_cloud_device(); else project_cloud();
     train_processes();
+}
+
+// project_cloud() on the GPU: upload the cloud as pcl::PointXYZRGB records, fetch the batch
+void gp_compressor::project_cloud_device()
+{
+    if (!ctx_) check(gpc_ctx_create(&ctx_, device_), nullptr, "gpc_ctx_create");
+    std::vector<gpc_point_xyzrgb> rec(cloud_.size());
+    for (size_t i = 0; i < cloud_.size(); ++i) {
+        const point& p = cloud_[i];
+        rec[i] = gpc_point_xyzrgb{p.x, p.y, p.z, 1.0f, p.b, p.g, p.r, 255, {0.0f, 0.0f, 0.0f}};
+    }
+    gpc_patches* pt = nullptr;
+    check(gpc_project_cloud(ctx_, rec.data(), (int)rec.size(), res_, sz_, &pt), ctx_, "gpc_project_cloud");
+    gpc_patches_view v;
+    gpc_patches_view_dev(pt, &v);
+    batch_ = patch_batch();
+    const size_t P = (size_t)v.P, N = (size_t)v.n_total;
+    batch_.off.assign(P + 1, 0);
+    batch_.x0.resize(N); batch_.x1.resize(N); batch_.y.resize(N); batch_.rgb.resize(3 * N);
+    batch_.rotations.resize(P); batch_.means.resize(P); batch_.rgb_means.resize(P);
+    batch_.W.resize(P * (size_t)v.m);
+    const int rc = gpc_patches_fetch(pt, batch_.off.data(), batch_.x0.data(), batch_.x1.data(), batch_.y.data(), batch_.rgb.data(),
+                                     P ? batch_.rotations[0].data() : nullptr, P ? batch_.means[0].data() : nullptr,
+                                     P ? batch_.rgb_means[0].data() : nullptr, batch_.W.data(), nullptr);
+    gpc_patches_destroy(pt);
+    check(rc, ctx_, "gpc_patches_fetch");
+    projected_ = true;
 }
 
 // src/gp_compressor.cpp:29-64
@@ -199,7 +226,8 @@ void gp_compressor::project_cloud()
                         if (ex * ex + ey * ey + ez * ez <= radius * radius) index_search.push_back(idx);
                     }
                 }
-        std::sort(index_search.begin(), index_search.end());
+        // hit order = patch point order: neighbour voxels in (dz, dy, dx) order, ascending index inside a voxel (PCL's is its
+        // octree traversal order); the GPU producer and the oracle walk the same order, so all three agree bit for bit
         std::array<double, 9> R{};
         std::array<double, 3> mid{center[0], center[1], center[2]}, cmean{0, 0, 0};
         const int k = (int)index_search.size();
@@ -538,6 +566,11 @@ int gpc_host_project(void* h)
 {
     try { static_cast<gpc::gp_compressor*>(h)->project_cloud(); return 0; } catch (...) { return -1; }
 }
+int gpc_host_project_device(void* h, char* err, int errlen)
+{
+    try { static_cast<gpc::gp_compressor*>(h)->project_cloud_device(); return 0; }
+    catch (const std::exception& e) { if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.what()); return -1; }
+}
 int gpc_host_patch_count(void* h) { return static_cast<gpc::gp_compressor*>(h)->patches().patches(); }
 int gpc_host_point_count(void* h) { return (int)static_cast<gpc::gp_compressor*>(h)->patches().x0.size(); }
 // copies the batch: off[P+1], x0/x1/y[N], rgb[3N], R[9P], mean[3P], rgb_mean[3P]
@@ -558,6 +591,12 @@ void gpc_host_get_batch(void* h, int32_t* off, double* x0, double* x1, double* y
     }
 }
 // GPU: save_compressed + load_compressed.  out_xyz / out_rgb hold up to P*sz*sz points; returns the count or < 0.
+void gpc_host_get_mask(void* h, uint8_t* W)
+{
+    const auto& b = static_cast<gpc::gp_compressor*>(h)->patches();
+    if (!b.W.empty()) std::memcpy(W, b.W.data(), b.W.size());
+}
+
 int gpc_host_roundtrip(void* h, float* out_xyz, uint8_t* out_rgb, int capacity_pts, double* mean_added, int* max_added,
                        char* err, int errlen)
 {

@@ -82,6 +82,10 @@ public:
 
     // host-only part, usable without a GPU
     void project_cloud();                            // src/gp_compressor.cpp:177-249
+    // the same batch, bit for bit, cut on the GPU (gpc_project_cloud); what save_compressed()
+    // uses unless gpu_producer is cleared
+    void project_cloud_device();
+    bool gpu_producer = true;
     const patch_batch& patches() const { return batch_; }
     // statistics the reference prints ("Mean added" / "Max added", :173-174)
     double mean_added() const { return mean_added_; }

@@ -34,9 +34,11 @@ def load():
         L.gpc_host_seed.argtypes = [vp, C.c_uint]
         L.gpc_host_set_sparse_kernel.argtypes = [vp, d, d, d, d, i]
         L.gpc_host_project.argtypes = [vp]
+        L.gpc_host_project_device.argtypes = [vp, vp, i]
         L.gpc_host_patch_count.argtypes = [vp]
         L.gpc_host_point_count.argtypes = [vp]
         L.gpc_host_get_batch.argtypes = [vp] * 9
+        L.gpc_host_get_mask.argtypes = [vp, vp]
         L.gpc_host_roundtrip.argtypes = [vp, vp, vp, i, vp, vp, vp, i]
         L.gpc_host_save_model.restype = C.c_longlong
         L.gpc_host_save_model.argtypes = [vp, C.c_char_p, vp, i]
@@ -66,15 +68,23 @@ class GpCompressor:
     def set_sparse_kernel(self, sigmaf_sq, l_sq, s20_depth, s20_rgb, capacity):
         self.L.gpc_host_set_sparse_kernel(self.h, sigmaf_sq, l_sq, s20_depth, s20_rgb, capacity)
 
-    def project_cloud(self):
-        assert self.L.gpc_host_project(self.h) == 0
+    def project_cloud(self, device=False):
+        """project_cloud() on the host, or (device=True) the same batch cut on the GPU"""
+        if device:
+            err = C.create_string_buffer(512)
+            if self.L.gpc_host_project_device(self.h, C.addressof(err), 512) != 0:
+                raise RuntimeError(f"project_cloud_device failed: {err.value.decode()}")
+        else:
+            assert self.L.gpc_host_project(self.h) == 0
         P, N = self.L.gpc_host_patch_count(self.h), self.L.gpc_host_point_count(self.h)
         off = np.zeros(P + 1, dtype=np.int32)
         x0, x1, y = np.zeros(N), np.zeros(N), np.zeros(N)
         rgb = np.zeros((3, N))
         R, mean, cm = np.zeros((P, 9)), np.zeros((P, 3)), np.zeros((P, 3))
         self.L.gpc_host_get_batch(self.h, *[a.ctypes.data for a in (off, x0, x1, y, rgb, R, mean, cm)])
-        return dict(off=off, x0=x0, x1=x1, y=y, rgb=rgb, R=R.reshape(P, 3, 3).transpose(0, 2, 1).copy(), mean=mean, rgb_mean=cm)
+        W = np.zeros((P, self.sz * self.sz), dtype=np.uint8)
+        self.L.gpc_host_get_mask(self.h, W.ctypes.data)
+        return dict(off=off, x0=x0, x1=x1, y=y, rgb=rgb, R=R.reshape(P, 3, 3).transpose(0, 2, 1).copy(), mean=mean, rgb_mean=cm, W=W)
 
     def roundtrip(self):
         """save_compressed("...") then load_compressed(): returns (xyz float32 (M,3), rgb uint8 (M,3), mean_added, max_added)."""
@@ -115,15 +125,6 @@ def decompress_file(path, capacity_pts, device=0):
 
 
 def synthetic_plane_cloud(n=10000, seed=1, extent=1.2):
-    """BASELINE config 1 / SURVEY section 8(d) C1: points on z = 0.02 sin(3x) cos(2y) + N(0, 2 mm), (x, y) in [0, extent)^2,
-    colour = smooth texture."""
-    rng = np.random.default_rng(seed)
-    x = rng.uniform(0, extent, n)
-    y = rng.uniform(0, extent, n)
-    z = 0.02 * np.sin(3 * x) * np.cos(2 * y) + rng.normal(0, 0.002, n)
-    xyz = np.stack([x, y, z], 1).astype(np.float32)
-    r = np.clip(127 + 100 * np.sin(10 * x), 0, 255)
-    g_ = np.clip(127 + 100 * np.cos(7 * y), 0, 255)
-    b = np.clip(127 + 60 * np.sin(5 * (x + y)), 0, 255)
-    rgb = np.stack([r, g_, b], 1).astype(np.uint8)
-    return xyz, rgb
+    """BASELINE config 1 / SURVEY section 8(d) C1 (see synth.plane_cloud)"""
+    from . import synth
+    return synth.plane_cloud(n, seed, extent)

@@ -73,3 +73,45 @@ def sattolo_perms(off, seed=7):
             ind[i], ind[r] = ind[r], ind[i]
         perm[off[p]:off[p + 1]] = ind
     return perm
+
+
+def plane_cloud(n=10000, seed=1, extent=1.2):
+    """BASELINE config 1: z = 0.02 sin(3x) cos(2y) + N(0, 2 mm) over [0, extent)^2 with a smooth
+    texture.  Returns xyz (n, 3) float32, rgb (n, 3) uint8."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, extent, n)
+    y = rng.uniform(0, extent, n)
+    z = 0.02 * np.sin(3 * x) * np.cos(2 * y) + rng.normal(0, 0.002, n)
+    return np.stack([x, y, z], 1).astype(np.float32), _texture(x, y, x + y)
+
+
+def room_cloud(n=200000, seed=3, size=(4.0, 3.0, 2.5), noise=0.003):
+    """A scanned room: the six faces of a box (normals along +-x, +-y, +-z, so every branch of compute_rotation,
+    src/gp_compressor.cpp:40-61, is taken) with gentle relief and sensor noise, plus a sphere standing in it (all the
+    normals in between).  Returns xyz (n, 3) float32, rgb (n, 3) uint8."""
+    rng = np.random.default_rng(seed)
+    n_s = n // 8
+    n_w = n - n_s
+    face = rng.integers(0, 6, n_w)
+    u, v = rng.uniform(0, 1, n_w), rng.uniform(0, 1, n_w)
+    relief = 0.01 * np.sin(9 * u) * np.cos(7 * v) + rng.normal(0, noise, n_w)
+    p = np.zeros((n_w, 3))
+    for f in range(6):
+        a = f // 2                       # axis of the normal
+        b, c = (a + 1) % 3, (a + 2) % 3
+        sel = face == f
+        p[sel, a] = (size[a] if f % 2 else 0.0) + relief[sel]
+        p[sel, b] = u[sel] * size[b]
+        p[sel, c] = v[sel] * size[c]
+    d = rng.normal(size=(n_s, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    s = np.array(size) / 2 + 0.6 * d * (1 + rng.normal(0, noise, (n_s, 1)))
+    xyz = np.concatenate([p, s]).astype(np.float32)
+    return xyz, _texture(xyz[:, 0] + xyz[:, 2], xyz[:, 1], xyz[:, 0] - xyz[:, 1])
+
+
+def _texture(a, b, c):
+    r = np.clip(127 + 100 * np.sin(10 * a), 0, 255)
+    g = np.clip(127 + 100 * np.cos(7 * b), 0, 255)
+    bl = np.clip(127 + 60 * np.sin(5 * c), 0, 255)
+    return np.stack([r, g, bl], 1).astype(np.uint8)

@@ -177,6 +177,38 @@ int gpc_reproject_dev(gpc_ctx* ctx, int P, int m, const int32_t* bv_count, const
                       const double* f_star, const double* c_star, const double* rotations, const double* means,
                       const double* rgb_means, gpc_point_xyzrgb* cloud, int32_t* n_points);
 
+/* ---- the step before the path: the patch producer on the GPU ---------------------------- */
+/* gp_compressor::project_cloud + compute_rotation + project_points (src/gp_compressor.cpp:177-249, 29-64, 66-118): a
+ * pcl::PointXYZRGB cloud in, the ragged patch batch of the entry points above out, resident in HBM -- voxel leaves of
+ * side `res` (anchored at the cloud's minimum corner, visited in ascending (z, y, x) order), radiusSearch(center,
+ * sqrt(3)/2 res) over the 27 neighbouring voxels, plane frame R_i from the smallest singular vector of the homogeneous
+ * points (:35-61), exclusive point ownership in leaf order (occupied_indices, :81-89), the +-res/2 window (:85-87), depth
+ * and colour mean removal (:101-107), centre shift (:116) and the sz x sz occupancy mask W (:90-92, :117).
+ * The arithmetic is the oracle's operation for operation (no FMA contraction): every output is bit-identical to it.
+ * gpc_project_cloud takes a HOST cloud, gpc_project_cloud_dev a DEVICE cloud; both synchronise (the sizes of the
+ * result depend on the data) and return an object owning the device buffers.  Errors: GPC_EINVAL (res <= 0, sz < 1,
+ * a non-finite coordinate), GPC_ERANGE (more than 2^21 voxels along an axis, or 2^62 in total). */
+typedef struct gpc_patches gpc_patches;
+typedef struct gpc_patches_view {
+    int32_t P, n_total, n_max, m;     /* patches (= leaves), points owned in total, largest patch, sz*sz */
+    const int32_t* off;               /* P + 1 */
+    const double *x0, *x1, *y;        /* n_total: pt(1), pt(2), mean-removed pt(0)   (X and y of :146-155) */
+    const double* rgb;                /* 3 planes of n_total: mean-removed colours   (C of :146-155) */
+    const double* rotations;          /* P x 9 column-major (columns = normal, u, v) */
+    const double *means, *rgb_means;  /* P x 3 */
+    const uint8_t* W;                 /* P x m occupancy mask */
+    const int32_t* src;               /* n_total: index of the cloud point behind each patch point */
+} gpc_patches_view;
+int gpc_project_cloud(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, double res, int sz, gpc_patches** out);
+int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, double res, int sz, gpc_patches** out);
+/* sizes + DEVICE pointers (valid until gpc_patches_destroy): feed them to gpc_dense_fit_predict_grid_dev /
+ * gpc_sparse_add_dev / gpc_reproject_dev without a host round trip */
+int gpc_patches_view_dev(const gpc_patches* p, gpc_patches_view* view);
+/* copy to HOST buffers sized by the view's counts; NULL pointers are skipped */
+int gpc_patches_fetch(const gpc_patches* p, int32_t* off, double* x0, double* x1, double* y, double* rgb, double* rotations,
+                      double* means, double* rgb_means, uint8_t* W, int32_t* src);
+void gpc_patches_destroy(gpc_patches* p);
+
 /* ---- patch -> rank partition for one process per GPU (src/gp_compressor.cpp:146-163: patches are independent) ----- */
 /* Longest-processing-time assignment of P patches with per-patch cost n_i^3 (dense) or n_i*cap^2 (sparse) onto
  * `world` ranks, every rank padded to ceil(P/world) slots so that the single all-gather of f_star is fixed-size.

@@ -123,6 +123,22 @@ void orc_grid(double res, int sz, double* xs0, double* xs1);           /* m = sz
 void orc_reproject(const double* R, const double* mean, double f, double xs0, double xs1, float* xyz);
 void orc_flatten_colors(const double* c3, uint8_t* rgb);               /* gp_compressor.cpp:251-265 */
 
+/* ---- f2: the patch producer, gp_compressor::project_cloud + compute_rotation + project_points
+ *      (src/gp_compressor.cpp:177-249, 29-64, 66-118); see gpc_oracle_producer.c for what is pinned down */
+typedef struct {
+    int P, n_total;
+    int32_t* off;                 /* P + 1 */
+    double *x0, *x1, *y;          /* n_total: pt(1), pt(2), mean-removed pt(0) */
+    double* rgb;                  /* 3 planes of n_total, mean-removed */
+    double *R, *mean, *rgb_mean;  /* P x 9 (column-major: normal, u, v), P x 3, P x 3 */
+    uint8_t* W;                   /* P x sz*sz occupancy */
+    int32_t* src;                 /* n_total: index of the cloud point each patch point came from */
+} orc_patches;
+int orc_project_cloud(const float* xyz, const uint8_t* rgb, int n, double res, int sz, orc_patches* out);
+void orc_patches_free(orc_patches* o);
+void orc_smallest_eigvec4(double A[4][4], double v[4]);
+void orc_compute_rotation(double M[4][4], int k, double R[9]);
+
 /* ---- whole-batch drivers used by tests and by bench.py's cpu_baseline (kind "port") ---- */
 /* dense path for a ragged batch (CSR offsets), same signature shape as gpc_dense_fit_predict in include/gpc.h.
  * scratch is allocated internally.  status[i]: 0 ok, 1 non-SPD pivot. */

@@ -32,6 +32,11 @@ class DenseParams(C.Structure):
                 ("ref_double_noise", C.c_int)]
 
 
+class Patches(C.Structure):
+    _fields_ = [("P", C.c_int), ("n_total", C.c_int), ("off", c_ip), ("x0", c_dp), ("x1", c_dp), ("y", c_dp), ("rgb", c_dp),
+                ("R", c_dp), ("mean", c_dp), ("rgb_mean", c_dp), ("W", C.POINTER(C.c_uint8)), ("src", c_ip)]
+
+
 class SparseParams(C.Structure):
     _fields_ = [("p0", C.c_double), ("p1", C.c_double), ("s20", C.c_double), ("eps_tol", C.c_double),
                 ("capacity", C.c_int), ("ny", C.c_int), ("noise_model", C.c_int), ("field_delete_bug", C.c_int)]
@@ -124,6 +129,9 @@ def _bind(L):
     L.orc_grid.argtypes = [d, C.c_int, c_dp, c_dp]
     L.orc_reproject.argtypes = [c_dp, c_dp, d, d, d, C.POINTER(C.c_float)]
     L.orc_flatten_colors.argtypes = [c_dp, C.POINTER(C.c_uint8)]
+    L.orc_project_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_int, d, C.c_int, C.POINTER(Patches)]
+    L.orc_patches_free.argtypes = [C.POINTER(Patches)]
+    L.orc_compute_rotation.argtypes = [c_dp, C.c_int, c_dp]
     return L
 
 
@@ -273,3 +281,32 @@ def shuffle_stream(n, rs):
     ind = np.zeros(n, dtype=np.int32)
     lib().orc_shuffle_stream(n, rs.ctypes.data_as(C.POINTER(C.c_uint32)), _ip(ind))
     return ind
+
+
+def project_cloud(xyz, rgb, res, sz):
+    """gp_compressor::project_cloud (src/gp_compressor.cpp:177-249): the patch batch as a dict of arrays; R[i] is the
+    3x3 matrix (columns normal, u, v)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    o = Patches()
+    rc = lib().orc_project_cloud(xyz.ctypes.data, rgb.ctypes.data, len(xyz), float(res), int(sz), C.byref(o))
+    assert rc == 0
+    P, N, m = o.P, o.n_total, sz * sz
+
+    def arr(ptr, n, dt):
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt).copy() if n > 0 else np.zeros(0, dt)
+    out = dict(off=arr(o.off, P + 1, np.int32), x0=arr(o.x0, N, np.float64), x1=arr(o.x1, N, np.float64),
+               y=arr(o.y, N, np.float64), rgb=arr(o.rgb, 3 * N, np.float64).reshape(3, N),
+               R=arr(o.R, 9 * P, np.float64).reshape(P, 3, 3).transpose(0, 2, 1).copy(),
+               mean=arr(o.mean, 3 * P, np.float64).reshape(P, 3), rgb_mean=arr(o.rgb_mean, 3 * P, np.float64).reshape(P, 3),
+               W=arr(o.W, P * m, np.uint8).reshape(P, m), src=arr(o.src, N, np.int32))
+    lib().orc_patches_free(C.byref(o))
+    return out
+
+
+def compute_rotation(M, k):
+    """compute_rotation (src/gp_compressor.cpp:29-64) from the 4x4 moment matrix of the k homogeneous points"""
+    A = np.ascontiguousarray(M, dtype=np.float64).copy()
+    R = np.zeros(9)
+    lib().orc_compute_rotation(_dp(A.reshape(-1)), int(k), _dp(R))
+    return R.reshape(3, 3).T.copy()

@@ -67,3 +67,16 @@ def test_model_file_roundtrip_c1(H, tmp_path):
         f.write(blob[: len(blob) // 2])
     with pytest.raises(RuntimeError):
         H.decompress_file(bad, 64 * sz * sz)
+
+
+def test_gpu_producer_equals_host_producer(H):
+    """gp_compressor::project_cloud_device (gpc_project_cloud, row f2) hands train_processes the batch project_cloud()
+    cuts on the host, bit for bit -- which is why save_compressed() may use either."""
+    from gp_compressor_amd import synth
+    for (xyz, rgb), res, sz in ((synth.plane_cloud(10000, seed=1), 0.15, 20), (synth.room_cloud(80000, seed=9), 0.15, 20)):
+        g = H.GpCompressor(xyz, rgb, res=res, sz=sz)
+        host = g.project_cloud()
+        dev = g.project_cloud(device=True)
+        assert len(host["off"]) > 10
+        for k in host:
+            assert np.array_equal(host[k], dev[k]), k

@@ -1,0 +1,152 @@
+"""GPU parity of the patch producer (gp_compressor::project_cloud + compute_rotation +
+project_points, src/gp_compressor.cpp:177-249, 29-64, 66-118) against the CPU oracle (orc_project_cloud).  Index, byte
+and floating-point outputs alike are BIT-EXACT: the kernels evaluate the oracle's expressions in its order."""
+import numpy as np
+import pytest
+
+from gp_compressor_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("off", "x0", "x1", "y", "rgb", "R", "mean", "rgb_mean", "W", "src")
+
+
+@pytest.fixture(scope="module")
+def gp():
+    from gp_compressor_amd import capi
+    capi.load()
+    ctx = capi.Context(0)
+    yield capi, ctx
+    ctx.close()
+
+
+def _same(a, b):
+    for k in KEYS:
+        assert a[k].shape == b[k].shape, k
+        assert np.array_equal(a[k], b[k]), (k, int(np.sum(a[k] != b[k])))
+
+
+@pytest.mark.parametrize("case", ["c1_plane", "room", "room_fine", "tilted_sheet"])
+def test_producer_matches_oracle_bit_for_bit(gp, oracle, case):
+    capi, ctx = gp
+    if case == "c1_plane":                        # BASELINE config 1: 10 k points, res 0.15, sz 20
+        xyz, rgb = synth.plane_cloud(10000, seed=1)
+        res, sz = 0.15, 20
+    elif case == "room":                          # every branch of the frame construction, shared spheres at the edges
+        xyz, rgb = synth.room_cloud(200000, seed=3)
+        res, sz = 0.15, 20
+    elif case == "room_fine":                     # many small leaves (lots of them below 4 points: identity frames)
+        xyz, rgb = synth.room_cloud(60000, seed=5)
+        res, sz = 0.04, 6
+    else:                                         # a sheet at 45 degrees: |n_x| == |n_z| up to rounding, negative coordinates
+        xyz, rgb = synth.plane_cloud(30000, seed=7)
+        c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+        xyz = (xyz.astype(np.float64) @ np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]).T - 0.7).astype(np.float32)
+        res, sz = 0.1, 10
+    want = oracle.project_cloud(xyz, rgb, res, sz)
+    pt = ctx.project_cloud(ctx.make_cloud(xyz, rgb), res, sz)
+    got = pt.fetch()
+    v = pt.view
+    assert (v.P, v.n_total, v.m) == (len(want["off"]) - 1, int(want["off"][-1]), sz * sz)
+    assert v.n_max == int(np.diff(want["off"]).max())
+    _same(got, want)
+    # the contract the GP kernels rely on
+    assert len(np.unique(got["src"])) == v.n_total                       # exclusive ownership
+    assert np.all(np.abs(got["x0"]) <= res / 2) and np.all(np.abs(got["x1"]) <= res / 2)
+    pt.close()
+
+
+def test_producer_edge_cases(gp, oracle):
+    capi, ctx = gp
+    # empty cloud
+    pt = ctx.project_cloud(ctx.make_cloud(np.zeros((0, 3)), np.zeros((0, 3))), 0.1, 4)
+    assert (pt.view.P, pt.view.n_total) == (0, 0) and np.array_equal(pt.fetch()["off"], [0])
+    pt.close()
+    # fewer than 4 points in a sphere: identity frame (src/gp_compressor.cpp:31-34); one point; coincident points
+    for xyz in (np.array([[0.01, 0.02, 0.03], [0.02, 0.01, 0.03], [0.9, 0.9, 0.9]]), np.array([[1.0, -2.0, 3.0]]),
+                np.tile(np.array([[0.5, 0.5, 0.5]]), (70, 1))):
+        rgb = (np.arange(3 * len(xyz)).reshape(-1, 3) * 7 % 256).astype(np.uint8)
+        want = oracle.project_cloud(xyz, rgb, 0.1, 4)
+        pt = ctx.project_cloud(ctx.make_cloud(xyz, rgb), 0.1, 4)
+        _same(pt.fetch(), want)
+        pt.close()
+    # argument checking: never aborts, reports
+    cloud = ctx.make_cloud(np.array([[0, 0, 0], [1, 1, 1]]), np.zeros((2, 3)))
+    for bad_res in (0.0, -1.0, float("nan")):
+        with pytest.raises(capi.GpcError) as e:
+            ctx.project_cloud(cloud, bad_res, 4)
+        assert e.value.code == capi.GPC_EINVAL
+    with pytest.raises(capi.GpcError) as e:
+        ctx.project_cloud(cloud, 0.1, 0)
+    assert e.value.code == capi.GPC_EINVAL
+    with pytest.raises(capi.GpcError) as e:
+        ctx.project_cloud(cloud, 1e-7, 4)                               # 10^7 voxels along an axis
+    assert e.value.code == capi.GPC_ERANGE
+    for bad in (np.nan, np.inf):
+        c2 = cloud.copy()
+        c2["y"][1] = bad
+        with pytest.raises(capi.GpcError) as e:
+            ctx.project_cloud(c2, 0.1, 4)
+        assert e.value.code == capi.GPC_EINVAL
+
+
+def test_producer_feeds_the_gp_kernels_on_device(gp, oracle):
+    """cloud -> patches -> dense GP -> cloud without a host pass over the points: the producer's device view goes straight
+    into gpc_dense_fit_predict_grid_dev and gpc_reproject_dev; same result as the host-buffer entry points on the fetched
+    batch."""
+    import torch
+    capi, ctx = gp
+    res, sz = 0.15, 20
+    xyz, rgb = synth.plane_cloud(10000, seed=1)
+    cloud = ctx.make_cloud(xyz, rgb)
+    d_cloud = torch.from_numpy(cloud.view(np.uint8).reshape(-1, 32)).cuda()
+    pt = ctx.project_cloud(d_cloud, res, sz, n=len(cloud))
+    v = pt.view
+    b = pt.fetch()
+    assert np.array_equal(b["off"], oracle.project_cloud(xyz, rgb, res, sz)["off"])
+    p = capi.default_params_dense(sigmaf_sq=1.0, l_sq=(res / 8) ** 2, noise=1e-4)
+    m = sz * sz
+    f = torch.zeros(v.P, m, dtype=torch.float64, device="cuda")
+    st = torch.zeros(v.P, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.dense_fit_predict_grid_dev(p, v.P, v.off, v.n_max, v.n_total, v.x0, v.x1, v.y, 1, res, sz, f, status=st)
+    out = torch.zeros(v.P * m, 32, dtype=torch.uint8, device="cuda")
+    npts = torch.zeros(1, dtype=torch.int32, device="cuda")
+    xs0, xs1 = synth.grid(res, sz)
+    d_xs0, d_xs1 = torch.from_numpy(xs0).cuda(), torch.from_numpy(xs1).cuda()
+    torch.cuda.synchronize()                       # the context enqueues on its own stream
+    ctx.reproject_dev(v.P, m, None, d_xs0, d_xs1, f, None, v.rotations, v.means, None, out, npts)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert int(npts.item()) == v.P * m
+    f_host, st_host = ctx.dense_fit_predict_grid(p, b["off"], b["x0"], b["x1"], b["y"][None, :], res, sz)
+    assert np.array_equal(st.cpu().numpy(), st_host)
+    ok = st_host == 0
+    assert ok.sum() >= 0.9 * v.P
+    # two launches of the dense kernel agree to rounding (its partial sums meet in LDS atomics, in arrival order)
+    assert np.max(np.abs(f.cpu().numpy()[ok] - f_host.reshape(v.P, m)[ok])) <= 1e-9 * np.max(np.abs(f_host.reshape(v.P, m)[ok]))
+    rec = out.cpu().numpy().view(capi.Context.POINT_DTYPE).reshape(v.P, m)
+    # the reconstructed surface lies on the input surface: z = 0.02 sin(3x) cos(2y) within the sensor noise
+    r = rec[ok].reshape(-1)
+    inside = (r["x"] > 0.05) & (r["x"] < 1.15) & (r["y"] > 0.05) & (r["y"] < 1.15)
+    err = r["z"][inside] - 0.02 * np.sin(3 * r["x"][inside]) * np.cos(2 * r["y"][inside])
+    assert inside.sum() > 0.5 * len(r) and np.sqrt(np.mean(err ** 2)) < 0.008
+    pt.close()
+
+
+def test_producer_full_size_c2(gp, oracle):
+    """The cloud behind BASELINE config 2's per-GPU batch: ~2 M points in ~8 k leaves of ~256 points.  Bit-exact against
+    the oracle at full size (it takes the CPU a few seconds), plus the size-independent properties."""
+    capi, ctx = gp
+    res, sz = 0.15, 20
+    side = 0.15 * 90                                # 90 x 90 = 8100 leaves on a gently curved ground
+    xyz, rgb = synth.plane_cloud(2_100_000, seed=11, extent=side)
+    want = oracle.project_cloud(xyz, rgb, res, sz)
+    pt = ctx.project_cloud(ctx.make_cloud(xyz, rgb), res, sz)
+    v = pt.view
+    got = pt.fetch()
+    _same(got, want)
+    cnt = np.diff(got["off"])
+    assert 8000 <= v.P <= 9000 and 200 <= np.median(cnt) <= 300 and v.n_total >= 0.99 * len(xyz)
+    assert len(np.unique(got["src"])) == v.n_total
+    pt.close()
