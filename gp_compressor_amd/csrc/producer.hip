@@ -9,19 +9,25 @@
 //   * a point is claimed by the FIRST leaf in leaf order whose sphere holds it and whose +-res/2 window accepts it
 //     (:81-89); candidates are the <= 27 leaves around the point's voxel, so ownership is a per-point minimum.
 // Pipeline (all HBM-bound integer / gather work; nothing here is GEMM-shaped):
-//   1 pc_bounds_kernel    min / max corner, finiteness                                  one pass over the cloud
+//   1 pc_bounds_kernel    min / max corner, finiteness: one pass over the cloud, one set of atomics per workgroup
 //   2 pc_keys_kernel      voxel key (z, y, x packed) per point, then rocPRIM's stable radix sort of (key, index) over
 //                         exactly the key's bits, pc_heads/pc_leaves: leaf table (sorted unique keys + segment starts)
 //   3 pc_gather_kernel    points re-laid in sorted order as 16-byte records (x, y, z, rgb): every later access to a
 //                         voxel's points is one contiguous, coalesced segment
-//   4 pc_rotation_kernel  one wave per leaf: 27 neighbour segments (binary search in the leaf table), sphere test by
-//                         ballot, 4x4 moment matrix accumulated in the oracle's order (16 lanes, one entry each),
-//                         cyclic Jacobi eigen-solve, frame construction (:37-63)
-//   5 pc_claim_kernel     one thread per point: first accepting leaf among the 27 neighbours; patch-frame coordinates
+//   4 pc_moment_kernel    one wave per leaf: 27 neighbour segments (binary search in the leaf table), sphere test by
+//                         ballot; the hits' exact products go to LDS in hit order and 16 lanes (one matrix entry each)
+//                         add them up in the oracle's order -- the only serial chain is one f64 add per hit
+//     pc_frame_kernel     one thread per leaf: cyclic Jacobi eigen-solve of the 4x4 moment matrix, frame (:37-63)
+//   5 pc_claim_kernel     one wave per leaf: the 27 candidate frames sit in LDS, the leaf's own points test them in
+//                         leaf order and stop at the first that accepts; patch-frame coordinates; counts
 //   6 pc_emit_kernel      one wave per leaf: ordered compaction (ballot + prefix popcount) of the points it owns, depth
 //                         mean as the oracle's sequential sum, colour means, mean removal, centre shift, mask W
+// Scratch lives in the context's grow-only workspace and the result in one allocation: a call costs three small
+// device->host reads (bounds, leaf count, totals) and no allocation in steady state beyond the result's.
 // Bit-exactness: floating-point contraction is off for this file and every expression is written in the association of
 // oracle/gpc_oracle_producer.c; products of two floats are exact in double, so the moment sums only fix the ORDER.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -64,6 +70,7 @@ __host__ __device__ static inline float pc_unordered(uint32_t o)
 // out[0..2] = ordered min, out[3..5] = ordered max, out[6] = 1 if a coordinate is not finite
 __global__ __launch_bounds__(PC_THREADS) void pc_bounds_kernel(const gpc_point_xyzrgb* cloud, int n, uint32_t* out)
 {
+    __shared__ uint32_t red[PC_WAVES][8];
     uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0, 0, 0};
     int bad = 0;
     for (int i = blockIdx.x * PC_THREADS + threadIdx.x; i < n; i += gridDim.x * PC_THREADS) {
@@ -85,13 +92,18 @@ __global__ __launch_bounds__(PC_THREADS) void pc_bounds_kernel(const gpc_point_x
         }
     }
     bad = __any(bad);
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&out[a], lo[a]);
-            atomicMax(&out[3 + a], hi[a]);
-        }
-        if (bad) atomicOr(&out[6], 1u);
+        for (int a = 0; a < 3; ++a) { red[w][a] = lo[a]; red[w][3 + a] = hi[a]; }
+        red[w][6] = (uint32_t)bad;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int a = threadIdx.x;
+        uint32_t v = red[0][a];
+        for (int q = 1; q < PC_WAVES; ++q) v = a < 3 ? min(v, red[q][a]) : max(v, red[q][a]);   // [6]: 0 / 1, max == or
+        if (a < 3) atomicMin(&out[a], v); else if (a < 6) atomicMax(&out[a], v); else if (v) atomicOr(&out[6], 1u);
     }
 }
 
@@ -201,12 +213,15 @@ __device__ static inline void pc_smallest_eigvec4(double A[4][4], double v[4])
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int q = p + 1; q < 4; ++q) offd += A[p][q] * A[p][q];
-        if (offd < 1e-300) break;
+        if (offd == 0.0) break;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
 #pragma unroll
             for (int q = p + 1; q < 4; ++q) {
-                if (!(fabs(A[p][q]) < 1e-300)) {
+                const double g = 100.0 * fabs(A[p][q]);       // negligible against both diagonal entries: drop it
+                const bool drop = fabs(A[p][p]) + g == fabs(A[p][p]) && fabs(A[q][q]) + g == fabs(A[q][q]);
+                if (A[p][q] != 0.0 && drop) A[p][q] = A[q][p] = 0.0;
+                if (A[p][q] != 0.0) {
                     const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
                     const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                     const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
@@ -222,6 +237,7 @@ __device__ static inline void pc_smallest_eigvec4(double A[4][4], double v[4])
                         A[p][k] = c * apk - s * aqk;
                         A[q][k] = s * apk + c * aqk;
                     }
+                    A[p][q] = A[q][p] = 0.0;                  // the rotation annihilates this pair: make it exact
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const double vkp = V[k][p], vkq = V[k][q];
@@ -265,6 +281,9 @@ struct PcArgs {
     const int32_t* vals;
     const PcPoint* sp;
     int32_t* nbr;          // P x 27 neighbour leaf ids (-1: empty voxel), (dz, dy, dx) order = ascending leaf order
+    double* M;             // P x 16 moment matrices
+    int32_t* kcount;       // P: points in the search sphere
+    double* cen;           // P x 3 voxel centres
     int32_t* owner;        // per sorted position: owning leaf or -1
     double *py, *px0, *px1;   // per sorted position: patch-frame coordinates in the owner's frame
     int32_t* cnt;          // P + 1: points owned per leaf (cnt[P] = 0)
@@ -276,12 +295,17 @@ struct PcArgs {
     int32_t* src;
 };
 
-__global__ __launch_bounds__(PC_THREADS) void pc_rotation_kernel(PcArgs A)
+#define PC_LROW 66         // LDS row pitch (doubles) of the product table: 64 hits + padding against bank conflicts
+
+__global__ __launch_bounds__(PC_THREADS) void pc_moment_kernel(PcArgs A)
 {
-    const int lane = threadIdx.x & 63;
-    const int leaf = blockIdx.x * PC_WAVES + (threadIdx.x >> 6);
+    // per wave: 10 rows (xx xy xz x yy yz y zz z 1) of the hits of one 64-point chunk, in hit order
+    __shared__ double prod[PC_WAVES][10 * PC_LROW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int leaf = blockIdx.x * PC_WAVES + w;
     if (leaf >= A.P) return;                                  // whole waves leave; no block-level synchronisation below
     const PcGrid& g = A.g;
+    double* pr = prod[w];
     int k3[3];
     pc_unpack(g, A.leaf_key[leaf], k3);
     double center[3];
@@ -296,42 +320,60 @@ __global__ __launch_bounds__(PC_THREADS) void pc_rotation_kernel(PcArgs A)
         A.nbr[(size_t)leaf * 27 + lane] = nb;
         if (nb >= 0) { seg0 = A.leaf_start[nb]; seg1 = A.leaf_start[nb + 1]; }
     }
+    if (lane < 3) A.cen[(size_t)leaf * 3 + lane] = lane == 0 ? center[0] : (lane == 1 ? center[1] : center[2]);
+    pr[9 * PC_LROW + lane] = 1.0;                             // the homogeneous coordinate's products
     const double r2 = g.radius * g.radius;
-    const int ea = (lane >> 2) & 3, eb = lane & 3;            // lanes 0..15: entry (ea, eb) of the moment matrix
+    // lanes 0..15: entry (ea, eb) of the moment matrix = product row of (min, max)
+    const int ea = (lane >> 2) & 3, eb = lane & 3, lo = min(ea, eb), hi = max(ea, eb);
+    const int row = (lo == 0 ? 0 : (lo == 1 ? 3 : (lo == 2 ? 5 : 6))) + hi;      // 0:0-3, 1:4-6, 2:7-8, 3:9
+    const double* mine = pr + row * PC_LROW;
     double M = 0.0;
     int k = 0;
     for (int j = 0; j < 27; ++j) {
         const int s0 = __builtin_amdgcn_readlane(seg0, j), s1 = __builtin_amdgcn_readlane(seg1, j);
         for (int base = s0; base < s1; base += 64) {
             const int s = base + lane;
-            float px = 0.f, py = 0.f, pz = 0.f;
+            double q0 = 0, q1 = 0, q2 = 0;
             bool in = false;
             if (s < s1) {
                 const float4 p = *reinterpret_cast<const float4*>(&A.sp[s]);
-                px = p.x; py = p.y; pz = p.z;
-                const double ex = (double)px - center[0], ey = (double)py - center[1], ez = (double)pz - center[2];
+                q0 = (double)p.x; q1 = (double)p.y; q2 = (double)p.z;
+                const double ex = q0 - center[0], ey = q1 - center[1], ez = q2 - center[2];
                 in = ex * ex + ey * ey + ez * ez <= r2;
             }
-            unsigned long long mask = __ballot(in);
-            k += __popcll(mask);
-            while (mask) {                                    // radiusSearch hit order = the oracle's accumulation order
-                const int b = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const double q0 = (double)pc_readlane_f(px, b), q1 = (double)pc_readlane_f(py, b), q2 = (double)pc_readlane_f(pz, b);
-                const double va = ea == 0 ? q0 : (ea == 1 ? q1 : (ea == 2 ? q2 : 1.0));
-                const double vb = eb == 0 ? q0 : (eb == 1 ? q1 : (eb == 2 ? q2 : 1.0));
-                M += va * vb;
+            const unsigned long long mask = __ballot(in);
+            const int hits = __popcll(mask);
+            if (in) {                                         // radiusSearch hit order = the oracle's accumulation order
+                const int r = __popcll(mask & ((1ull << lane) - 1));
+                pr[0 * PC_LROW + r] = q0 * q0; pr[1 * PC_LROW + r] = q0 * q1; pr[2 * PC_LROW + r] = q0 * q2; pr[3 * PC_LROW + r] = q0;
+                pr[4 * PC_LROW + r] = q1 * q1; pr[5 * PC_LROW + r] = q1 * q2; pr[6 * PC_LROW + r] = q1;
+                pr[7 * PC_LROW + r] = q2 * q2; pr[8 * PC_LROW + r] = q2;
             }
+            __builtin_amdgcn_wave_barrier();                  // LDS is in order within a wave; keep the compiler in order too
+#pragma unroll 8
+            for (int r = 0; r < hits; ++r) M += mine[r];
+            __builtin_amdgcn_wave_barrier();
+            k += hits;
         }
     }
+    if (lane < 16) A.M[(size_t)leaf * 16 + lane] = M;
+    if (lane == 0) A.kcount[leaf] = k;
+}
+
+#define PC_FRAME_THREADS 64     // one wave per workgroup: the leaves spread over as many CUs as possible
+
+__global__ __launch_bounds__(PC_FRAME_THREADS) void pc_frame_kernel(PcArgs A)
+{
+    const int leaf = blockIdx.x * PC_FRAME_THREADS + threadIdx.x;
+    if (leaf >= A.P) return;
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (k >= 4) {                                             // :31-34
+    if (A.kcount[leaf] >= 4) {                                // :31-34
         double Mm[4][4], v[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) Mm[a][b] = pc_readlane_d(M, 4 * a + b);
-        pc_smallest_eigvec4(Mm, v);                          // wave-uniform: every lane solves the same 4x4 problem
+            for (int b = 0; b < 4; ++b) Mm[a][b] = A.M[(size_t)leaf * 16 + 4 * a + b];
+        pc_smallest_eigvec4(Mm, v);
         double normal[3] = {v[0], v[1], v[2]};
         pc_normalize(normal);
         const double x[3] = {1, 0, 0}, y[3] = {0, 1, 0}, z[3] = {0, 0, 1};
@@ -352,47 +394,64 @@ __global__ __launch_bounds__(PC_THREADS) void pc_rotation_kernel(PcArgs A)
 #pragma unroll
         for (int a = 0; a < 3; ++a) { R[a] = normal[a]; R[3 + a] = c1[a]; R[6 + a] = c2[a]; }
     }
-    if (lane < 9) {
-        double r = R[0];
 #pragma unroll
-        for (int i = 1; i < 9; ++i) r = lane == i ? R[i] : r;
-        A.R[(size_t)leaf * 9 + lane] = r;
-    }
+    for (int i = 0; i < 9; ++i) A.R[(size_t)leaf * 9 + i] = R[i];
 }
 
 // ---- 5: ownership ----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PC_THREADS) void pc_claim_kernel(PcArgs A)
 {
-    const int s = blockIdx.x * PC_THREADS + threadIdx.x;
-    if (s >= A.n) return;
+    __shared__ double frames[PC_WAVES][27][12];               // per wave: centre (3) + R (9) of the 27 candidate leaves
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int leaf = blockIdx.x * PC_WAVES + w;
+    if (leaf >= A.P) return;
     const PcGrid& g = A.g;
-    const float4 p = *reinterpret_cast<const float4*>(&A.sp[s]);
-    const int32_t* nbr = A.nbr + (size_t)A.leaf_of[s] * 27;
-    const double r2 = g.radius * g.radius;
-    int owner = -1;
-    double pt[3] = {0, 0, 0};
-    for (int j = 0; j < 27 && owner < 0; ++j) {
-        const int L = nbr[j];
-        if (L < 0) continue;
-        int k3[3];
-        pc_unpack(g, A.leaf_key[L], k3);
-        double c[3];
-        pc_center(g, k3, c);
-        const double d[3] = {(double)p.x - c[0], (double)p.y - c[1], (double)p.z - c[2]};
-        if (!(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] <= r2)) continue;          // not in this leaf's search sphere
-        const double* R = A.R + (size_t)L * 9;
-        double q[3];
+    int nb = -1;
+    if (lane < 27) {
+        nb = A.nbr[(size_t)leaf * 27 + lane];
+        if (nb >= 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) q[a] = R[3 * a] * d[0] + R[3 * a + 1] * d[1] + R[3 * a + 2] * d[2];   // R^T d  (:84)
-        if (q[1] > g.half || q[1] < -g.half || q[2] > g.half || q[2] < -g.half) continue;                // :85-87
-        owner = L;
-        pt[0] = q[0]; pt[1] = q[1]; pt[2] = q[2];
+            for (int i = 0; i < 3; ++i) frames[w][lane][i] = A.cen[(size_t)nb * 3 + i];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) frames[w][lane][3 + i] = A.R[(size_t)nb * 9 + i];
+        }
     }
-    A.owner[s] = owner;
-    A.py[s] = pt[0];
-    A.px0[s] = pt[1];
-    A.px1[s] = pt[2];
-    if (owner >= 0) atomicAdd(&A.cnt[owner], 1);
+    __builtin_amdgcn_wave_barrier();
+    const double r2 = g.radius * g.radius;
+    const int s0 = A.leaf_start[leaf], s1 = A.leaf_start[leaf + 1];
+    for (int base = s0; base < s1; base += 64) {
+        const int s = base + lane;
+        const bool valid = s < s1;
+        double p[3] = {0, 0, 0};
+        if (valid) {
+            const float4 f = *reinterpret_cast<const float4*>(&A.sp[s]);
+            p[0] = (double)f.x; p[1] = (double)f.y; p[2] = (double)f.z;
+        }
+        int owner = -1;
+        double pt[3] = {0, 0, 0};
+        for (int j = 0; j < 27; ++j) {                        // candidates in leaf order: the first that accepts owns the point
+            const int L = __builtin_amdgcn_readlane(nb, j);
+            if (L < 0) continue;
+            if (!__any(valid && owner < 0)) break;
+            const double* fr = frames[w][j];
+            const double d[3] = {p[0] - fr[0], p[1] - fr[1], p[2] - fr[2]};
+            const bool in = valid && owner < 0 && d[0] * d[0] + d[1] * d[1] + d[2] * d[2] <= r2;    // in L's search sphere
+            if (!__any(in)) continue;
+            double q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) q[a] = fr[3 + 3 * a] * d[0] + fr[3 + 3 * a + 1] * d[1] + fr[3 + 3 * a + 2] * d[2];   // R^T d  (:84)
+            const bool acc = in && !(q[1] > g.half || q[1] < -g.half || q[2] > g.half || q[2] < -g.half);     // :85-87
+            if (acc) { owner = L; pt[0] = q[0]; pt[1] = q[1]; pt[2] = q[2]; }
+            const int c = __popcll(__ballot(acc));
+            if (c && lane == 0) atomicAdd(&A.cnt[L], c);
+        }
+        if (valid) {
+            A.owner[s] = owner;
+            A.py[s] = pt[0];
+            A.px0[s] = pt[1];
+            A.px1[s] = pt[2];
+        }
+    }
 }
 
 __global__ __launch_bounds__(PC_THREADS) void pc_nmax_kernel(const int32_t* cnt, int P, int32_t* nmax)
@@ -491,27 +550,11 @@ __global__ __launch_bounds__(PC_THREADS) void pc_emit_kernel(PcArgs A)
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 struct gpc_patches {
     gpc_ctx* ctx = nullptr;
-    gpc_patches_view v{};       // device pointers
-    void* bufs[12] = {};
-    int nbufs = 0;
+    gpc_patches_view v{};       // device pointers into `block`
+    void* block = nullptr;      // one allocation holds every array of the batch
 };
 
 namespace {
-
-struct DevBufs {                // scratch that dies with the call
-    void* p[24] = {};
-    int n = 0;
-    hipError_t get(void** out, size_t bytes)
-    {
-        hipError_t e = hipMalloc(out, bytes ? bytes : 1);
-        if (e == hipSuccess) p[n++] = *out;
-        return e;
-    }
-    ~DevBufs()
-    {
-        for (int i = 0; i < n; ++i) (void)hipFree(p[i]);
-    }
-};
 
 int bits_for(int kmax)
 {
@@ -520,11 +563,48 @@ int bits_for(int kmax)
     return b;
 }
 
-hipError_t keep(gpc_patches* o, void** out, size_t bytes)
+// carves 256-byte aligned pieces out of one buffer; with base == nullptr it only measures
+struct Carver {
+    char* base;
+    size_t used = 0;
+    explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+    template <class T> T* take(size_t count)
+    {
+        T* p = base ? reinterpret_cast<T*>(base + used) : nullptr;
+        used += (count * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+struct Scratch {                // per call, in the context's workspace
+    uint32_t* bounds;
+    uint64_t *k0, *k1, *leaf_key;
+    int32_t *v0, *vals, *head, *leaf_of, *leaf_start, *nbr, *kcount, *owner, *cnt;
+    PcPoint* sp;
+    double *py, *px0, *px1, *M, *cen;
+    void* prim;
+    size_t prim_bytes;
+};
+
+size_t carve_scratch(Carver& c, Scratch& s, size_t n, size_t pb, size_t prim_bytes)
 {
-    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
-    if (e == hipSuccess) o->bufs[o->nbufs++] = *out;
-    return e;
+    s.bounds = c.take<uint32_t>(8);
+    s.k0 = c.take<uint64_t>(n); s.k1 = c.take<uint64_t>(n);
+    s.v0 = c.take<int32_t>(n); s.vals = c.take<int32_t>(n);
+    s.head = c.take<int32_t>(n); s.leaf_of = c.take<int32_t>(n);
+    s.owner = c.take<int32_t>(n);
+    s.sp = c.take<PcPoint>(n);
+    s.py = c.take<double>(n); s.px0 = c.take<double>(n); s.px1 = c.take<double>(n);
+    s.leaf_key = c.take<uint64_t>(pb);
+    s.leaf_start = c.take<int32_t>(pb + 1);
+    s.nbr = c.take<int32_t>(27 * pb);
+    s.kcount = c.take<int32_t>(pb);
+    s.cnt = c.take<int32_t>(pb + 2);
+    s.M = c.take<double>(16 * pb);
+    s.cen = c.take<double>(3 * pb);
+    s.prim = c.take<char>(prim_bytes);
+    s.prim_bytes = prim_bytes;
+    return c.used;
 }
 
 }  // namespace
@@ -544,7 +624,7 @@ extern "C" {
 void gpc_patches_destroy(gpc_patches* o)
 {
     if (!o) return;
-    for (int i = 0; i < o->nbufs; ++i) (void)hipFree(o->bufs[i]);
+    if (o->block) (void)hipFree(o->block);
     delete o;
 }
 
@@ -563,24 +643,26 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
     gpc_patches* o = new gpc_patches;
     o->ctx = ctx;
     o->v.m = sz * sz;
-    int32_t* d_off = nullptr;
     if (n == 0) {
-        PC_HIP(keep(o, (void**)&d_off, sizeof(int32_t)));
-        PC_HIP(hipMemsetAsync(d_off, 0, sizeof(int32_t), st));
+        PC_HIP(hipMalloc(&o->block, 256));
+        PC_HIP(hipMemsetAsync(o->block, 0, 256, st));
         PC_HIP(hipStreamSynchronize(st));
-        o->v.off = d_off;
+        o->v.off = static_cast<int32_t*>(o->block);
         *out = o;
         return GPC_OK;
     }
-    DevBufs tmp;
     const int nblk = (n + PC_THREADS - 1) / PC_THREADS;
+    const size_t N = (size_t)n;
 
-    // 1: bounds
-    uint32_t* d_bounds = nullptr;
-    PC_HIP(tmp.get((void**)&d_bounds, 8 * sizeof(uint32_t)));
+    // 1: bounds (its 32 bytes of scratch sit at the start of the workspace whatever the leaf bound turns out to be)
+    {
+        const int rc = gpc_ws_reserve(ctx, 4096);
+        if (rc != GPC_OK) { gpc_patches_destroy(o); return rc; }
+    }
+    uint32_t* d_bounds = static_cast<uint32_t*>(ctx->ws);
     const uint32_t init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0, 0, 0};
     PC_HIP(hipMemcpyAsync(d_bounds, init, sizeof(init), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(pc_bounds_kernel, dim3(nblk < ctx->num_cus * 8 ? nblk : ctx->num_cus * 8), dim3(PC_THREADS), 0, st, cloud, n, d_bounds);
+    hipLaunchKernelGGL(pc_bounds_kernel, dim3(nblk < ctx->num_cus * 4 ? nblk : ctx->num_cus * 4), dim3(PC_THREADS), 0, st, cloud, n, d_bounds);
     PC_HIP(hipGetLastError());
     uint32_t hb[8];
     PC_HIP(hipMemcpyAsync(hb, d_bounds, sizeof(hb), hipMemcpyDeviceToHost, st));
@@ -594,6 +676,7 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
     g.radius = std::sqrt(3.0f) / 2.0f * res;            // :194
     g.half = res / 2.0f;
     g.sz = sz;
+    double cells = 1.0;
     for (int a = 0; a < 3; ++a) {
         g.mn[a] = (double)pc_unordered(hb[a]);
         const double ext = std::floor(((double)pc_unordered(hb[3 + a]) - g.mn[a]) / res);
@@ -602,104 +685,104 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
             return gpc_fail(ctx, GPC_ERANGE, "more than 2^21 voxels of side res along an axis");
         }
         g.kmax[a] = (int)ext;
+        cells *= ext + 1.0;
     }
     g.bx = bits_for(g.kmax[0]); g.by = bits_for(g.kmax[1]); g.bz = bits_for(g.kmax[2]);
     const int key_bits = g.bx + g.by + g.bz;           // <= 63
+    const size_t pb = cells < (double)n ? (size_t)cells : N;   // bound on the number of leaves
+
+    // scratch
+    size_t sort_bytes = 0, scan_bytes = 0, scan2_bytes = 0;
+    PC_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, N,
+                                     0u, (unsigned)key_bits, st));
+    PC_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, (int32_t*)nullptr, (int32_t*)nullptr, N, rocprim::plus<int32_t>(), st));
+    PC_HIP(rocprim::exclusive_scan(nullptr, scan2_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, pb + 1, rocprim::plus<int32_t>(), st));
+    const size_t prim_bytes = std::max(sort_bytes, std::max(scan_bytes, scan2_bytes));
+    Scratch S;
+    {
+        Carver measure(nullptr);
+        const int rc = gpc_ws_reserve(ctx, carve_scratch(measure, S, N, pb, prim_bytes));
+        if (rc != GPC_OK) { gpc_patches_destroy(o); return rc; }
+        Carver c(ctx->ws);
+        carve_scratch(c, S, N, pb, prim_bytes);
+    }
 
     // 2: keys, stable sort, leaf table
-    uint64_t *d_k0 = nullptr, *d_k1 = nullptr;
-    int32_t *d_v0 = nullptr, *d_vals = nullptr, *d_head = nullptr, *d_leaf_of = nullptr;
-    PC_HIP(tmp.get((void**)&d_k0, sizeof(uint64_t) * (size_t)n));
-    PC_HIP(tmp.get((void**)&d_k1, sizeof(uint64_t) * (size_t)n));
-    PC_HIP(tmp.get((void**)&d_v0, sizeof(int32_t) * (size_t)n));
-    PC_HIP(tmp.get((void**)&d_vals, sizeof(int32_t) * (size_t)n));
-    PC_HIP(tmp.get((void**)&d_head, sizeof(int32_t) * (size_t)n));
-    PC_HIP(tmp.get((void**)&d_leaf_of, sizeof(int32_t) * (size_t)n));
-    hipLaunchKernelGGL(pc_keys_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, g, cloud, n, d_k0, d_v0);
+    hipLaunchKernelGGL(pc_keys_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, g, cloud, n, S.k0, S.v0);
     PC_HIP(hipGetLastError());
-    size_t sort_bytes = 0, scan_bytes = 0, scan2_bytes = 0;
-    PC_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, d_k0, d_k1, d_v0, d_vals, (size_t)n, 0u, (unsigned)key_bits, st));
-    PC_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, d_head, d_leaf_of, (size_t)n, rocprim::plus<int32_t>(), st));
-    void* d_tmp = nullptr;
-    PC_HIP(tmp.get(&d_tmp, sort_bytes > scan_bytes ? sort_bytes : scan_bytes));
-    PC_HIP(rocprim::radix_sort_pairs(d_tmp, sort_bytes, d_k0, d_k1, d_v0, d_vals, (size_t)n, 0u, (unsigned)key_bits, st));
-    hipLaunchKernelGGL(pc_heads_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, d_k1, n, d_head);
+    size_t tb = S.prim_bytes;
+    PC_HIP(rocprim::radix_sort_pairs(S.prim, tb, S.k0, S.k1, S.v0, S.vals, N, 0u, (unsigned)key_bits, st));
+    hipLaunchKernelGGL(pc_heads_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, S.k1, n, S.head);
     PC_HIP(hipGetLastError());
-    PC_HIP(rocprim::inclusive_scan(d_tmp, scan_bytes, d_head, d_leaf_of, (size_t)n, rocprim::plus<int32_t>(), st));
+    tb = S.prim_bytes;
+    PC_HIP(rocprim::inclusive_scan(S.prim, tb, S.head, S.leaf_of, N, rocprim::plus<int32_t>(), st));
     int32_t P = 0;
-    PC_HIP(hipMemcpyAsync(&P, d_leaf_of + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipMemcpyAsync(&P, S.leaf_of + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // 3: sorted-order copy (does not need P: overlaps the read-back)
+    hipLaunchKernelGGL(pc_gather_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, cloud, S.vals, n, S.sp);
+    PC_HIP(hipGetLastError());
     PC_HIP(hipStreamSynchronize(st));
     if ((long long)P * (long long)(sz * sz) > 0x7fffffffLL) {
         gpc_patches_destroy(o);
         return gpc_fail(ctx, GPC_ERANGE, "P * sz * sz exceeds 2^31-1");
     }
+    if ((size_t)P > pb) {
+        gpc_patches_destroy(o);
+        return gpc_fail(ctx, GPC_EHIP, "internal: %d leaves exceed the bound %zu", (int)P, pb);
+    }
 
+    // the result: one block; per-point arrays are sized by n (an upper bound of the points owned)
+    const size_t Pz = (size_t)P, m = (size_t)(sz * sz);
+    Carver oc(nullptr);
+    for (int pass = 0; pass < 2; ++pass) {
+        oc = Carver(pass ? o->block : nullptr);
+        o->v.off = oc.take<int32_t>(Pz + 1);
+        o->v.rotations = oc.take<double>(9 * Pz);
+        o->v.means = oc.take<double>(3 * Pz);
+        o->v.rgb_means = oc.take<double>(3 * Pz);
+        o->v.W = oc.take<uint8_t>(Pz * m);
+        o->v.x0 = oc.take<double>(N);
+        o->v.x1 = oc.take<double>(N);
+        o->v.y = oc.take<double>(N);
+        o->v.rgb = oc.take<double>(3 * N);
+        o->v.src = oc.take<int32_t>(N);
+        if (!pass) PC_HIP(hipMalloc(&o->block, oc.used));
+    }
     PcArgs A;
     memset(&A, 0, sizeof(A));
     A.g = g; A.n = n; A.P = P;
-    uint64_t* d_leaf_key = nullptr;
-    int32_t *d_leaf_start = nullptr, *d_nbr = nullptr, *d_owner = nullptr, *d_cnt = nullptr, *d_nmax = nullptr;
-    PcPoint* d_sp = nullptr;
-    double *d_py = nullptr, *d_px0 = nullptr, *d_px1 = nullptr;
-    PC_HIP(tmp.get((void**)&d_leaf_key, sizeof(uint64_t) * (size_t)P));
-    PC_HIP(tmp.get((void**)&d_leaf_start, sizeof(int32_t) * ((size_t)P + 1)));
-    PC_HIP(tmp.get((void**)&d_nbr, sizeof(int32_t) * 27 * (size_t)P));
-    PC_HIP(tmp.get((void**)&d_owner, sizeof(int32_t) * (size_t)n));
-    PC_HIP(tmp.get((void**)&d_cnt, sizeof(int32_t) * ((size_t)P + 2)));
-    PC_HIP(tmp.get((void**)&d_sp, sizeof(PcPoint) * (size_t)n));
-    PC_HIP(tmp.get((void**)&d_py, sizeof(double) * (size_t)n));
-    PC_HIP(tmp.get((void**)&d_px0, sizeof(double) * (size_t)n));
-    PC_HIP(tmp.get((void**)&d_px1, sizeof(double) * (size_t)n));
-    d_nmax = d_cnt + (P + 1);
-    double *d_R = nullptr, *d_mean = nullptr, *d_cmean = nullptr;
-    uint8_t* d_W = nullptr;
-    PC_HIP(keep(o, (void**)&d_off, sizeof(int32_t) * ((size_t)P + 1)));
-    PC_HIP(keep(o, (void**)&d_R, sizeof(double) * 9 * (size_t)P));
-    PC_HIP(keep(o, (void**)&d_mean, sizeof(double) * 3 * (size_t)P));
-    PC_HIP(keep(o, (void**)&d_cmean, sizeof(double) * 3 * (size_t)P));
-    PC_HIP(keep(o, (void**)&d_W, (size_t)P * (size_t)(sz * sz)));
-    PC_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * ((size_t)P + 2), st));
-    PC_HIP(hipMemsetAsync(d_W, 0, (size_t)P * (size_t)(sz * sz), st));
-    A.leaf_key = d_leaf_key; A.leaf_start = d_leaf_start; A.leaf_of = d_leaf_of; A.vals = d_vals; A.sp = d_sp;
-    A.nbr = d_nbr; A.owner = d_owner; A.py = d_py; A.px0 = d_px0; A.px1 = d_px1; A.cnt = d_cnt; A.off = d_off; A.nmax = d_nmax;
-    A.R = d_R; A.mean = d_mean; A.rgb_mean = d_cmean; A.W = d_W;
-    hipLaunchKernelGGL(pc_leaves_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, d_k1, n, (int)P, d_leaf_of, d_leaf_key, d_leaf_start);
-    PC_HIP(hipGetLastError());
-    // 3: sorted-order copy
-    hipLaunchKernelGGL(pc_gather_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, cloud, d_vals, n, d_sp);
+    A.leaf_key = S.leaf_key; A.leaf_start = S.leaf_start; A.leaf_of = S.leaf_of; A.vals = S.vals; A.sp = S.sp;
+    A.nbr = S.nbr; A.M = S.M; A.kcount = S.kcount; A.cen = S.cen; A.owner = S.owner; A.py = S.py; A.px0 = S.px0; A.px1 = S.px1;
+    A.cnt = S.cnt; A.nmax = S.cnt + (P + 1);
+    A.off = const_cast<int32_t*>(o->v.off); A.R = const_cast<double*>(o->v.rotations); A.mean = const_cast<double*>(o->v.means);
+    A.rgb_mean = const_cast<double*>(o->v.rgb_means); A.W = const_cast<uint8_t*>(o->v.W);
+    A.x0 = const_cast<double*>(o->v.x0); A.x1 = const_cast<double*>(o->v.x1); A.y = const_cast<double*>(o->v.y);
+    A.rgb = const_cast<double*>(o->v.rgb); A.src = const_cast<int32_t*>(o->v.src);
+    PC_HIP(hipMemsetAsync(S.cnt, 0, sizeof(int32_t) * (Pz + 2), st));
+    PC_HIP(hipMemsetAsync(A.W, 0, Pz * m, st));
+    hipLaunchKernelGGL(pc_leaves_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, S.k1, n, (int)P, S.leaf_of, S.leaf_key, S.leaf_start);
     PC_HIP(hipGetLastError());
     // 4: frames
     const int lblk = (P + PC_WAVES - 1) / PC_WAVES;
-    hipLaunchKernelGGL(pc_rotation_kernel, dim3(lblk), dim3(PC_THREADS), 0, st, A);
+    hipLaunchKernelGGL(pc_moment_kernel, dim3(lblk), dim3(PC_THREADS), 0, st, A);
+    PC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(pc_frame_kernel, dim3((P + PC_FRAME_THREADS - 1) / PC_FRAME_THREADS), dim3(PC_FRAME_THREADS), 0, st, A);
     PC_HIP(hipGetLastError());
     // 5: ownership, offsets
-    hipLaunchKernelGGL(pc_claim_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, A);
+    hipLaunchKernelGGL(pc_claim_kernel, dim3(lblk), dim3(PC_THREADS), 0, st, A);
     PC_HIP(hipGetLastError());
-    PC_HIP(rocprim::exclusive_scan(nullptr, scan2_bytes, d_cnt, d_off, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), st));
-    void* d_tmp2 = nullptr;
-    PC_HIP(tmp.get(&d_tmp2, scan2_bytes));
-    PC_HIP(rocprim::exclusive_scan(d_tmp2, scan2_bytes, d_cnt, d_off, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), st));
-    hipLaunchKernelGGL(pc_nmax_kernel, dim3(64), dim3(PC_THREADS), 0, st, d_cnt, (int)P, d_nmax);
+    tb = S.prim_bytes;
+    PC_HIP(rocprim::exclusive_scan(S.prim, tb, S.cnt, A.off, (int32_t)0, Pz + 1, rocprim::plus<int32_t>(), st));
+    hipLaunchKernelGGL(pc_nmax_kernel, dim3(64), dim3(PC_THREADS), 0, st, S.cnt, (int)P, A.nmax);
     PC_HIP(hipGetLastError());
-    int32_t total = 0, nmax = 0;
-    PC_HIP(hipMemcpyAsync(&total, d_off + P, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    PC_HIP(hipMemcpyAsync(&nmax, d_nmax, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    PC_HIP(hipStreamSynchronize(st));
-    // 6: the patch batch
-    double *d_x0 = nullptr, *d_x1 = nullptr, *d_y = nullptr, *d_rgb = nullptr;
-    int32_t* d_src = nullptr;
-    PC_HIP(keep(o, (void**)&d_x0, sizeof(double) * (size_t)total));
-    PC_HIP(keep(o, (void**)&d_x1, sizeof(double) * (size_t)total));
-    PC_HIP(keep(o, (void**)&d_y, sizeof(double) * (size_t)total));
-    PC_HIP(keep(o, (void**)&d_rgb, sizeof(double) * 3 * (size_t)total));
-    PC_HIP(keep(o, (void**)&d_src, sizeof(int32_t) * (size_t)total));
-    A.x0 = d_x0; A.x1 = d_x1; A.y = d_y; A.rgb = d_rgb; A.src = d_src;
+    // 6: the patch batch (the colour planes' pitch is the total, read from off[P] on the device)
     hipLaunchKernelGGL(pc_emit_kernel, dim3(lblk), dim3(PC_THREADS), 0, st, A);
     PC_HIP(hipGetLastError());
-    PC_HIP(hipStreamSynchronize(st));                  // the scratch buffers are freed on return
+    int32_t total = 0, nmax = 0;
+    PC_HIP(hipMemcpyAsync(&total, A.off + P, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipMemcpyAsync(&nmax, A.nmax, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
     o->v.P = P; o->v.n_total = total; o->v.n_max = nmax;
-    o->v.off = d_off; o->v.x0 = d_x0; o->v.x1 = d_x1; o->v.y = d_y; o->v.rgb = d_rgb; o->v.rotations = d_R; o->v.means = d_mean;
-    o->v.rgb_means = d_cmean; o->v.W = d_W; o->v.src = d_src;
     *out = o;
     return GPC_OK;
 }

@@ -43,10 +43,15 @@ void smallest_eigvec4(double A[4][4], double v[4])
         double offd = 0;
         for (int p = 0; p < 4; ++p)
             for (int q = p + 1; q < 4; ++q) offd += A[p][q] * A[p][q];
-        if (offd < 1e-300) break;
+        if (offd == 0.0) break;
         for (int p = 0; p < 4; ++p) {
             for (int q = p + 1; q < 4; ++q) {
-                if (std::fabs(A[p][q]) < 1e-300) continue;
+                if (A[p][q] == 0.0) continue;
+                const double g = 100.0 * std::fabs(A[p][q]);     // negligible against both diagonal entries: drop it
+                if (std::fabs(A[p][p]) + g == std::fabs(A[p][p]) && std::fabs(A[q][q]) + g == std::fabs(A[q][q])) {
+                    A[p][q] = A[q][p] = 0.0;
+                    continue;
+                }
                 const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
                 const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
@@ -60,6 +65,7 @@ void smallest_eigvec4(double A[4][4], double v[4])
                     A[p][k] = c * apk - s * aqk;
                     A[q][k] = s * apk + c * aqk;
                 }
+                A[p][q] = A[q][p] = 0.0;                       // the rotation annihilates this pair: make it exact
                 for (int k = 0; k < 4; ++k) {
                     const double vkp = V[k][p], vkq = V[k][q];
                     V[k][p] = c * vkp - s * vkq;

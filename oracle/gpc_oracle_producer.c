@@ -50,7 +50,8 @@ static int find_leaf(const pkey* leaves, int P, int x, int y, int z)
     return -1;
 }
 
-/* eigenvector of the smallest eigenvalue of the symmetric 4x4 matrix A (destroyed): cyclic Jacobi */
+/* eigenvector of the smallest eigenvalue of the symmetric 4x4 matrix A (destroyed): cyclic Jacobi with exact
+ * annihilation, run until the off-diagonal part is exactly zero (6-8 sweeps) */
 void orc_smallest_eigvec4(double A[4][4], double v[4])
 {
     double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
@@ -58,10 +59,15 @@ void orc_smallest_eigvec4(double A[4][4], double v[4])
         double offd = 0;
         for (int p = 0; p < 4; ++p)
             for (int q = p + 1; q < 4; ++q) offd += A[p][q] * A[p][q];
-        if (offd < 1e-300) break;
+        if (offd == 0.0) break;
         for (int p = 0; p < 4; ++p) {
             for (int q = p + 1; q < 4; ++q) {
-                if (fabs(A[p][q]) < 1e-300) continue;
+                if (A[p][q] == 0.0) continue;
+                const double g = 100.0 * fabs(A[p][q]);     /* negligible against both diagonal entries: drop it */
+                if (fabs(A[p][p]) + g == fabs(A[p][p]) && fabs(A[q][q]) + g == fabs(A[q][q])) {
+                    A[p][q] = A[q][p] = 0.0;
+                    continue;
+                }
                 const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
@@ -75,6 +81,7 @@ void orc_smallest_eigvec4(double A[4][4], double v[4])
                     A[p][k] = c * apk - s * aqk;
                     A[q][k] = s * apk + c * aqk;
                 }
+                A[p][q] = A[q][p] = 0.0;                      /* the rotation annihilates this pair: make it exact */
                 for (int k = 0; k < 4; ++k) {
                     const double vkp = V[k][p], vkq = V[k][q];
                     V[k][p] = c * vkp - s * vkq;
