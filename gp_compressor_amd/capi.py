@@ -67,6 +67,8 @@ PROTOTYPES = {
     "gpc_sparse_predict_dev": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "gpc_sparse_likelihood": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_likelihood_dev": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gpc_sparse_train_sigmaf": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp]),
+    "gpc_sparse_train_sigmaf_dev": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp]),
     "gpc_sparse_sizes": (C.c_int, [_vp, _vp]),
     "gpc_sparse_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_ld": (C.c_int, [_vp]),
@@ -363,6 +365,26 @@ class Sparse:
     def likelihood_dev(self, off, n_total, x0, x1, y, dX=None, l=None):
         self.ctx._check(self.lib.gpc_sparse_likelihood_dev(self.h, _ptr(off), int(n_total), _ptr(x0), _ptr(x1), _ptr(y),
                                                            _ptr(dX), _ptr(l)))
+
+    def train_sigmaf(self, off, x0, x1, y, step=float(np.float32(1e-4)), max_counter=100):
+        """the live part of train_parameters (src/sparse_gp.hpp:586-640) per patch: returns p0 (P,), iters (P,),
+        ls (P, max_counter + 2), delta (P, 2)"""
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        assert off.shape[0] == self.P + 1 and y.shape[0] == int(off[-1])
+        p0 = np.full(self.P, np.nan)
+        iters = np.full(self.P, -1, dtype=np.int32)
+        ls = np.zeros((self.P, max_counter + 2))
+        delta = np.full((self.P, 2), np.nan)
+        self.ctx._check(self.lib.gpc_sparse_train_sigmaf(self.h, _ptr(off), _ptr(x0), _ptr(x1), _ptr(y), float(step), int(max_counter),
+                                                         _ptr(p0), _ptr(iters), _ptr(ls), _ptr(delta)))
+        return p0, iters, ls, delta
+
+    def train_sigmaf_dev(self, off, n_total, x0, x1, y, step, max_counter, p0, iters, ls, delta):
+        self.ctx._check(self.lib.gpc_sparse_train_sigmaf_dev(self.h, _ptr(off), int(n_total), _ptr(x0), _ptr(x1), _ptr(y), float(step),
+                                                             int(max_counter), _ptr(p0), _ptr(iters), _ptr(ls), _ptr(delta)))
 
     def sizes(self):
         b = np.zeros(self.P, dtype=np.int32)

@@ -639,6 +639,7 @@ struct SpLikParams {
     const double *alpha, *C, *BV;
     const int32_t* b;
     double *dX, *l;
+    double* raw;   // train_sigmaf pass (prm.sigmaf_sq == 1): per point e^T C e, alpha^T e, sum_j |x - BV_j|^2 e_j alpha_j
 };
 #define SP_NQ 12   // partial sums per thread: kCk, 2 x (k_dx^T v), ny x mu, 2 x ny x (k_dx^T alpha)
 
@@ -740,8 +741,87 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_likelihood_kernel(SpLikPara
                     }
                     d[0] = (ny == 1) ? (double)(-1.0f) / (sigma * sqrtsigma) * offv[0] * exppart : 0.0;   // field: dx(0) = 0
                 }
+                if (A.raw) {
+                    const double u0 = A.x0[o + p0 + tid], u1 = A.x1[o + p0 + tid];
+                    double h = 0.0;
+                    for (int j = 0; j < b; ++j) {
+                        const double d0 = u0 - bv[2 * j], d1 = u1 - bv[2 * j + 1];
+                        h += (d0 * d0 + d1 * d1) * Kc[j * SP_PC + tid] * al[j];
+                    }
+                    double* w = A.raw + (size_t)(o + p0 + tid) * 3;
+                    w[0] = r[0]; w[1] = r[3]; w[2] = h;
+                }
             }
         }
+    }
+}
+
+// ---- row f4: the live part of sparse_gp::train_parameters (src/sparse_gp.hpp:586-640) ---------------------------------
+// The inner do-loop holds the state (alpha, C, BV) fixed and moves only kernel.param()(0) = sigma_f^2 = p, and every
+// quantity it evaluates is a polynomial in p over per-point sums that do not depend on p:
+//     k = p e,   alpha^T k = p a_i,   k_dtheta(:,0)^T alpha = a_i,   k_dtheta(:,1)^T alpha = p 0.5f/p1^2 h_i,   k^T C k = p^2 q_i
+// with e_j = exp(-0.5f/p1 |x_i - BV_j|^2), a_i = alpha^T e, h_i = sum_j |x_i - BV_j|^2 e_j alpha_j, q_i = e^T C e.  The O(n b^2)
+// sums come from one pass of sparse_likelihood_kernel (MFMA C K) with sigma_f^2 = 1; the <= 102 iterations are then O(n)
+// each and run here, one wave per patch.
+struct SpTrainParams {
+    int P, max_counter;
+    double sf, l_sq, s20, step;
+    const int32_t *off, *b;
+    const double *raw, *y;
+    double *p0, *ls, *delta;
+    int32_t* iters;
+};
+
+__device__ static inline double sp_wave_sum(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);    // the same bits in every lane
+    return v;
+}
+
+__global__ __launch_bounds__(SP_THREADS) void sparse_train_kernel(SpTrainParams A)
+{
+    const int lane = threadIdx.x & 63;
+    const int patch = blockIdx.x * (SP_THREADS / 64) + (threadIdx.x >> 6);
+    if (patch >= A.P) return;
+    const int o = A.off[patch], n = A.off[patch + 1] - o;
+    double p = A.sf, d0 = 0.0, d1 = 0.0;
+    int iters = 0;
+    if (A.b[patch] >= 20) {                                        // "if (first && BV.cols() < 20) return;"  (:609-611)
+        const double logsqrt2pi = (double)0.5f * log((double)2.0f * 3.14159265358979323846);
+        const double hc = (double)0.5f / (A.l_sq * A.l_sq);
+        const double* raw = A.raw + (size_t)o * 3;
+        const double* y = A.y + o;
+        int counter = 0;
+        do {
+            d0 = d1 = 0.0;
+            for (int i = lane; i < n; i += 64) {                   // likelihood_dtheta (:510-519), summed over the points (:619-623)
+                const double a = raw[3 * i + 1], h = raw[3 * i + 2];
+                const double r = p * a - y[i];
+                d0 += r * a;
+                d1 += r * (p * hc * h);
+            }
+            d0 = sp_wave_sum(d0);
+            d1 = sp_wave_sum(d1);
+            p += A.step * d0;                                      // :624
+            double ls = 0.0;
+            for (int i = lane; i < n; i += 64) {                   // log_likelihood (:356-385) with the updated parameter
+                const double q = raw[3 * i], a = raw[3 * i + 1];
+                const double mu = p * a, sigma = A.s20 + p + p * p * q;
+                const double cent2 = (y[i] - mu) * (y[i] - mu);
+                ls += -logsqrt2pi - (double)0.5f * log(sigma) - (double)0.5f * cent2 / sigma;
+            }
+            ls = sp_wave_sum(ls);
+            if (lane == 0) A.ls[(size_t)patch * (A.max_counter + 2) + counter] = ls;
+            iters = counter + 1;
+            if (counter > A.max_counter) break;                    // :630-633
+            ++counter;
+        } while (sqrt(d0 * d0 + d1 * d1) > (double)1e-2f);         // :636 (a NaN gradient ends the loop as well)
+    }
+    if (lane == 0) {
+        A.p0[patch] = p;
+        A.iters[patch] = iters;
+        A.delta[2 * patch] = d0;
+        A.delta[2 * patch + 1] = d1;
     }
 }
 
@@ -886,20 +966,15 @@ int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double
     return GPC_OK;
 }
 
-int gpc_sparse_likelihood_dev(gpc_sparse* g, const int32_t* off, int n_total, const double* x0, const double* x1,
-                              const double* y, double* dX, double* l)
+// caller holds ctx->mu.  raw != nullptr: the train_sigmaf pass (sigma_f^2 = 1, per-point sums only)
+static int sp_likelihood_launch(gpc_sparse* g, const int32_t* off, int n_total, const double* x0, const double* x1, const double* y,
+                                double* dX, double* l, double* raw)
 {
-    if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
-    if (g->P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
-    if (n_total < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
-    if (n_total > 0 && (!x0 || !x1 || !y)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/y is NULL");
-    if (g->prm.noise_model != 0) return gpc_fail(ctx, GPC_EINVAL, "likelihoods are defined for the Gaussian noise model");
-    if (g->P == 0 || n_total == 0 || (!dX && !l)) return GPC_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    GPC_HIP(ctx, hipSetDevice(ctx->device));
     SpLikParams A;
     A.prm = g->prm;
+    A.raw = raw;
+    if (raw) A.prm.sigmaf_sq = 1.0;
     A.c_exp = (double)(-0.5f) / g->prm.l_sq;
     A.P = g->P; A.ny = g->ny; A.ld = g->ld; A.n_total = n_total;
     A.off = off; A.x0 = x0; A.x1 = x1; A.y = y;
@@ -918,6 +993,110 @@ int gpc_sparse_likelihood_dev(gpc_sparse* g, const int32_t* off, int n_total, co
     int grid = std::min(g->P, ctx->num_cus * per_cu);
     hipLaunchKernelGGL(sparse_likelihood_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());
+    return GPC_OK;
+}
+
+int gpc_sparse_likelihood_dev(gpc_sparse* g, const int32_t* off, int n_total, const double* x0, const double* x1,
+                              const double* y, double* dX, double* l)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    if (g->P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    if (n_total < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
+    if (n_total > 0 && (!x0 || !x1 || !y)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/y is NULL");
+    if (g->prm.noise_model != 0) return gpc_fail(ctx, GPC_EINVAL, "likelihoods are defined for the Gaussian noise model");
+    if (g->P == 0 || n_total == 0 || (!dX && !l)) return GPC_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    return sp_likelihood_launch(g, off, n_total, x0, x1, y, dX, l, nullptr);
+}
+
+#define GPC_TRAIN_MAX_COUNTER 10000
+
+int gpc_sparse_train_sigmaf_dev(gpc_sparse* g, const int32_t* off, int n_total, const double* x0, const double* x1, const double* y,
+                                double step, int max_counter, double* p0, int32_t* iters, double* ls, double* delta)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    if (g->ny != 1) return gpc_fail(ctx, GPC_EINVAL, "train_parameters exists for sparse_gp (ny == 1) only");
+    if (g->prm.noise_model != 0) return gpc_fail(ctx, GPC_EINVAL, "likelihoods are defined for the Gaussian noise model");
+    if (g->P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    if (n_total < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
+    if (max_counter < 0 || max_counter > GPC_TRAIN_MAX_COUNTER) return gpc_fail(ctx, GPC_EINVAL, "max_counter must be in [0, %d]", GPC_TRAIN_MAX_COUNTER);
+    if (!(step == step)) return gpc_fail(ctx, GPC_EINVAL, "step is NaN");
+    if (n_total > 0 && (!x0 || !x1 || !y)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/y is NULL");
+    if (g->P > 0 && (!p0 || !iters || !ls || !delta)) return gpc_fail(ctx, GPC_EINVAL, "p0/iters/ls/delta is NULL");
+    if (g->P == 0) return GPC_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = gpc_ws_reserve(ctx, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1));
+    if (rc != GPC_OK) return rc;
+    double* raw = static_cast<double*>(ctx->ws);
+    if (n_total > 0) {
+        rc = sp_likelihood_launch(g, off, n_total, x0, x1, y, nullptr, nullptr, raw);
+        if (rc != GPC_OK) return rc;
+    }
+    SpTrainParams T;
+    T.P = g->P; T.max_counter = max_counter;
+    T.sf = g->prm.sigmaf_sq; T.l_sq = g->prm.l_sq; T.s20 = g->prm.noise; T.step = step;
+    T.off = off; T.b = g->b; T.raw = raw; T.y = y;
+    T.p0 = p0; T.ls = ls; T.delta = delta; T.iters = iters;
+    const int wpb = SP_THREADS / 64;
+    hipLaunchKernelGGL(sparse_train_kernel, dim3((g->P + wpb - 1) / wpb), dim3(SP_THREADS), 0, ctx->stream, T);
+    GPC_HIP(ctx, hipGetLastError());
+    return GPC_OK;
+}
+
+int gpc_sparse_train_sigmaf(gpc_sparse* g, const int32_t* off, const double* x0, const double* x1, const double* y, double step,
+                            int max_counter, double* p0, int32_t* iters, double* ls, double* delta)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    const int P = g->P;
+    if (P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    if (P == 0) return GPC_OK;
+    if (off[0] != 0) return gpc_fail(ctx, GPC_EINVAL, "off[0] must be 0");
+    for (int i = 0; i < P; ++i)
+        if (off[i + 1] < off[i]) return gpc_fail(ctx, GPC_EINVAL, "off must be non-decreasing (patch %d)", i);
+    if (max_counter < 0 || max_counter > GPC_TRAIN_MAX_COUNTER) return gpc_fail(ctx, GPC_EINVAL, "max_counter must be in [0, %d]", GPC_TRAIN_MAX_COUNTER);
+    const size_t N = (size_t)off[P], Pz = (size_t)P, W = (size_t)max_counter + 2;
+    if (N > 0 && (!x0 || !x1 || !y)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/y is NULL");
+    if (!p0 || !iters || !ls || !delta) return gpc_fail(ctx, GPC_EINVAL, "p0/iters/ls/delta is NULL");
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    void *d_off = nullptr, *d_x0 = nullptr, *d_x1 = nullptr, *d_y = nullptr, *d_p0 = nullptr, *d_it = nullptr, *d_ls = nullptr, *d_de = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {d_off, d_x0, d_x1, d_y, d_p0, d_it, d_ls, d_de})
+            if (p) (void)hipFree(p);
+    };
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMalloc(&d_off, 4 * (Pz + 1));
+    if (e == hipSuccess) e = hipMalloc(&d_x0, 8 * (N + 1));
+    if (e == hipSuccess) e = hipMalloc(&d_x1, 8 * (N + 1));
+    if (e == hipSuccess) e = hipMalloc(&d_y, 8 * (N + 1));
+    if (e == hipSuccess) e = hipMalloc(&d_p0, 8 * Pz);
+    if (e == hipSuccess) e = hipMalloc(&d_it, 4 * Pz);
+    if (e == hipSuccess) e = hipMalloc(&d_ls, 8 * Pz * W);
+    if (e == hipSuccess) e = hipMalloc(&d_de, 16 * Pz);
+    if (e == hipSuccess) e = hipMemsetAsync(d_ls, 0, 8 * Pz * W, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off, 4 * (Pz + 1), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && N) e = hipMemcpyAsync(d_x0, x0, 8 * N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && N) e = hipMemcpyAsync(d_x1, x1, 8 * N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && N) e = hipMemcpyAsync(d_y, y, 8 * N, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+        cleanup();
+        return gpc_fail(ctx, e == hipErrorOutOfMemory ? GPC_ENOMEM : GPC_EHIP, "gpc_sparse_train_sigmaf: %s", hipGetErrorString(e));
+    }
+    int rc = gpc_sparse_train_sigmaf_dev(g, (const int32_t*)d_off, (int)N, (const double*)d_x0, (const double*)d_x1, (const double*)d_y,
+                                         step, max_counter, (double*)d_p0, (int32_t*)d_it, (double*)d_ls, (double*)d_de);
+    if (rc == GPC_OK) e = hipMemcpyAsync(p0, d_p0, 8 * Pz, hipMemcpyDeviceToHost, s);
+    if (rc == GPC_OK && e == hipSuccess) e = hipMemcpyAsync(iters, d_it, 4 * Pz, hipMemcpyDeviceToHost, s);
+    if (rc == GPC_OK && e == hipSuccess) e = hipMemcpyAsync(ls, d_ls, 8 * Pz * W, hipMemcpyDeviceToHost, s);
+    if (rc == GPC_OK && e == hipSuccess) e = hipMemcpyAsync(delta, d_de, 16 * Pz, hipMemcpyDeviceToHost, s);
+    hipError_t e2 = hipStreamSynchronize(s);
+    cleanup();
+    if (rc != GPC_OK) return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return gpc_fail(ctx, GPC_EHIP, "gpc_sparse_train_sigmaf: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return GPC_OK;
 }
 

@@ -158,6 +158,23 @@ int gpc_sparse_ld(const gpc_sparse* g);
 int gpc_sparse_set_state(gpc_sparse* g, const int32_t* bv_count, const double* alpha, const double* C, const double* Q,
                          const double* BV);
 
+/* ---- hyper-parameter training: the live part of sparse_gp::train_parameters ---------------- */
+/* src/sparse_gp.hpp:586-640 up to the exit(0) at :640 (the call site is commented out upstream, src/gp_compressor.cpp:161):
+ * gradient ascent on kernel.param()(0) = sigma_f^2 with the trained state held fixed, per patch and entirely on the device,
+ *     do { delta = sum_i likelihood_dtheta(x_i, y_i);          (:510-519, kernel_dtheta src/rbf_kernel.cpp:49-58)
+ *          p(0) += step * delta(0);                            (:624, step = 1e-4f upstream)
+ *          ls.push_back(sum_i log_likelihood(x_i, y_i));       (:625-627, :356-385)
+ *          if (counter > max_counter) break; ++counter;        (:630-633, max_counter = 100 upstream)
+ *     } while (delta.norm() > 1e-2f);                          (:636)
+ * A patch with fewer than 20 basis vectors is left alone like upstream (:609-611): iters = 0, p0 = the object's value.
+ * ny == 1 only.  Outputs per patch: p0[P] the trained sigma_f^2, iters[P], ls[P][max_counter + 2] the likelihood trace the
+ * reference plots, delta[P][2] the last gradient.  The object itself is not modified (upstream re-trains in the outer loop
+ * the exit(0) cuts off): create a new gpc_sparse with the trained parameter to use it. */
+int gpc_sparse_train_sigmaf(gpc_sparse* g, const int32_t* off, const double* x0, const double* x1, const double* y, double step,
+                            int max_counter, double* p0, int32_t* iters, double* ls, double* delta);
+int gpc_sparse_train_sigmaf_dev(gpc_sparse* g, const int32_t* off, int n_total, const double* x0, const double* x1, const double* y,
+                                double step, int max_counter, double* p0, int32_t* iters, double* ls, double* delta);
+
 /* ---- the step after the path: reprojection + colour clamp, fused ------------------------ */
 /* The tail of the patch loop of gp_compressor::load_compressed (src/gp_compressor.cpp:335-373, flatten_colors :251-265):
  * pt = R_i (f*, x*_0, x*_1) + mean_i as float, rgb = clamp(short(C* + RGB_mean_i)), written as pcl::PointXYZRGB records.

@@ -619,6 +619,75 @@ void orc_sparse_likelihood(const orc_sparse* g, int n, const double* x0, const d
     free(v);
 }
 
+/* ---- f4: the live part of sparse_gp::train_parameters (sparse_gp.hpp:586-640, up to the exit(0) at :640) on a trained
+ * state: gradient ascent on kernel.param()(0) = sigma_f^2 with the state (alpha, C, BV) held fixed, exactly as the inner
+ * do-loop does --
+ *     delta = sum_i likelihood_dtheta(x_i, y_i)      (:510-519; kernel_dtheta rbf_kernel.cpp:49-58)
+ *     p(0) += step * delta(0)                        (:624)
+ *     ls.push_back( sum_i log_likelihood(x_i, y_i) ) (:625-627, log_likelihood :356-385, evaluated with the NEW p(0))
+ *     if (counter > max_counter) break; ++counter;   (:630-633, max_counter = 100 upstream)
+ * while (delta.norm() > 1e-2f)                       (:636)
+ * and the DEBUG early return for fewer than 20 basis vectors (:609-611) -> iters = 0.  ny == 1 only (sparse_gp_field has no
+ * such method).  The object's own kernel parameter is left alone; the trained value comes back in *p0_out.  ls must hold
+ * max_counter + 2 entries.  log_likelihood's long double temporaries (:380-382) are evaluated in double. */
+void orc_sparse_train_sigmaf(const orc_sparse* g, int n, const double* x0, const double* x1, const double* y, double step,
+                             int max_counter, double* p0_out, int32_t* iters, double* ls, double* delta_out)
+{
+    const size_t ld = (size_t)g->ld;
+    const int b = g->b;
+    const double p1 = g->p.p1, s20 = g->p.s20;
+    double p0 = g->p.p0;
+    *p0_out = p0;
+    *iters = 0;
+    delta_out[0] = delta_out[1] = 0.0;
+    if (b < 20) return;
+    const double logsqrt2pi = (double)0.5f * log((double)2.0f * M_PI);
+    double* k = (double*)malloc(sizeof(double) * (size_t)b);
+    int counter = 0;
+    double delta[2];
+    do {
+        delta[0] = delta[1] = 0.0;
+        for (int i = 0; i < n; ++i) {                         /* likelihood_dtheta */
+            double ak = 0.0, kd0 = 0.0, kd1 = 0.0;
+            for (int j = 0; j < b; ++j) {
+                const double d0 = x0[i] - g->BV[2 * j], d1 = x1[i] - g->BV[2 * j + 1];
+                const double offset = d0 * d0 + d1 * d1;
+                const double e = exp((double)(-0.5f) / p1 * offset);          /* k_dtheta(j, 0) */
+                const double t1 = p0 * (double)0.5f / (p1 * p1) * offset * e; /* k_dtheta(j, 1) */
+                ak += Al(0, j) * (p0 * e);                                    /* alpha^T k */
+                kd0 += e * Al(0, j);
+                kd1 += t1 * Al(0, j);
+            }
+            delta[0] += (ak - y[i]) * kd0;
+            delta[1] += (ak - y[i]) * kd1;
+        }
+        p0 += step * delta[0];
+        double lsum = 0.0;
+        for (int i = 0; i < n; ++i) {                         /* log_likelihood with the updated parameter */
+            for (int j = 0; j < b; ++j) k[j] = orc_rbf_kernel(p0, p1, x0[i], x1[i], g->BV[2 * j], g->BV[2 * j + 1]);
+            const double kstar = orc_rbf_kernel(p0, p1, x0[i], x1[i], x0[i], x1[i]);
+            double mu = 0.0, kCk = 0.0;
+            for (int r = 0; r < b; ++r) {
+                double sum = 0.0;
+                for (int c = 0; c < b; ++c) sum += Cm(r, c) * k[c];
+                kCk += k[r] * sum;
+                mu += k[r] * Al(0, r);
+            }
+            const double sigma = s20 + kstar + kCk;
+            const double cent2 = (y[i] - mu) * (y[i] - mu);
+            lsum += -logsqrt2pi - (double)0.5f * log(sigma) - (double)0.5f * cent2 / sigma;
+        }
+        ls[counter] = lsum;
+        *iters = counter + 1;
+        if (counter > max_counter) break;
+        ++counter;
+    } while (sqrt(delta[0] * delta[0] + delta[1] * delta[1]) > (double)1e-2f);
+    free(k);
+    *p0_out = p0;
+    delta_out[0] = delta[0];
+    delta_out[1] = delta[1];
+}
+
 void orc_sparse_get_state(const orc_sparse* g, double* alpha, double* C, double* Q, double* BV)
 {
     const size_t ld = (size_t)g->ld;

@@ -107,6 +107,10 @@ void orc_sparse_predict(const orc_sparse* g, int m, const double* xs0, const dou
 /* compute_likelihoods / compute_derivatives (sparse_gp.hpp:387-427, 463-508; field: sparse_gp_field.hpp:322-392) */
 void orc_sparse_likelihood(const orc_sparse* g, int n, const double* x0, const double* x1, const double* y,
                            double* dX, double* l);
+/* the live part of train_parameters (sparse_gp.hpp:586-640): gradient ascent on sigma_f^2 on the trained state; ls holds
+ * max_counter + 2 entries, delta_out 2 */
+void orc_sparse_train_sigmaf(const orc_sparse* g, int n, const double* x0, const double* x1, const double* y, double step,
+                             int max_counter, double* p0_out, int32_t* iters, double* ls, double* delta_out);
 void orc_sparse_get_state(const orc_sparse* g, double* alpha, double* C, double* Q, double* BV);
 /* statistics: how many full / sparse updates and deletions happened (for BV-count agreement reports) */
 void orc_sparse_get_counters(const orc_sparse* g, int32_t* n_full, int32_t* n_sparse, int32_t* n_deleted);

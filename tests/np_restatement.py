@@ -202,3 +202,30 @@ def grid(res, sz):
     X0 = np.tile(g, sz)          # x inner
     X1 = np.repeat(g, sz)        # y outer
     return X0, X1
+
+
+def train_sigmaf_np(p0, p1, s20, alpha, Cm, BV, q0, q1, y, step, max_counter):
+    """the live part of train_parameters (src/sparse_gp.hpp:586-640), NumPy, on a given state"""
+    if len(BV) < 20:
+        return p0, 0, np.zeros(max_counter + 2), np.zeros(2)
+    d2 = (q0[:, None] - BV[None, :, 0]) ** 2 + (q1[:, None] - BV[None, :, 1]) ** 2
+    e = np.exp(np.float64(np.float32(-0.5)) / p1 * d2)                      # n x b
+    ls = np.zeros(max_counter + 2)
+    c0 = 0.5 * np.log(2.0 * np.pi)
+    counter = 0
+    while True:
+        ak = (p0 * e) @ alpha
+        kd0 = e @ alpha
+        kd1 = (p0 * 0.5 / (p1 * p1) * d2 * e) @ alpha
+        delta = np.array([np.sum((ak - y) * kd0), np.sum((ak - y) * kd1)])
+        p0 = p0 + step * delta[0]
+        k = p0 * e
+        sigma = s20 + p0 + np.einsum("ij,jk,ik->i", k, Cm, k)
+        ls[counter] = np.sum(-c0 - 0.5 * np.log(sigma) - 0.5 * (y - k @ alpha) ** 2 / sigma)
+        it = counter + 1
+        if counter > max_counter:
+            break
+        counter += 1
+        if not np.sqrt(delta @ delta) > np.float64(np.float32(1e-2)):
+            break
+    return p0, it, ls, delta

@@ -122,6 +122,7 @@ def _bind(L):
     L.orc_sparse_delete_bv.argtypes = [C.c_void_p, C.c_int]
     L.orc_sparse_predict.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_dp, C.c_int]
     L.orc_sparse_likelihood.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]
+    L.orc_sparse_train_sigmaf.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, d, C.c_int, c_dp, c_ip, c_dp, c_dp]
     L.orc_sparse_get_state.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp]
     L.orc_sparse_get_counters.argtypes = [C.c_void_p, c_ip, c_ip, c_ip]
     L.orc_shuffle_libc.argtypes = [C.c_int, c_ip]
@@ -260,6 +261,17 @@ class Sparse:
         self.L.orc_sparse_likelihood(self.h, n, _dp(np.ascontiguousarray(x0)), _dp(np.ascontiguousarray(x1)), _dp(y),
                                      _dp(dX), _dp(l))
         return dX, l
+
+    def train_sigmaf(self, x0, x1, y, step=float(np.float32(1e-4)), max_counter=100):
+        """the live part of train_parameters: returns p0, iters, ls (max_counter + 2), delta (2)"""
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        p0 = np.zeros(1)
+        iters = np.zeros(1, dtype=np.int32)
+        ls = np.zeros(max_counter + 2)
+        delta = np.zeros(2)
+        self.L.orc_sparse_train_sigmaf(self.h, len(y), _dp(np.ascontiguousarray(x0)), _dp(np.ascontiguousarray(x1)), _dp(y),
+                                       float(step), int(max_counter), _dp(p0), _ip(iters), _dp(ls), _dp(delta))
+        return float(p0[0]), int(iters[0]), ls, delta
 
     def state(self):
         b = self.size()

@@ -437,3 +437,39 @@ def test_sparse_probit_plug_point(oracle):
         gp.add(X[i], [1.0])
     a, C, Q, BV = g.state()
     assert np.all(np.isnan(a)) and np.all(np.isnan(gp.alpha))
+
+
+def test_sparse_train_sigmaf(oracle):
+    """Row f4: the live part of sparse_gp::train_parameters (sparse_gp.hpp:586-640) restated in the oracle, pinned by (i) an
+    independent NumPy restatement on the oracle's own state (trained parameter, likelihood trace, gradient, iteration
+    count), (ii) what likelihood_dtheta is: half the theta-gradient of (alpha^T k - y)^2 at fixed alpha, by finite
+    differences in both kernel parameters, (iii) the early return below 20 basis vectors and the counter rule."""
+    res, n = 0.15, 160
+    off, x0, x1, y = synth.make_patches(1, n, res=res, seed=77)
+    y = y[0]
+    p1, s20 = (res / 4) ** 2, 1e-3
+    for p0, step, maxc, want_iters in ((1.0, float(np.float32(1e-4)), 100, 102), (0.002, 1e-6, 30, None), (1.0, 1e-4, 2, 4)):
+        g = oracle.Sparse(oracle.sparse_params(1, capacity=50, p0=p0, p1=p1, s20=s20 if p0 == 1.0 else 1e-5), 52)
+        g.add_measurements(x0, x1, y[None, :])
+        alpha, C, Q, BV = g.state()
+        assert g.size() >= 20
+        po, it, ls, delta = g.train_sigmaf(x0, x1, y, step=step, max_counter=maxc)
+        pr, ir, lr, dr = R.train_sigmaf_np(p0, p1, s20 if p0 == 1.0 else 1e-5, alpha[0], C, BV, x0, x1, y, step, maxc)
+        assert it == ir and (want_iters is None or it == want_iters)
+        assert abs(po - pr) <= 1e-10 * abs(pr)
+        assert np.max(np.abs(ls - lr)) <= 1e-9 * np.max(np.abs(lr))
+        assert np.max(np.abs(delta - dr)) <= 1e-8 * np.max(np.abs(dr))
+        # (ii) first-iteration gradient = 1/2 d/dtheta sum_i (alpha^T k_i(theta) - y_i)^2
+        _, _, _, d1 = R.train_sigmaf_np(p0, p1, 1e-3, alpha[0], C, BV, x0, x1, y, 0.0, 0)
+
+        def half_sq(a, b_):
+            K = R.rbf(a, b_, BV, np.stack([x0, x1], 1))
+            return 0.5 * np.sum((alpha[0] @ K - y) ** 2)
+        fd0 = (half_sq(p0 * (1 + 1e-6), p1) - half_sq(p0 * (1 - 1e-6), p1)) / (2e-6 * p0)
+        fd1 = (half_sq(p0, p1 * (1 + 1e-6)) - half_sq(p0, p1 * (1 - 1e-6))) / (2e-6 * p1)
+        assert abs(d1[0] - fd0) <= 1e-5 * abs(fd0) and abs(d1[1] - fd1) <= 1e-5 * abs(fd1)
+    # fewer than 20 basis vectors: untouched
+    g = oracle.Sparse(oracle.sparse_params(1, capacity=10, p0=1.0, p1=p1, s20=s20), 12)
+    g.add_measurements(x0, x1, y[None, :])
+    po, it, ls, delta = g.train_sigmaf(x0, x1, y)
+    assert (po, it) == (1.0, 0) and np.all(ls == 0)

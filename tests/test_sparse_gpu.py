@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 
 from gp_compressor_amd import synth
+from np_restatement import train_sigmaf_np
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -301,4 +302,86 @@ def test_sparse_full_size_c4(gp, oracle):
         scale = np.max(np.abs(outs[0]))
         sens = max(np.max(np.abs(o - outs[0])) for o in outs[1:])
         assert np.max(np.abs(f[i] - outs[0])) <= max(2e-5 * scale, 5.0 * sens), (i, sens / scale)
+    g.close()
+
+
+@pytest.mark.parametrize("regime", ["unit_amplitude", "small_amplitude", "early_stop"])
+def test_sparse_train_sigmaf(gp, oracle, regime):
+    """SURVEY section 8 row f4: gpc_sparse_train_sigmaf = the live part of sparse_gp::train_parameters, per patch on the
+    device.  (i) against the NumPy restatement on the GPU's OWN state: 1e-9 on the trained parameter, 1e-8 on the last gradient,
+    1e-7 on the likelihood trace (cancellation in sigma), iteration counts equal; (ii) against the oracle end to end at the tolerance of the state;
+    (iii) fewer than 20 basis vectors -> untouched (src/sparse_gp.hpp:609-611), empty point set, argument checks."""
+    capi, ctx = gp
+    res, P, n, cap = 0.15, 7, 200, 60
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=71, ragged=True)
+    y = y[0]
+    if regime == "unit_amplitude":          # 102 iterations: the gradient norm never falls below 1e-2 (p(1) is not moved)
+        kw, step, maxc = dict(sigmaf_sq=1.0, l_sq=(res / 4) ** 2, noise=1e-3, capacity=cap), float(np.float32(1e-4)), 100
+    elif regime == "small_amplitude":       # sigma_f^2 of the order of the signal: the parameter moves by tens of percent
+        kw, step, maxc = dict(sigmaf_sq=0.002, l_sq=(res / 4) ** 2, noise=1e-5, capacity=cap), 6e-6, 100
+    else:                                   # max_counter cuts the loop: counter > 3 -> 5 iterations
+        kw, step, maxc = dict(sigmaf_sq=1.0, l_sq=(res / 4) ** 2, noise=1e-3, capacity=cap), float(np.float32(1e-4)), 3
+    # patch 2: 12 points only -> fewer than 20 basis vectors; patch 4: trained, but evaluated on an empty point set
+    cnt = np.diff(off)
+    keep = np.ones(off[-1], bool)
+    keep[off[2] + 12:off[3]] = False
+    cnt_t = cnt.copy()
+    cnt_t[2] = 12
+    off_t = np.concatenate([[0], np.cumsum(cnt_t)]).astype(np.int32)
+    g = capi.Sparse(ctx, capi.default_params_sparse(1, **kw), P, 1)
+    st = g.add(off_t, x0[keep], x1[keep], y[None, keep])
+    assert np.all(st == 0)
+    sizes = g.sizes()
+    assert sizes[2] < 20 and np.all(np.delete(sizes, 2) >= 20)
+    qkeep = keep.copy()
+    qkeep[off[4]:off[5]] = False
+    cnt_q = cnt_t.copy()
+    cnt_q[4] = 0
+    qoff = np.concatenate([[0], np.cumsum(cnt_q)]).astype(np.int32)
+    q0, q1, yq = x0[qkeep], x1[qkeep], y[qkeep]
+    p0, iters, ls, delta = g.train_sigmaf(qoff, q0, q1, yq, step=step, max_counter=maxc)
+    alpha, Cm, Q, BV = g.state()
+    moved = 0.0
+    for i in range(P):
+        sl = slice(qoff[i], qoff[i + 1])
+        b = int(sizes[i])
+        pr, ir, lr, dr = train_sigmaf_np(kw["sigmaf_sq"], kw["l_sq"], kw["noise"], alpha[i][0, :b], Cm[i][:b, :b], BV[i][:b],
+                                          q0[sl], q1[sl], yq[sl], step, maxc)
+        assert iters[i] == ir, (i, iters[i], ir)
+        assert abs(p0[i] - pr) <= 1e-9 * abs(pr), i
+        if ir:
+            # sigma = s20 + p + p^2 e^T C e cancels to ~s20 (1e-3 of its terms, see the likelihood test): the MFMA and the
+            # NumPy summation orders show at 1e-8 in log(sigma)
+            assert np.max(np.abs(ls[i] - lr)) <= 1e-7 * np.max(np.abs(lr)) + 1e-9, i
+            assert np.max(np.abs(delta[i] - dr)) <= 1e-8 * np.max(np.abs(dr)) + 1e-12, i
+            assert np.all(ls[i, ir:] == 0)
+        moved = max(moved, abs(p0[i] / kw["sigmaf_sq"] - 1))
+    assert iters[2] == 0 and p0[2] == kw["sigmaf_sq"]
+    assert iters[4] == 1 and p0[4] == kw["sigmaf_sq"]             # no points: zero gradient, one pass through the loop
+    if regime == "unit_amplitude":
+        assert np.all(np.delete(iters, [2, 4]) == 102)
+    elif regime == "small_amplitude":
+        assert moved > 0.05
+    else:
+        assert np.all(np.delete(iters, [2, 4]) == 5)
+    # end to end against the oracle (same insertion order = identity)
+    op = oracle.sparse_params(1, p0=kw["sigmaf_sq"], p1=kw["l_sq"], s20=kw["noise"], capacity=cap)
+    for i in (0, 5):
+        go = oracle.Sparse(op, cap + 2)
+        a, b_ = off_t[i], off_t[i + 1]
+        go.add_measurements(x0[keep][a:b_], x1[keep][a:b_], y[None, keep][:, a:b_])
+        sl = slice(qoff[i], qoff[i + 1])
+        po, io, lo, do = go.train_sigmaf(q0[sl], q1[sl], yq[sl], step=step, max_counter=maxc)
+        assert io == iters[i]
+        assert abs(p0[i] - po) <= 1e-4 * abs(po)
+        assert np.max(np.abs(ls[i] - lo)) <= 1e-4 * np.max(np.abs(lo))
+    # argument checks
+    with pytest.raises(capi.GpcError) as e:
+        g.train_sigmaf(qoff, q0, q1, yq, max_counter=-1)
+    assert e.value.code == capi.GPC_EINVAL
+    g3 = capi.Sparse(ctx, capi.default_params_sparse(3, capacity=10), 1, 3)
+    with pytest.raises(capi.GpcError) as e:
+        g3.train_sigmaf(np.array([0, 1], np.int32), np.zeros(1), np.zeros(1), np.zeros(1))
+    assert e.value.code == capi.GPC_EINVAL
+    g3.close()
     g.close()
