@@ -206,7 +206,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     // one workgroup per patch, straight-line (a persistent patch loop makes hipcc hoist hundreds of lane-dependent
     // LDS addresses out of it and spill; the block hand-over costs ~1-2 us against ~100 us of work)
     do {
-        const int patch = blockIdx.x;
+        int patch = blockIdx.x;
+        if (A.sel) {                                  // size-class dispatch: this launch owns the patches sel[0 .. count)
+            if ((int)blockIdx.x >= __builtin_amdgcn_readfirstlane(A.sel_count[0])) continue;
+            patch = __builtin_amdgcn_readfirstlane(A.sel[blockIdx.x]);
+        }
         // wave-uniform by construction, but loaded through the vector memory path: without readfirstlane hipcc treats n
         // (and every `ti < nt` test derived from it) as divergent and lowers the slot guards to EXEC-masked code
         const int o = __builtin_amdgcn_readfirstlane(A.off[patch]);

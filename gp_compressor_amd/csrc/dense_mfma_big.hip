@@ -105,7 +105,9 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
 
     gpc_exp_table_init(T);
 
-    for (int patch = blockIdx.x; patch < A.P; patch += gridDim.x) {
+    const int n_patches = A.sel ? __builtin_amdgcn_readfirstlane(A.sel_count[0]) : A.P;   // size-class dispatch: sel[0 .. count)
+    for (int pk = blockIdx.x; pk < n_patches; pk += gridDim.x) {
+        const int patch = A.sel ? __builtin_amdgcn_readfirstlane(A.sel[pk]) : pk;
         const int o = __builtin_amdgcn_readfirstlane(A.off[patch]);
         const int n = __builtin_amdgcn_readfirstlane(A.off[patch + 1]) - o;
         double* fs = A.f_star + (size_t)patch * ny * m;

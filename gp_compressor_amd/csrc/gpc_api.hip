@@ -148,6 +148,18 @@ static int dense_check(gpc_ctx* ctx, const gpc_params* prm, int P, const void* o
     return GPC_OK;
 }
 
+// Ragged batches whose largest patch exceeds the register-resident kernel's 256 points: patches are sorted into the two size
+// classes on the device (no host round trip: `off` lives there), the small ones go to the register-resident kernel and only
+// the large ones to the tiled kernel.  Patches are independent, so the order inside a class does not matter.
+__global__ void dense_classify_kernel(int P, const int32_t* off, int bound, int32_t* sel_small, int32_t* sel_big, int32_t* counts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int n = off[i + 1] - off[i];
+    if (n <= bound) sel_small[atomicAdd(&counts[0], 1)] = i;
+    else sel_big[atomicAdd(&counts[1], 1)] = i;
+}
+
 static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
 {
     if (a.P == 0 || (a.m == 0 && !a.alpha_out)) return GPC_OK;
@@ -158,9 +170,27 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
     if (dense_mfma_supported(a) && !getenv("GPC_FORCE_GENERIC") && !getenv("GPC_FORCE_BIG")) return dense_mfma_launch(ctx, a);
     if ((dense_big_supported(a) || (getenv("GPC_FORCE_BIG") && a.n_max <= 1024 && !a.v_star)) && !getenv("GPC_FORCE_GENERIC")) {   // GPC_FORCE_BIG: diagnostic
         int grid_b = 0;
-        int rcb = gpc_ws_reserve(ctx, dense_big_ws_bytes(ctx, a, &grid_b));
+        const size_t big_bytes = (dense_big_ws_bytes(ctx, a, &grid_b) + 255) & ~(size_t)255;
+        const bool split = a.n_max > 256 && a.P > 1 && !getenv("GPC_FORCE_BIG") && !getenv("GPC_NO_SPLIT");
+        int rcb = gpc_ws_reserve(ctx, big_bytes + (split ? sizeof(int32_t) * (2 * (size_t)a.P + 64) : 0));
         if (rcb != GPC_OK) return rcb;
-        return dense_big_launch(ctx, a, grid_b);
+        if (!split) return dense_big_launch(ctx, a, grid_b);
+        int32_t* counts = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->ws) + big_bytes);
+        int32_t* sel_small = counts + 64;
+        int32_t* sel_big = sel_small + a.P;
+        GPC_HIP(ctx, hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(dense_classify_kernel, dim3((a.P + 255) / 256), dim3(256), 0, ctx->stream, a.P, a.off, 256, sel_small, sel_big, counts);
+        GPC_HIP(ctx, hipGetLastError());
+        DenseArgs s = a;
+        s.n_max = 256;
+        s.sel = sel_small; s.sel_count = counts;
+        int rc = dense_mfma_launch(ctx, s);            // workgroups beyond the class count leave at once
+        if (rc != GPC_OK) return rc;
+        DenseArgs b = a;
+        b.sel = sel_big; b.sel_count = counts + 1;
+        rc = dense_big_launch(ctx, b, grid_b);
+        ctx->last_dense_kernel = "dense_mfma_nt16 + dense_mfma_big";
+        return rc;
     }
     int grid = 0;
     size_t bytes = dense_generic_ws_bytes(ctx, a, &grid);

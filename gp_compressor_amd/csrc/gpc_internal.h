@@ -82,6 +82,10 @@ struct DenseArgs {
     int grid_sz;
     double *f_star, *v_star, *alpha_out;
     int32_t* status;
+    // size-class dispatch of a ragged batch (gpc_api.hip): when sel != nullptr a kernel works on the patches sel[0 .. *sel_count)
+    // (both on the device) instead of 0 .. P-1
+    const int32_t* sel;
+    const int32_t* sel_count;
 };
 
 // generic kernel: any n <= GPC_MAX_POINTS, K/L in a global-memory workspace slot per workgroup

@@ -86,7 +86,8 @@ def test_dense_vs_oracle(gp, oracle, kernel_choice, P, n, ny, ragged, seed):
     f, _, st, al = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
     fo, _, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, want_alpha=True)
     n_max = int(np.max(np.diff(off)))
-    want_kernel = {"generic": "dense_generic", "big": "dense_mfma_big"}.get(kernel_choice, "dense_mfma_big" if n_max > 256 else "dense_mfma_nt")
+    want_kernel = {"generic": "dense_generic", "big": "dense_mfma_big"}.get(
+        kernel_choice, ("dense_mfma_nt16 + dense_mfma_big" if P > 1 else "dense_mfma_big") if n_max > 256 else "dense_mfma_nt")
     assert ctx.last_dense_kernel().startswith(want_kernel), ctx.last_dense_kernel()
     assert np.array_equal(st, so)
     _close(f, fo, FTOL)
@@ -160,11 +161,12 @@ def test_dense_edge_cases(gp, oracle):
     assert np.all(np.isnan(f[0])) and np.all(np.isnan(al[0, :3])) and np.all(np.isfinite(f[1]))
 
 
-def test_dense_big_kernel_edge_cases(gp, oracle):
-    """The tiled left-looking kernel (n_max > 256) on a batch that mixes an empty patch, a tiny patch, a patch that is not
+def test_dense_big_kernel_edge_cases(gp, oracle, monkeypatch):
+    """The tiled left-looking kernel (n_max > 256; GPC_NO_SPLIT keeps the whole batch on it) on a batch that mixes an empty patch, a tiny patch, a patch that is not
     SPD (duplicated point, zero noise: the failing pivot sits in a late tile column) and full-size patches; grid and
     point-wise entries, ny = 3."""
     capi, ctx = gp
+    monkeypatch.setenv("GPC_NO_SPLIT", "1")
     res, sz = 0.15, 8
     xs0, xs1 = oracle.grid(res, sz)
     rng = np.random.default_rng(5)
@@ -190,6 +192,44 @@ def test_dense_big_kernel_edge_cases(gp, oracle):
     assert st2.tolist() == st.tolist()
     for i in good:
         assert np.max(np.abs(f2[i] - f[i])) <= 1e-9 * max(np.max(np.abs(f[i])), 1e-12)
+
+
+def test_dense_size_class_split(gp, oracle, monkeypatch):
+    """A ragged batch whose largest patch exceeds 256 points is sorted into size classes on the device: patches of up to
+    256 points run on the register-resident kernel, only the larger ones on the tiled kernel.  Same results as the oracle,
+    and per kernel the same as when it runs alone; empty patches, a non-SPD patch in each class, status per patch."""
+    capi, ctx = gp
+    res, sz = 0.15, 10
+    rng = np.random.default_rng(17)
+    counts = np.concatenate([rng.integers(1, 257, 40), rng.integers(257, 700, 25), [0, 256, 257, 1, 1024, 0]])
+    rng.shuffle(counts)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    P, N = len(counts), int(off[-1])
+    x0, x1 = rng.uniform(-res / 2, res / 2, N), rng.uniform(-res / 2, res / 2, N)
+    y = rng.normal(0, 0.01, (1, N))
+    small = int(np.flatnonzero((counts > 40) & (counts <= 256))[0])
+    big = int(np.flatnonzero(counts > 300)[0])
+    for i in (small, big):                      # a duplicated point: singular without noise
+        x0[off[i] + 30], x1[off[i] + 30] = x0[off[i] + 3], x1[off[i] + 3]
+    p0 = capi.default_params_dense(noise=0.0, sigmaf_sq=1.0, l_sq=0.003 ** 2)
+    po = oracle.dense_params(1.0, 0.003 ** 2, 0.0)
+    f, st = ctx.dense_fit_predict_grid(p0, off, x0, x1, y, res, sz)
+    assert ctx.last_dense_kernel() == "dense_mfma_nt16 + dense_mfma_big"
+    xs0, xs1 = oracle.grid(res, sz)
+    fo, _, so = oracle.dense_fit_predict_batch(po, off, x0, x1, y, xs0, xs1)
+    assert st.tolist() == so.tolist() and st[small] == 1 and st[big] == 1 and st.sum() == 2
+    for i in range(P):
+        if st[i] == 0:
+            assert np.max(np.abs(f[i] - fo[i])) <= 1e-8 * max(np.max(np.abs(fo[i])), 1e-12), (i, counts[i])
+        else:
+            assert np.all(np.isnan(f[i]))
+    assert np.all(f[counts == 0] == 0)
+    # the tiled kernel alone on the same batch: patches of the large class are bit-identical (same kernel, same arithmetic)
+    monkeypatch.setenv("GPC_NO_SPLIT", "1")
+    f1, st1 = ctx.dense_fit_predict_grid(p0, off, x0, x1, y, res, sz)
+    assert ctx.last_dense_kernel() == "dense_mfma_big" and st1.tolist() == st.tolist()
+    ok_big = (counts > 256) & (st == 0)
+    assert np.max(np.abs(f[ok_big] - f1[ok_big])) <= 1e-10 * np.max(np.abs(f1[ok_big]))
 
 
 def test_dense_argument_errors(gp):
@@ -262,7 +302,7 @@ def test_dense_full_size_properties(gp, oracle, P, n, label):
     y2 = rng.normal(0, 0.01, size=y.shape)
     p = capi.default_params_dense()
     fa, sta, ala = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz, want_alpha=True)
-    assert ctx.last_dense_kernel().startswith("dense_mfma_nt16" if n <= 256 else "dense_mfma_big")
+    assert ctx.last_dense_kernel().startswith("dense_mfma_nt16") if n <= 256 else ctx.last_dense_kernel().endswith("dense_mfma_big")
     fb, stb = ctx.dense_fit_predict_grid(p, off, x0, x1, y2, res, sz)
     fc, stc = ctx.dense_fit_predict_grid(p, off, x0, x1, y + 2.0 * y2, res, sz)
     assert np.all(sta == 0) and np.all(stb == 0) and np.all(stc == 0)
