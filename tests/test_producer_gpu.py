@@ -150,3 +150,57 @@ def test_producer_full_size_c2(gp, oracle):
     assert 8000 <= v.P <= 9000 and 200 <= np.median(cnt) <= 300 and v.n_total >= 0.99 * len(xyz)
     assert len(np.unique(got["src"])) == v.n_total
     pt.close()
+
+
+def test_producer_feeds_the_sparse_gps_on_device(gp, oracle):
+    """The reference's own flow (sparse depth GP + sparse colour field per leaf, src/gp_compressor.cpp:146-163, 298-380) on
+    the device from end to end: producer view -> gpc_sparse_add_dev (depth and RGB) -> gpc_sparse_predict_dev ->
+    gpc_reproject_dev with the colour planes; same cloud as the host-buffer entry points give on the fetched batch."""
+    import torch
+    capi, ctx = gp
+    res, sz = 0.15, 12
+    m = sz * sz
+    xyz, rgb = synth.plane_cloud(10000, seed=2)
+    pt = ctx.project_cloud(ctx.make_cloud(xyz, rgb), res, sz)
+    v = pt.view
+    b = pt.fetch()
+    pd = capi.default_params_sparse(1, sigmaf_sq=1.0, l_sq=(res / 2) ** 2, noise=1e-2, capacity=40)
+    pc = capi.default_params_sparse(3, sigmaf_sq=1.0, l_sq=(res / 2) ** 2, noise=25.0, capacity=40)
+    xs0, xs1 = synth.grid(res, sz)
+    d_xs0, d_xs1 = torch.from_numpy(xs0).cuda(), torch.from_numpy(xs1).cuda()
+    f = torch.zeros(v.P, m, dtype=torch.float64, device="cuda")
+    c = torch.zeros(v.P, 3, m, dtype=torch.float64, device="cuda")
+    bv = torch.zeros(v.P, dtype=torch.int32, device="cuda")
+    out = torch.zeros(v.P * m, 32, dtype=torch.uint8, device="cuda")
+    npts = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    gd, gc = capi.Sparse(ctx, pd, v.P, 1), capi.Sparse(ctx, pc, v.P, 3)
+    gd.add_dev(v.off, v.n_max, v.n_total, v.x0, v.x1, v.y)
+    gc.add_dev(v.off, v.n_max, v.n_total, v.x0, v.x1, v.rgb)
+    gd.predict_dev(m, d_xs0, d_xs1, f)
+    gc.predict_dev(m, d_xs0, d_xs1, c)
+    sizes = gd.sizes()
+    bv.copy_(torch.from_numpy(sizes))
+    torch.cuda.synchronize()
+    ctx.reproject_dev(v.P, m, bv, d_xs0, d_xs1, f, c, v.rotations, v.means, v.rgb_means, out, npts)
+    ctx.synchronize()
+    n_out = int(npts.item())
+    assert n_out == int((sizes > 0).sum()) * m and n_out >= 0.9 * v.P * m
+    dev_cloud = out[:n_out].cpu().numpy().view(capi.Context.POINT_DTYPE).reshape(-1)
+    # the same through host buffers (identity insertion order in both)
+    hd, hc = capi.Sparse(ctx, pd, v.P, 1), capi.Sparse(ctx, pc, v.P, 3)
+    hd.add(b["off"], b["x0"], b["x1"], b["y"][None, :])
+    hc.add(b["off"], b["x0"], b["x1"], b["rgb"])
+    fh, _, _ = hd.predict(xs0, xs1, want_sigma=False)
+    ch, _, _ = hc.predict(xs0, xs1, want_sigma=False)
+    host_cloud = ctx.reproject(xs0, xs1, fh[:, 0, :], b["R"].transpose(0, 2, 1).reshape(v.P, 9), b["mean"], c_star=ch,
+                               rgb_means=b["rgb_mean"], bv_count=hd.sizes())
+    assert np.array_equal(hd.sizes(), sizes)
+    assert np.array_equal(dev_cloud, host_cloud)          # the sparse kernels are deterministic: same records, bit for bit
+    # and the surface is the input's
+    inside = (dev_cloud["x"] > 0.05) & (dev_cloud["x"] < 1.15) & (dev_cloud["y"] > 0.05) & (dev_cloud["y"] < 1.15)
+    err = dev_cloud["z"][inside] - 0.02 * np.sin(3 * dev_cloud["x"][inside]) * np.cos(2 * dev_cloud["y"][inside])
+    assert np.sqrt(np.mean(err ** 2)) < 0.004
+    for g in (gd, gc, hd, hc):
+        g.close()
+    pt.close()
