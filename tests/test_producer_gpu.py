@@ -26,7 +26,7 @@ def _same(a, b):
         assert np.array_equal(a[k], b[k]), (k, int(np.sum(a[k] != b[k])))
 
 
-@pytest.mark.parametrize("case", ["c1_plane", "room", "room_fine", "tilted_sheet"])
+@pytest.mark.parametrize("case", ["c1_plane", "room", "room_fine", "tilted_sheet", "volume", "far_offset", "lattice"])
 def test_producer_matches_oracle_bit_for_bit(gp, oracle, case):
     capi, ctx = gp
     if case == "c1_plane":                        # BASELINE config 1: 10 k points, res 0.15, sz 20
@@ -38,11 +38,26 @@ def test_producer_matches_oracle_bit_for_bit(gp, oracle, case):
     elif case == "room_fine":                     # many small leaves (lots of them below 4 points: identity frames)
         xyz, rgb = synth.room_cloud(60000, seed=5)
         res, sz = 0.04, 6
-    else:                                         # a sheet at 45 degrees: |n_x| == |n_z| up to rounding, negative coordinates
+    elif case == "tilted_sheet":                  # a sheet at 45 degrees: |n_x| == |n_z| up to rounding, negative coordinates
         xyz, rgb = synth.plane_cloud(30000, seed=7)
         c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
         xyz = (xyz.astype(np.float64) @ np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]).T - 0.7).astype(np.float32)
         res, sz = 0.1, 10
+    elif case == "volume":                        # a filled cube: all 27 neighbours occupied, no plane to fit, every point has
+        rng = np.random.default_rng(21)           # many candidate owners -- the ownership rule decides
+        xyz = rng.uniform(-0.5, 0.5, (120000, 3)).astype(np.float32)
+        rgb = rng.integers(0, 256, (120000, 3)).astype(np.uint8)
+        res, sz = 0.1, 8
+    elif case == "far_offset":                    # a small scene 2 km from the origin: the float coordinates are quantised to 1.2e-4
+        xyz, rgb = synth.room_cloud(40000, seed=8, size=(2.0, 1.5, 1.0))
+        xyz = (xyz.astype(np.float64) + np.array([2000.0, -1500.0, 300.0])).astype(np.float32)
+        res, sz = 0.07, 10
+    else:                                         # points ON the voxel faces and many exact duplicates: ties in every comparison
+        g = np.arange(0, 9) * 0.125
+        xyz = np.stack(np.meshgrid(g, g, g[:3], indexing="ij"), -1).reshape(-1, 3)
+        xyz = np.concatenate([xyz, xyz, xyz + np.array([0.0625, 0.0, 0.0])]).astype(np.float32)
+        rgb = (np.arange(3 * len(xyz)).reshape(-1, 3) * 5 % 256).astype(np.uint8)
+        res, sz = 0.125, 4
     want = oracle.project_cloud(xyz, rgb, res, sz)
     pt = ctx.project_cloud(ctx.make_cloud(xyz, rgb), res, sz)
     got = pt.fetch()
