@@ -49,6 +49,9 @@ PROTOTYPES = {
     "gpc_ctx_create": (C.c_int, [C.POINTER(_vp), _i]),
     "gpc_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "gpc_ctx_synchronize": (C.c_int, [_vp]),
+    "gpc_dev_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "gpc_dev_free": (C.c_int, [_vp, _vp]),
+    "gpc_dev_memcpy": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _i]),
     "gpc_ctx_destroy": (None, [_vp]),
     "gpc_last_error": (C.c_char_p, [_vp]),
     "gpc_last_dense_kernel": (C.c_char_p, [_vp]),

@@ -117,6 +117,40 @@ int gpc_ctx_synchronize(gpc_ctx* ctx)
     return GPC_OK;
 }
 
+int gpc_dev_malloc(gpc_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx) return GPC_EINVAL;
+    if (!out) return gpc_fail(ctx, GPC_EINVAL, "out is NULL");
+    *out = nullptr;
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    GPC_HIP(ctx, hipMalloc(out, bytes ? bytes : 8));
+    return GPC_OK;
+}
+
+int gpc_dev_free(gpc_ctx* ctx, void* p)
+{
+    if (!ctx) return GPC_EINVAL;
+    if (!p) return GPC_OK;
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));     // nothing enqueued may still be using it
+    GPC_HIP(ctx, hipFree(p));
+    return GPC_OK;
+}
+
+int gpc_dev_memcpy(gpc_ctx* ctx, void* dst, const void* src, size_t bytes, int kind)
+{
+    if (!ctx) return GPC_EINVAL;
+    if (bytes == 0) return GPC_OK;
+    if (!dst || !src) return gpc_fail(ctx, GPC_EINVAL, "dst/src is NULL");
+    const hipMemcpyKind k = kind == GPC_COPY_H2D ? hipMemcpyHostToDevice : kind == GPC_COPY_D2H ? hipMemcpyDeviceToHost
+                          : kind == GPC_COPY_D2D ? hipMemcpyDeviceToDevice : hipMemcpyDefault;
+    if (k == hipMemcpyDefault) return gpc_fail(ctx, GPC_EINVAL, "kind must be GPC_COPY_H2D, _D2H or _D2D");
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    GPC_HIP(ctx, hipMemcpyAsync(dst, src, bytes, k, ctx->stream));
+    GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GPC_OK;
+}
+
 void gpc_ctx_destroy(gpc_ctx* ctx)
 {
     if (!ctx) return;

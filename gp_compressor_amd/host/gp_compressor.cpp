@@ -108,8 +108,19 @@ gp_compressor::gp_compressor(const pointcloud& ncloud, double res, int sz, gp_mo
     gpc_default_params_dense(&dense_params);
 }
 
+void gp_compressor::release_device()
+{
+    if (dev_patches_) { gpc_patches_destroy(dev_patches_); dev_patches_ = nullptr; }
+    if (ctx_) {
+        if (d_dense_f_) (void)gpc_dev_free(ctx_, d_dense_f_);
+        if (d_dense_c_) (void)gpc_dev_free(ctx_, d_dense_c_);
+    }
+    d_dense_f_ = d_dense_c_ = nullptr;
+}
+
 gp_compressor::~gp_compressor()
 {
+    release_device();
     if (gps_) gpc_sparse_destroy(gps_);
     if (rgb_gps_) gpc_sparse_destroy(rgb_gps_);
     if (ctx_) gpc_ctx_destroy(ctx_);
@@ -131,6 +142,7 @@ void gp_compressor::project_cloud_device()
         const point& p = cloud_[i];
         rec[i] = gpc_point_xyzrgb{p.x, p.y, p.z, 1.0f, p.b, p.g, p.r, 255, {0.0f, 0.0f, 0.0f}};
     }
+    release_device();
     gpc_patches* pt = nullptr;
     check(gpc_project_cloud(ctx_, rec.data(), (int)rec.size(), res_, sz_, &pt), ctx_, "gpc_project_cloud");
     gpc_patches_view v;
@@ -144,7 +156,7 @@ void gp_compressor::project_cloud_device()
     const int rc = gpc_patches_fetch(pt, batch_.off.data(), batch_.x0.data(), batch_.x1.data(), batch_.y.data(), batch_.rgb.data(),
                                      P ? batch_.rotations[0].data() : nullptr, P ? batch_.means[0].data() : nullptr,
                                      P ? batch_.rgb_means[0].data() : nullptr, batch_.W.data(), nullptr);
-    gpc_patches_destroy(pt);
+    if (rc != GPC_OK) gpc_patches_destroy(pt); else dev_patches_ = pt;     // the batch stays on the device for train_processes()
     check(rc, ctx_, "gpc_patches_fetch");
     projected_ = true;
 }
@@ -190,6 +202,7 @@ void gp_compressor::compute_rotation(double R[9], const std::vector<double>& pts
 // src/gp_compressor.cpp:177-249 with project_points (:66-118) inlined per leaf
 void gp_compressor::project_cloud()
 {
+    release_device();
     batch_ = patch_batch();
     batch_.off.push_back(0);
     const size_t npts = cloud_.size();
@@ -314,6 +327,36 @@ void gp_compressor::train_processes()
     if (!ctx_) check(gpc_ctx_create(&ctx_, device_), nullptr, "gpc_ctx_create");
     const int m = sz_ * sz_;
     status_.assign(P, 0);
+    gpc_patches_view dv{};
+    const bool on_device = dev_patches_ != nullptr;
+    if (on_device) gpc_patches_view_dev(dev_patches_, &dv);
+    if (model_ == gp_model::dense && on_device) {
+        // depth and colour grids predicted straight from the device batch; they stay in HBM for load_compressed()
+        void* d_st = nullptr;
+        if (d_dense_f_) { (void)gpc_dev_free(ctx_, d_dense_f_); d_dense_f_ = nullptr; }
+        if (d_dense_c_) { (void)gpc_dev_free(ctx_, d_dense_c_); d_dense_c_ = nullptr; }
+        check(gpc_dev_malloc(ctx_, sizeof(double) * (size_t)P * m, (void**)&d_dense_f_), ctx_, "gpc_dev_malloc");
+        check(gpc_dev_malloc(ctx_, sizeof(double) * (size_t)P * 3 * m, (void**)&d_dense_c_), ctx_, "gpc_dev_malloc");
+        check(gpc_dev_malloc(ctx_, sizeof(int32_t) * (size_t)P, &d_st), ctx_, "gpc_dev_malloc");
+        int rc = gpc_dense_fit_predict_grid_dev(ctx_, &dense_params, P, dv.off, dv.n_max, dv.n_total, dv.x0, dv.x1, dv.y, 1, res_, sz_,
+                                                d_dense_f_, nullptr, (int32_t*)d_st);
+        if (rc == GPC_OK)
+            rc = gpc_dense_fit_predict_grid_dev(ctx_, &dense_params, P, dv.off, dv.n_max, dv.n_total, dv.x0, dv.x1, dv.rgb, 3, res_, sz_,
+                                                d_dense_c_, nullptr, (int32_t*)d_st);
+        if (rc == GPC_OK) rc = gpc_dev_memcpy(ctx_, status_.data(), d_st, sizeof(int32_t) * (size_t)P, GPC_COPY_D2H);
+        (void)gpc_dev_free(ctx_, d_st);
+        check(rc, ctx_, "gpc_dense_fit_predict_grid_dev");
+        mean_added_ = 0;
+        max_added_ = 0;
+        for (int i = 0; i < P; ++i) {
+            const int n = batch_.off[i + 1] - batch_.off[i];
+            mean_added_ += n;
+            max_added_ = std::max(max_added_, n);
+        }
+        mean_added_ /= P;
+        trained_ = true;
+        return;
+    }
     if (model_ == gp_model::dense) {
         dense_f_.assign((size_t)P * m, 0.0);
         dense_c_.assign((size_t)P * 3 * m, 0.0);
@@ -344,10 +387,30 @@ void gp_compressor::train_processes()
         shuffle(perm_d, n);
         shuffle(perm_c, n);
     }
-    check(gpc_sparse_add(gps_, batch_.off.data(), batch_.x0.data(), batch_.x1.data(), batch_.y.data(), perm_d.data(),
-                         status_.data()), ctx_, "gpc_sparse_add(depth)");
-    check(gpc_sparse_add(rgb_gps_, batch_.off.data(), batch_.x0.data(), batch_.x1.data(), batch_.rgb.data(), perm_c.data(),
-                         status_.data()), ctx_, "gpc_sparse_add(rgb)");
+    if (on_device) {
+        // the points are already in HBM: only the two insertion orders go up
+        const size_t N = (size_t)dv.n_total;
+        void *d_pd = nullptr, *d_pc = nullptr, *d_st = nullptr;
+        check(gpc_dev_malloc(ctx_, sizeof(int32_t) * N, &d_pd), ctx_, "gpc_dev_malloc");
+        check(gpc_dev_malloc(ctx_, sizeof(int32_t) * N, &d_pc), ctx_, "gpc_dev_malloc");
+        check(gpc_dev_malloc(ctx_, sizeof(int32_t) * (size_t)P, &d_st), ctx_, "gpc_dev_malloc");
+        int rc = gpc_dev_memcpy(ctx_, d_pd, perm_d.data(), sizeof(int32_t) * N, GPC_COPY_H2D);
+        if (rc == GPC_OK) rc = gpc_dev_memcpy(ctx_, d_pc, perm_c.data(), sizeof(int32_t) * N, GPC_COPY_H2D);
+        if (rc == GPC_OK)
+            rc = gpc_sparse_add_dev(gps_, dv.off, dv.n_max, dv.n_total, dv.x0, dv.x1, dv.y, (const int32_t*)d_pd, (int32_t*)d_st);
+        if (rc == GPC_OK)
+            rc = gpc_sparse_add_dev(rgb_gps_, dv.off, dv.n_max, dv.n_total, dv.x0, dv.x1, dv.rgb, (const int32_t*)d_pc, (int32_t*)d_st);
+        if (rc == GPC_OK) rc = gpc_dev_memcpy(ctx_, status_.data(), d_st, sizeof(int32_t) * (size_t)P, GPC_COPY_D2H);
+        (void)gpc_dev_free(ctx_, d_pd);
+        (void)gpc_dev_free(ctx_, d_pc);
+        (void)gpc_dev_free(ctx_, d_st);
+        check(rc, ctx_, "gpc_sparse_add_dev");
+    } else {
+        check(gpc_sparse_add(gps_, batch_.off.data(), batch_.x0.data(), batch_.x1.data(), batch_.y.data(), perm_d.data(),
+                             status_.data()), ctx_, "gpc_sparse_add(depth)");
+        check(gpc_sparse_add(rgb_gps_, batch_.off.data(), batch_.x0.data(), batch_.x1.data(), batch_.rgb.data(), perm_c.data(),
+                             status_.data()), ctx_, "gpc_sparse_add(rgb)");
+    }
     std::vector<int32_t> bv(P);
     check(gpc_sparse_sizes(gps_, bv.data()), ctx_, "gpc_sparse_sizes");
     double mean = 0, added = 0;                  // "Mean added" / "Max added" (:164-168, 173-174)
@@ -396,6 +459,46 @@ pointcloud gp_compressor::load_compressed()
             xs1[pcount] = res_ * (((double)y + 0.5f) / (double)sz_ - 0.5f);
             ++pcount;
         }
+    if (dev_patches_) {
+        // predict (sparse) and reproject on the device; the records are the only download
+        gpc_patches_view dv{};
+        gpc_patches_view_dev(dev_patches_, &dv);
+        std::vector<int32_t> bvh(P, 1);
+        if (model_ == gp_model::dense) for (int i = 0; i < P; ++i) bvh[i] = batch_.off[i + 1] - batch_.off[i];
+        else check(gpc_sparse_sizes(gps_, bvh.data()), ctx_, "gpc_sparse_sizes");
+        void *d_xs0 = nullptr, *d_xs1 = nullptr, *d_bv = nullptr, *d_f = nullptr, *d_c = nullptr, *d_rec = nullptr, *d_n = nullptr;
+        auto free_all = [&]() { for (void* q : {d_xs0, d_xs1, d_bv, d_rec, d_n}) if (q) (void)gpc_dev_free(ctx_, q);
+                                if (model_ != gp_model::dense) { if (d_f) (void)gpc_dev_free(ctx_, d_f); if (d_c) (void)gpc_dev_free(ctx_, d_c); } };
+        int rc = gpc_dev_malloc(ctx_, 8 * (size_t)m, &d_xs0);
+        if (rc == GPC_OK) rc = gpc_dev_malloc(ctx_, 8 * (size_t)m, &d_xs1);
+        if (rc == GPC_OK) rc = gpc_dev_malloc(ctx_, 4 * (size_t)P, &d_bv);
+        if (rc == GPC_OK) rc = gpc_dev_malloc(ctx_, sizeof(gpc_point_xyzrgb) * (size_t)P * m, &d_rec);
+        if (rc == GPC_OK) rc = gpc_dev_malloc(ctx_, 4, &d_n);
+        if (rc == GPC_OK) rc = gpc_dev_memcpy(ctx_, d_xs0, xs0.data(), 8 * (size_t)m, GPC_COPY_H2D);
+        if (rc == GPC_OK) rc = gpc_dev_memcpy(ctx_, d_xs1, xs1.data(), 8 * (size_t)m, GPC_COPY_H2D);
+        if (rc == GPC_OK) rc = gpc_dev_memcpy(ctx_, d_bv, bvh.data(), 4 * (size_t)P, GPC_COPY_H2D);
+        if (model_ == gp_model::dense) {
+            d_f = d_dense_f_;
+            d_c = d_dense_c_;
+        } else {
+            if (rc == GPC_OK) rc = gpc_dev_malloc(ctx_, 8 * (size_t)P * m, &d_f);
+            if (rc == GPC_OK) rc = gpc_dev_malloc(ctx_, 8 * (size_t)P * 3 * m, &d_c);
+            if (rc == GPC_OK) rc = gpc_sparse_predict_dev(gps_, m, (const double*)d_xs0, (const double*)d_xs1, (double*)d_f, nullptr, 0, nullptr);
+            if (rc == GPC_OK) rc = gpc_sparse_predict_dev(rgb_gps_, m, (const double*)d_xs0, (const double*)d_xs1, (double*)d_c, nullptr, 0, nullptr);
+        }
+        if (rc == GPC_OK)
+            rc = gpc_reproject_dev(ctx_, P, m, (const int32_t*)d_bv, (const double*)d_xs0, (const double*)d_xs1, (const double*)d_f,
+                                   (const double*)d_c, dv.rotations, dv.means, dv.rgb_means, (gpc_point_xyzrgb*)d_rec, (int32_t*)d_n);
+        int32_t npts = 0;
+        if (rc == GPC_OK) rc = gpc_dev_memcpy(ctx_, &npts, d_n, 4, GPC_COPY_D2H);
+        std::vector<gpc_point_xyzrgb> recs((size_t)(rc == GPC_OK ? npts : 0));
+        if (rc == GPC_OK && npts > 0) rc = gpc_dev_memcpy(ctx_, recs.data(), d_rec, sizeof(gpc_point_xyzrgb) * (size_t)npts, GPC_COPY_D2H);
+        free_all();
+        check(rc, ctx_, "load_compressed (device)");
+        out.resize(recs.size());
+        for (size_t q = 0; q < recs.size(); ++q) out[q] = point{recs[q].x, recs[q].y, recs[q].z, recs[q].r, recs[q].g, recs[q].b};
+        return out;
+    }
     std::vector<double> f_star, c_star;
     std::vector<int32_t> bv(P, 1);
     if (model_ == gp_model::dense) {
@@ -577,6 +680,7 @@ int gpc_host_project_device(void* h, char* err, int errlen)
     try { static_cast<gpc::gp_compressor*>(h)->project_cloud_device(); return 0; }
     catch (const std::exception& e) { if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.what()); return -1; }
 }
+void gpc_host_set_gpu_producer(void* h, int on) { static_cast<gpc::gp_compressor*>(h)->gpu_producer = on != 0; }
 int gpc_host_patch_count(void* h) { return static_cast<gpc::gp_compressor*>(h)->patches().patches(); }
 int gpc_host_point_count(void* h) { return (int)static_cast<gpc::gp_compressor*>(h)->patches().x0.size(); }
 // copies the batch: off[P+1], x0/x1/y[N], rgb[3N], R[9P], mean[3P], rgb_mean[3P]

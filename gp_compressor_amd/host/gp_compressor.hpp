@@ -113,6 +113,11 @@ protected:
     gpc_sparse* gps_ = nullptr;
     gpc_sparse* rgb_gps_ = nullptr;
     std::vector<double> dense_f_, dense_c_;   // dense model: grids predicted at training time (fit + predict are fused)
+    // device-resident flow (project_cloud_device): the batch stays in HBM, the GP kernels and the reprojection read it
+    // there, and only `off`, the insertion orders and the final cloud cross PCIe
+    gpc_patches* dev_patches_ = nullptr;
+    double *d_dense_f_ = nullptr, *d_dense_c_ = nullptr;
+    void release_device();
     std::vector<int32_t> status_;
     double mean_added_ = 0.0;
     int max_added_ = 0;

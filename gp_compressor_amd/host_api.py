@@ -35,6 +35,7 @@ def load():
         L.gpc_host_set_sparse_kernel.argtypes = [vp, d, d, d, d, i]
         L.gpc_host_project.argtypes = [vp]
         L.gpc_host_project_device.argtypes = [vp, vp, i]
+        L.gpc_host_set_gpu_producer.argtypes = [vp, i]
         L.gpc_host_patch_count.argtypes = [vp]
         L.gpc_host_point_count.argtypes = [vp]
         L.gpc_host_get_batch.argtypes = [vp] * 9
@@ -64,6 +65,10 @@ class GpCompressor:
         if getattr(self, "h", None):
             self.L.gpc_host_destroy(self.h)
             self.h = None
+
+    def set_gpu_producer(self, on):
+        """save_compressed(): cut the patches on the GPU and keep the whole round trip on the device (default), or on the host"""
+        self.L.gpc_host_set_gpu_producer(self.h, int(bool(on)))
 
     def set_sparse_kernel(self, sigmaf_sq, l_sq, s20_depth, s20_rgb, capacity):
         self.L.gpc_host_set_sparse_kernel(self.h, sigmaf_sq, l_sq, s20_depth, s20_rgb, capacity)

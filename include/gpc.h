@@ -29,6 +29,7 @@
 #ifndef GPC_H
 #define GPC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -86,6 +87,15 @@ int gpc_ctx_create(gpc_ctx** out, int device);
 #define GPC_STREAM_OWN ((void*)(intptr_t)-1)
 int gpc_ctx_set_stream(gpc_ctx* ctx, void* hip_stream);
 int gpc_ctx_synchronize(gpc_ctx* ctx);
+/* Device buffers for callers built without the HIP toolchain (the reference is a g++ / CMake project): what the `_dev`
+ * entry points need to be chained from plain C++.  gpc_dev_memcpy is synchronous and ordered after the work already
+ * enqueued on the context's stream; kind: */
+#define GPC_COPY_H2D 1
+#define GPC_COPY_D2H 2
+#define GPC_COPY_D2D 3
+int gpc_dev_malloc(gpc_ctx* ctx, size_t bytes, void** out);
+int gpc_dev_free(gpc_ctx* ctx, void* p);
+int gpc_dev_memcpy(gpc_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
 void gpc_ctx_destroy(gpc_ctx* ctx);
 /* text of the last failure on this context ("" if none); valid until the next call on the context */
 const char* gpc_last_error(const gpc_ctx* ctx);
