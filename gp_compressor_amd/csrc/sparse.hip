@@ -107,6 +107,47 @@ __device__ static inline void sp_rmw_cq(double* C, double* Q, int ld, int nb, F 
     }
 }
 
+// The same pass in the mat-vec's own traversal -- wave w owns the column quarter w, its lanes the rows, columns ascending --
+// which lets it hand the NEXT point's mat-vecs C' k' and Q' k' (k' = kvn, evaluated against the basis as it stands after
+// this update) out of the values it is about to store: the partial sums land in `pnext` exactly where the stand-alone
+// mat-vec of the next iteration would have put them, the same numbers bit for bit, and C and Q are not read a second time
+// (a third of the traffic of a point).
+#ifndef SP_RMW_NEXT
+#define SP_RMW_NEXT 8
+#endif
+template <class F>
+__device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int nb, const double* kvn, double* pnext, F f)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int jlo = (nb * wave) >> 2, jhi = (nb * (wave + 1)) >> 2;
+    for (int i = lane; i < nb; i += 64) {
+        double ac = 0.0, aq = 0.0;
+        for (int j0 = jlo; j0 < jhi; j0 += SP_RMW_NEXT) {
+            double c[SP_RMW_NEXT], q[SP_RMW_NEXT];
+#pragma unroll
+            for (int u = 0; u < SP_RMW_NEXT; ++u) {
+                const int j = (j0 + u < jhi) ? j0 + u : jhi - 1;      // clamped: the loads are unconditional and come first
+                c[u] = C[i + (size_t)j * ld];
+                q[u] = Q[i + (size_t)j * ld];
+            }
+#pragma unroll
+            for (int u = 0; u < SP_RMW_NEXT; ++u) {
+                const int j = j0 + u;
+                if (j < jhi) {
+                    f(i, j, c[u], q[u]);
+                    C[i + (size_t)j * ld] = c[u];
+                    Q[i + (size_t)j * ld] = q[u];
+                    const double kj = kvn[j];
+                    ac += c[u] * kj;
+                    aq += q[u] * kj;
+                }
+            }
+        }
+        pnext[(wave * 2 + 0) * ld + i] = ac;
+        pnext[(wave * 2 + 1) * ld + i] = aq;
+    }
+}
+
 // delete_bv(loc): sparse_gp.hpp:252-295 / sparse_gp_field.hpp:219-263.  b is workgroup-uniform; returns b-1.
 __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_bug, double* Cstar, double* Qstar,
                                    double* Crep, double* Qrep)
@@ -172,9 +213,11 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
 // rank-1 terms, and one pass writes the final C and Q.  Every element goes through the same floating-point operations
 // in the same order as the two-pass form, so the result is the same to the last bit; only the intermediate (b+1) x (b+1)
 // matrices never reach memory.  b == capacity on entry and on return.
+// When the coordinates of the NEXT point are known (nxt != nullptr) the pass also forms that point's mat-vecs (sp_rmw_cq_next).
 __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, double gamma, const double* qv, double px0, double px1,
                                             int field_bug, const double* ck, double* eh, double* sv, double* Cstar, double* Qstar,
-                                            double* Crep, double* Qrep, double* anew, double* sval, int* sidx)
+                                            double* Crep, double* Qrep, double* anew, double* sval, int* sidx,
+                                            const double* nxt, double* kvn, double* pnext, double sf, double c_exp, const double* T)
 {
     const int tid = threadIdx.x, ld = S.ld, ny = S.ny, last = b;
     const double ig = (double)1.0f / gamma;
@@ -240,7 +283,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
         }
     }
     // the one pass over C and Q
-    sp_rmw_cq(S.C, S.Q, ld, nb, [&](int i, int j, double& c, double& q) {
+    auto element = [&](int i, int j, double& c, double& q) {
         double bc, bq;
         if (i == loc) { bc = Crep[j]; bq = Qrep[j]; }
         else if (j == loc) { bc = Crep[i]; bq = Qrep[i]; }
@@ -252,7 +295,16 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
         const double cc = ((Qstar[i] + Cstar[i]) * (Qstar[j] + Cstar[j])) / qc_den;
         c = bc + (qq - cc);
         q = bq - qq;
-    });
+    };
+    if (nxt) {
+        // k' against the updated basis (BV[loc] was replaced above, behind a barrier)
+        const double n0 = nxt[0], n1 = nxt[1];
+        for (int i = tid; i < nb; i += SP_THREADS) kvn[i] = gpc_rbf(sf, c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
+        __syncthreads();
+        sp_rmw_cq_next(S.C, S.Q, ld, nb, kvn, pnext, element);
+    } else {
+        sp_rmw_cq(S.C, S.Q, ld, nb, element);
+    }
     __syncthreads();
     return nb;
 }
@@ -266,6 +318,7 @@ struct SpAddParams {
     const int32_t* perm;
     double *alpha, *C, *Q, *BV;
     int32_t *b, *count, *stat, *status_out;
+    int fuse_next;   // 1: full-update passes also form the next point's mat-vecs (0 only through GPC_SPARSE_NO_FUSE, for the tests)
 };
 
 __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A)   // <= 256 VGPRs: at least two workgroups per CU
@@ -286,6 +339,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
     double* Qstar = part + ld;
     double* Crep = part + 2 * ld;
     double* Qrep = part + 3 * ld;
+    double* pnext = part + 8 * ld;                 // the NEXT point's mat-vec partials, formed inside the fused update pass
+    double* kvn = pnext + 8 * ld;                  // ... and its k  [ld]
     gpc_exp_table_init(T);
 
     const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, eps_tol = A.prm.eps_tol;
@@ -303,6 +358,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
         int st = A.stat[patch];
         __syncthreads();
 
+        bool have_next = false;                      // k and the mat-vec partials of this iteration's point were formed by the previous one
         for (int it = 0; it < n; ++it) {
             const int r = A.perm ? A.perm[o + it] : it;
             const double px0 = A.x0[o + r], px1 = A.x1[o + r];
@@ -310,6 +366,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
             for (int c = 0; c < ny; ++c) yv[c] = A.y[(size_t)c * A.n_total + o + r];
             const double kstar = sf;   // kernel_function(X, X) = p(0)*exp(0)  (:98)
 
+            const bool from_prev = have_next;
+            have_next = false;
             if (b == 0) {
                 // First point (:100-114)
                 if (tid == 0) {
@@ -325,11 +383,16 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
             }
 
             // k = construct_covariance(X, BV)  (:119, :523-530)
-            for (int i = tid; i < b; i += SP_THREADS) kv[i] = gpc_rbf(sf, A.c_exp, px0, px1, S.BV[2 * i], S.BV[2 * i + 1], T);
+            if (from_prev) {
+                double* t_ = kv; kv = kvn; kvn = t_;       // formed with the update pass of the previous point
+            } else {
+                for (int i = tid; i < b; i += SP_THREADS) kv[i] = gpc_rbf(sf, A.c_exp, px0, px1, S.BV[2 * i], S.BV[2 * i + 1], T);
+            }
             __syncthreads();
 
             // C k and e_hat = Q k (:140,:160,:171): wave w covers columns j in its quarter, lanes cover rows
-            {
+            const double* pp = from_prev ? pnext : part;
+            if (!from_prev) {
                 const int jlo = (b * wave) >> 2, jhi = (b * (wave + 1)) >> 2;
                 for (int i = lane; i < b; i += 64) {
                     double ac = 0.0, aq = 0.0;
@@ -346,8 +409,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
             double sums[4] = {0.0, 0.0, 0.0, 0.0};   // m[0..2] partial, (kCk, ke) handled in a second pass
             double dots[4] = {0.0, 0.0, 0.0, 0.0};
             for (int i = tid; i < b; i += SP_THREADS) {
-                const double c_ = part[0 * ld + i] + part[2 * ld + i] + part[4 * ld + i] + part[6 * ld + i];
-                const double q_ = part[1 * ld + i] + part[3 * ld + i] + part[5 * ld + i] + part[7 * ld + i];
+                const double c_ = pp[0 * ld + i] + pp[2 * ld + i] + pp[4 * ld + i] + pp[6 * ld + i];
+                const double q_ = pp[1 * ld + i] + pp[3 * ld + i] + pp[5 * ld + i] + pp[7 * ld + i];
                 ck[i] = c_;
                 eh[i] = q_;
                 const double ki = kv[i];
@@ -410,8 +473,16 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 st = GPC_STATUS_OVERFLOW;                   // capacity == -1 and GPC_MAX_BV reached: skip the point
             } else if (capacity > 0 && b + 1 > capacity) {
                 // full update + the capacity deletion it forces, in one pass over C and Q
+                double nx[2] = {0.0, 0.0};
+                const bool more = A.fuse_next && it + 1 < n;
+                if (more) {
+                    const int rn = A.perm ? A.perm[o + it + 1] : it + 1;
+                    nx[0] = A.x0[o + rn];
+                    nx[1] = A.x1[o + rn];
+                }
                 b = sp_full_update_delete(S, b, rr, gamma, qv, px0, px1, A.prm.ref_field_delete_bug, ck, eh, sv, Cstar, Qstar, Crep,
-                                          Qrep, part + 4 * ld, sval, sidx);
+                                          Qrep, part + 4 * ld, sval, sidx, more ? nx : nullptr, kvn, pnext, sf, A.c_exp, T);
+                have_next = more;
             } else {
                 // full update (:164-203)
                 for (int i = tid; i <= b; i += SP_THREADS) {
@@ -430,11 +501,22 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 __syncthreads();
                 const double ig = (double)1.0f / gamma;
                 const int nb = b + 1;
-                sp_rmw_cq(S.C, S.Q, ld, nb, [&](int i, int j, double& c, double& q) {
+                auto grow = [&](int i, int j, double& c, double& q) {
                     const bool old = (i < b) && (j < b);          // the new row / column starts from zero, whatever memory held
                     c = (old ? c : 0.0) + (rr * sv[i]) * sv[j];
                     q = (old ? q : 0.0) + (ig * eh[i]) * eh[j];
-                });
+                };
+                if (A.fuse_next && it + 1 < n) {
+                    // the next point's k against the grown basis, and its mat-vecs out of this pass
+                    const int rn = A.perm ? A.perm[o + it + 1] : it + 1;
+                    const double n0 = A.x0[o + rn], n1 = A.x1[o + rn];
+                    for (int i = tid; i < nb; i += SP_THREADS) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
+                    __syncthreads();
+                    sp_rmw_cq_next(S.C, S.Q, ld, nb, kvn, pnext, grow);
+                    have_next = true;
+                } else {
+                    sp_rmw_cq(S.C, S.Q, ld, nb, grow);
+                }
                 b = nb;
                 __syncthreads();
             }
@@ -454,6 +536,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 sp_block_argmin(best, loc, sval, sidx);
                 if (loc < 0 || loc >= b) loc = 0;          // all-NaN scores: the reference keeps minloc = 0
                 b = sp_delete_bv(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
+                have_next = false;
             }
             // Delete for geometric reasons (:226-242)
             {
@@ -470,7 +553,10 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                     sp_block_argmin(best, loc, sval, sidx);
                     if (loc < 0 || loc >= b) loc = 0;
                     minscore = best;
-                    if (minscore < (double)1e-9f) b = sp_delete_bv(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
+                    if (minscore < (double)1e-9f) {
+                        b = sp_delete_bv(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
+                        have_next = false;              // the matrices and the basis changed after the pass
+                    }
                     else if (!(minscore >= (double)1e-9f)) break;   // NaN: `minscore < 1e-9f` is false in the reference too
                 }
             }
@@ -868,7 +954,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_train_kernel(SpTrainParams 
 
 // ------------------------------------------------------------------------------------------------ host side
 
-static size_t sp_add_lds(int ld) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (ld + 1) + 8 * ld); }
+static size_t sp_add_lds(int ld) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (ld + 1) + 8 * ld + 9 * ld); }
 static size_t sp_lik_lds(int ld, bool fast)
 {
     return sizeof(double) * (size_t)(64 + 5 * ld + SP_NQ * 8 * SP_PC + (size_t)ld * SP_PC * (fast ? 2 : 1));
@@ -965,6 +1051,7 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     A.off = off; A.x0 = x0; A.x1 = x1; A.y = y; A.perm = perm;
     A.alpha = g->alpha; A.C = g->C; A.Q = g->Q; A.BV = g->BV;
     A.b = g->b; A.count = g->count; A.stat = g->stat; A.status_out = status;
+    A.fuse_next = getenv("GPC_SPARSE_NO_FUSE") ? 0 : 1;
     const size_t lds = sp_add_lds(g->ld);
     int per_cu = (int)((160u * 1024u) / lds);
     per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);

@@ -385,3 +385,42 @@ def test_sparse_train_sigmaf(gp, oracle, regime):
     assert e.value.code == capi.GPC_EINVAL
     g3.close()
     g.close()
+
+
+@pytest.mark.parametrize("ny,cap,kernel", [(1, 100, "fill"), (3, 60, "fill"), (1, 200, "fill"), (1, 100, "default"), (1, 33, "geo")])
+def test_sparse_fused_next_matvec_is_bit_identical(gp, ny, cap, kernel, monkeypatch):
+    """The full-update passes over C and Q also form the NEXT point's mat-vecs C k', Q k' from the values they store (a third
+    less traffic per point).  Same numbers as the stand-alone mat-vec would give: with and without the fusion
+    (GPC_SPARSE_NO_FUSE) the states are identical bit for bit -- while the basis grows, when it is full (fused update +
+    capacity deletion), with explicit insertion orders, across chunked calls, and when geometric deletions invalidate the
+    prefetched products."""
+    capi, ctx = gp
+    res, P, n = 0.15, 24, 256
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=7 + cap, ragged=True, ny=ny)
+    perm = synth.sattolo_perms(off, seed=2)
+    kw = dict(capacity=cap)
+    if kernel == "fill":
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 8) ** 2, noise=1e-4 if ny == 1 else 1.0)
+    if kernel == "geo":            # long length scale: near-duplicate basis vectors -> geometric deletions right after full updates
+        kw.update(sigmaf_sq=1.0, l_sq=(res * 2) ** 2, noise=1e-6, eps_tol=1e-14)
+    p = capi.default_params_sparse(ny, **kw)
+    results = []
+    for no_fuse in (False, True):
+        if no_fuse:
+            monkeypatch.setenv("GPC_SPARSE_NO_FUSE", "1")
+        g = capi.Sparse(ctx, p, P, ny)
+        st1 = g.add(off, x0, x1, y, perm)
+        st2 = g.add(off, x0, x1, y)
+        results.append((st1, st2, g.sizes(), *g.state()))
+        g.close()
+    a, b_ = results
+    assert np.array_equal(a[0], b_[0]) and np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2])
+    if kernel == "geo":
+        assert a[2].max() < cap                    # the geometric rule, not the capacity, bounds the basis here
+    for i in range(P):
+        nb = int(a[2][i])
+        (al0, C0, Q0, BV0), (al1, C1, Q1, BV1) = a[3:], b_[3:]
+        assert np.array_equal(al0[i][:, :nb], al1[i][:, :nb], equal_nan=True)
+        assert np.array_equal(C0[i][:nb, :nb], C1[i][:nb, :nb], equal_nan=True)
+        assert np.array_equal(Q0[i][:nb, :nb], Q1[i][:nb, :nb], equal_nan=True)
+        assert np.array_equal(BV0[i][:nb], BV1[i][:nb], equal_nan=True)
