@@ -115,7 +115,7 @@ __device__ static inline void sp_rmw_cq(double* C, double* Q, int ld, int nb, F 
 #ifndef SP_RMW_NEXT
 #define SP_RMW_NEXT 8
 #endif
-template <class F>
+template <bool WRITE_Q = true, class F>
 __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int nb, const double* kvn, double* pnext, F f)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -136,7 +136,7 @@ __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int n
                 if (j < jhi) {
                     f(i, j, c[u], q[u]);
                     C[i + (size_t)j * ld] = c[u];
-                    Q[i + (size_t)j * ld] = q[u];
+                    if (WRITE_Q) Q[i + (size_t)j * ld] = q[u];          // the sparse update leaves Q alone: read for Q k' only
                     const double kj = kvn[j];
                     ac += c[u] * kj;
                     aq += q[u] * kj;
@@ -451,7 +451,15 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 }
                 __syncthreads();
                 const double re = rr * eta;
-                {
+                if (A.fuse_next && it + 1 < n) {
+                    // the basis does not change: the next point's k against it, and its mat-vecs out of this pass (Q is only read)
+                    const int rn = A.perm ? A.perm[o + it + 1] : it + 1;
+                    const double n0 = A.x0[o + rn], n1 = A.x1[o + rn];
+                    for (int i = tid; i < b; i += SP_THREADS) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
+                    __syncthreads();
+                    sp_rmw_cq_next<false>(S.C, S.Q, ld, b, kvn, pnext, [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; });
+                    have_next = true;
+                } else {
                     const int nn = b * b;
                     for (int e0 = tid; e0 < nn; e0 += SP_THREADS * SP_RMW) {     // loads first, see sp_rmw_cq
                         double cv[SP_RMW];

@@ -387,7 +387,8 @@ def test_sparse_train_sigmaf(gp, oracle, regime):
     g.close()
 
 
-@pytest.mark.parametrize("ny,cap,kernel", [(1, 100, "fill"), (3, 60, "fill"), (1, 200, "fill"), (1, 100, "default"), (1, 33, "geo")])
+@pytest.mark.parametrize("ny,cap,kernel", [(1, 100, "fill"), (3, 60, "fill"), (1, 200, "fill"), (1, 100, "default"), (1, 33, "geo"),
+                                            (1, 80, "mixed"), (3, 80, "mixed")])
 def test_sparse_fused_next_matvec_is_bit_identical(gp, ny, cap, kernel, monkeypatch):
     """The full-update passes over C and Q also form the NEXT point's mat-vecs C k', Q k' from the values they store (a third
     less traffic per point).  Same numbers as the stand-alone mat-vec would give: with and without the fusion
@@ -403,6 +404,8 @@ def test_sparse_fused_next_matvec_is_bit_identical(gp, ny, cap, kernel, monkeypa
         kw.update(sigmaf_sq=1.0, l_sq=(res / 8) ** 2, noise=1e-4 if ny == 1 else 1.0)
     if kernel == "geo":            # long length scale: near-duplicate basis vectors -> geometric deletions right after full updates
         kw.update(sigmaf_sq=1.0, l_sq=(res * 2) ** 2, noise=1e-6, eps_tol=1e-14)
+    if kernel == "mixed":          # a moderate length scale: sparse (projected) updates and full updates alternate on a mid-sized basis
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 3) ** 2, noise=1e-3 if ny == 1 else 1.0, eps_tol=1e-3)
     p = capi.default_params_sparse(ny, **kw)
     results = []
     for no_fuse in (False, True):
@@ -417,6 +420,8 @@ def test_sparse_fused_next_matvec_is_bit_identical(gp, ny, cap, kernel, monkeypa
     assert np.array_equal(a[0], b_[0]) and np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2])
     if kernel == "geo":
         assert a[2].max() < cap                    # the geometric rule, not the capacity, bounds the basis here
+    if kernel == "mixed":
+        assert 15 <= np.median(a[2]) < cap         # neither tiny nor saturated: both update forms ran
     for i in range(P):
         nb = int(a[2][i])
         (al0, C0, Q0, BV0), (al1, C1, Q1, BV1) = a[3:], b_[3:]
