@@ -388,7 +388,7 @@ def test_sparse_train_sigmaf(gp, oracle, regime):
 
 
 @pytest.mark.parametrize("ny,cap,kernel", [(1, 100, "fill"), (3, 60, "fill"), (1, 200, "fill"), (1, 100, "default"), (1, 33, "geo"),
-                                            (1, 80, "mixed"), (3, 80, "mixed")])
+                                            (1, 80, "mixed"), (3, 80, "mixed"), (1, 255, "fill"), (1, -1, "fill")])
 def test_sparse_fused_next_matvec_is_bit_identical(gp, ny, cap, kernel, monkeypatch):
     """The full-update passes over C and Q also form the NEXT point's mat-vecs C k', Q k' from the values they store (a third
     less traffic per point).  Same numbers as the stand-alone mat-vec would give: with and without the fusion
@@ -396,8 +396,8 @@ def test_sparse_fused_next_matvec_is_bit_identical(gp, ny, cap, kernel, monkeypa
     capacity deletion), with explicit insertion orders, across chunked calls, and when geometric deletions invalidate the
     prefetched products."""
     capi, ctx = gp
-    res, P, n = 0.15, 24, 256
-    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=7 + cap, ragged=True, ny=ny)
+    res, P, n = 0.15, 24, (400 if cap == 255 else 256)
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=7 + cap, ragged=True, ny=ny, n_min=(300 if cap == 255 else None))
     perm = synth.sattolo_perms(off, seed=2)
     kw = dict(capacity=cap)
     if kernel == "fill":
@@ -422,6 +422,10 @@ def test_sparse_fused_next_matvec_is_bit_identical(gp, ny, cap, kernel, monkeypa
         assert a[2].max() < cap                    # the geometric rule, not the capacity, bounds the basis here
     if kernel == "mixed":
         assert 15 <= np.median(a[2]) < cap         # neither tiny nor saturated: both update forms ran
+    if cap == 255:
+        assert a[2].max() == 255                   # the largest capacity the kernels take (GPC_MAX_BV - 1)
+    if cap == -1:                                  # exact GP: the basis runs into GPC_MAX_BV and further points are refused
+        assert a[2].max() == capi.MAX_BV and np.any(a[1] == 4) and np.array_equal(a[1] == 4, a[2] == capi.MAX_BV)
     for i in range(P):
         nb = int(a[2][i])
         (al0, C0, Q0, BV0), (al1, C1, Q1, BV1) = a[3:], b_[3:]
