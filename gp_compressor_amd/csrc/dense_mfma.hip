@@ -772,7 +772,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
                         const int i = ibase + 4 * s + lg;
-                        const double al = sf * av[c * MF_NPAD + i];
+                        // rows between 16 nt and the end of this 32-row group are never written by the solve: whatever the
+                        // previous kernel left in LDS there (possibly NaN) must not reach the sum -- select, do not multiply
+                        const double al = (i < n) ? sf * av[c * MF_NPAD + i] : 0.0;
 #pragma unroll
                         for (int nl = 0; nl < 2; ++nl) {
                             const double bop = eb[nl][s] * al;

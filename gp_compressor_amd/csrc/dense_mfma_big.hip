@@ -451,7 +451,9 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
                         const int i = ibase + 4 * s + lg;
-                        const double al = sf * av[c * BG_NPAD + i];     // av is zero beyond n (identity padding solves to 0)
+                        // av is zero from n to 16 nt (identity padding solves to 0) but never written beyond: stale LDS there
+                        // (possibly NaN from the previous kernel on this CU) must not reach the sum -- select, do not multiply
+                        const double al = (i < n) ? sf * av[c * BG_NPAD + i] : 0.0;
                         double ea[2], eb[2];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {

@@ -34,7 +34,12 @@ struct SpState {
     int ld, ny;
 };
 
-// ---- block-wide helpers (all SP_THREADS threads call) -------------------------------------------------------
+// The add kernel and its helpers run with 256 threads per patch, or with 64 (one wave per patch) when capacity <= 64 lets a
+// single wave cover every row: SP_NTH is the launch's workgroup size.  Both shapes produce the same bits (the reductions
+// and the quarter-wise mat-vec sums are laid out identically); the narrow one has no cross-wave barriers and keeps four
+// times as many patches in flight, which is what the small-basis regime needs.
+#define SP_NTH ((int)blockDim.x)
+// ---- block-wide helpers (all SP_NTH threads call) -------------------------------------------------------
 
 // dot products of up to 4 pairs at once; results broadcast to every thread
 __device__ static inline void sp_block_sum4(double (&v)[4], double* scratch /*4*4 doubles*/)
@@ -46,6 +51,10 @@ __device__ static inline void sp_block_sum4(double (&v)[4], double* scratch /*4*
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) scratch[w * 4 + q] = v[q];
+        if (w == 0)                                   // one-wave shape: the three absent waves contribute the +0.0 they would have summed
+            for (int w2 = SP_NTH >> 6; w2 < 4; ++w2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) scratch[w2 * 4 + q] = 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -67,7 +76,7 @@ __device__ static inline void sp_block_argmin(double& val, int& idx, double* sva
     __syncthreads();
     val = sval[0];
     idx = sidx[0];
-    for (int q = 1; q < SP_THREADS / 64; ++q) {
+    for (int q = 1; q < SP_NTH / 64; ++q) {
         double ov = sval[q];
         int oi = sidx[q];
         if (ov < val || (ov == val && oi < idx) || (val != val && ov == ov)) { val = ov; idx = oi; }
@@ -84,12 +93,12 @@ template <class F>
 __device__ static inline void sp_rmw_cq(double* C, double* Q, int ld, int nb, F f)
 {
     const int nn = nb * nb;
-    for (int e0 = threadIdx.x; e0 < nn; e0 += SP_THREADS * SP_RMW) {
+    for (int e0 = threadIdx.x; e0 < nn; e0 += SP_NTH * SP_RMW) {
         double c[SP_RMW], q[SP_RMW];
         int ii[SP_RMW], jj[SP_RMW];
 #pragma unroll
         for (int u = 0; u < SP_RMW; ++u) {
-            const int e = e0 + u * SP_THREADS;
+            const int e = e0 + u * SP_NTH;
             const int ec = e < nn ? e : e0;                      // clamped: the load is unconditional
             ii[u] = ec % nb;
             jj[u] = ec / nb;
@@ -98,7 +107,7 @@ __device__ static inline void sp_rmw_cq(double* C, double* Q, int ld, int nb, F 
         }
 #pragma unroll
         for (int u = 0; u < SP_RMW; ++u) {
-            if (e0 + u * SP_THREADS < nn) {
+            if (e0 + u * SP_NTH < nn) {
                 f(ii[u], jj[u], c[u], q[u]);
                 C[ii[u] + (size_t)jj[u] * ld] = c[u];
                 Q[ii[u] + (size_t)jj[u] * ld] = q[u];
@@ -118,8 +127,9 @@ __device__ static inline void sp_rmw_cq(double* C, double* Q, int ld, int nb, F 
 template <bool WRITE_Q = true, class F>
 __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int nb, const double* kvn, double* pnext, F f)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int jlo = (nb * wave) >> 2, jhi = (nb * (wave + 1)) >> 2;
+    const int lane = threadIdx.x & 63;
+    for (int quarter = threadIdx.x >> 6; quarter < 4; quarter += SP_NTH >> 6) {     // one quarter per wave, or all four in turn
+    const int jlo = (nb * quarter) >> 2, jhi = (nb * (quarter + 1)) >> 2;
     for (int i = lane; i < nb; i += 64) {
         double ac = 0.0, aq = 0.0;
         for (int j0 = jlo; j0 < jhi; j0 += SP_RMW_NEXT) {
@@ -143,8 +153,9 @@ __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int n
                 }
             }
         }
-        pnext[(wave * 2 + 0) * ld + i] = ac;
-        pnext[(wave * 2 + 1) * ld + i] = aq;
+        pnext[(quarter * 2 + 0) * ld + i] = ac;
+        pnext[(quarter * 2 + 1) * ld + i] = aq;
+    }
     }
 }
 
@@ -157,7 +168,7 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
     for (int c = 0; c < ny; ++c) alphastar[c] = S.alpha[c * ld + loc];
     const double cstar = S.C[loc + (size_t)loc * ld];
     const double qstar = S.Q[loc + (size_t)loc * ld];
-    for (int i = tid; i < b; i += SP_THREADS) {
+    for (int i = tid; i < b; i += SP_NTH) {
         Cstar[i] = S.C[i + (size_t)loc * ld];
         Qstar[i] = S.Q[i + (size_t)loc * ld];
         Crep[i] = S.C[i + (size_t)last * ld];
@@ -171,7 +182,7 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
         Qrep[loc] = Qrep[last];     // (:278)
     }
     __syncthreads();
-    for (int i = tid; i < b; i += SP_THREADS) {
+    for (int i = tid; i < b; i += SP_NTH) {
         const double cr = Crep[i], qr = Qrep[i];
         S.C[loc + (size_t)i * ld] = cr;   // C.row(loc) = Crep^T
         S.C[i + (size_t)loc * ld] = cr;   // C.col(loc) = Crep
@@ -187,7 +198,7 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
     const int nb = b - 1;
     const double qc_den = qstar + cstar;
     // alpha update (:285) / field variant (:250-253, multiplies when bug-compatible)
-    for (int i = tid; i < nb; i += SP_THREADS) {
+    for (int i = tid; i < nb; i += SP_NTH) {
         const double qc = Qstar[i] + Cstar[i];
         for (int c = 0; c < ny; ++c) {
             if (ny == 1) S.alpha[i] -= alphastar[0] / qc_den * qc;
@@ -221,7 +232,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
 {
     const int tid = threadIdx.x, ld = S.ld, ny = S.ny, last = b;
     const double ig = (double)1.0f / gamma;
-    for (int i = tid; i <= b; i += SP_THREADS) {
+    for (int i = tid; i <= b; i += SP_NTH) {
         const double si = (i < b) ? ck[i] : (double)1.0f;
         sv[i] = si;
         if (i == b) eh[b] = (double)(-1.0f);
@@ -235,7 +246,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
     double best = 0.0;
     int loc = 0x7fffffff;
     bool have = false;
-    for (int i = tid; i <= b; i += SP_THREADS) {
+    for (int i = tid; i <= b; i += SP_NTH) {
         double a2 = 0.0;
         for (int c = 0; c < ny; ++c) { const double a = anew[c * ld + i]; a2 += a * a; }
         const double c0 = (i < b) ? S.C[i + (size_t)i * ld] : 0.0, q0 = (i < b) ? S.Q[i + (size_t)i * ld] : 0.0;
@@ -247,7 +258,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
     sp_block_argmin(best, loc, sval, sidx);
     if (loc < 0 || loc > b) loc = 0;          // all-NaN scores: the reference keeps minloc = 0
     // columns loc and last of the updated matrices (delete_bv :259-278)
-    for (int i = tid; i <= b; i += SP_THREADS) {
+    for (int i = tid; i <= b; i += SP_NTH) {
         const bool old = (i < b) && (loc < b);
         const double c0 = old ? S.C[i + (size_t)loc * ld] : 0.0, q0 = old ? S.Q[i + (size_t)loc * ld] : 0.0;
         Cstar[i] = c0 + (rr * sv[i]) * sv[loc];
@@ -274,7 +285,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
     const int nb = b;
     const double qc_den = qstar + cstar;
     // alpha (:257, :285; field variant :250-253 multiplies when bug-compatible)
-    for (int i = tid; i < nb; i += SP_THREADS) {
+    for (int i = tid; i < nb; i += SP_NTH) {
         const double qc = Qstar[i] + Cstar[i];
         for (int c = 0; c < ny; ++c) {
             const double asw = (i == loc) ? anew[c * ld + last] : anew[c * ld + i];
@@ -299,7 +310,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
     if (nxt) {
         // k' against the updated basis (BV[loc] was replaced above, behind a barrier)
         const double n0 = nxt[0], n1 = nxt[1];
-        for (int i = tid; i < nb; i += SP_THREADS) kvn[i] = gpc_rbf(sf, c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
+        for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
         __syncthreads();
         sp_rmw_cq_next(S.C, S.Q, ld, nb, kvn, pnext, element);
     } else {
@@ -386,29 +397,31 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
             if (from_prev) {
                 double* t_ = kv; kv = kvn; kvn = t_;       // formed with the update pass of the previous point
             } else {
-                for (int i = tid; i < b; i += SP_THREADS) kv[i] = gpc_rbf(sf, A.c_exp, px0, px1, S.BV[2 * i], S.BV[2 * i + 1], T);
+                for (int i = tid; i < b; i += SP_NTH) kv[i] = gpc_rbf(sf, A.c_exp, px0, px1, S.BV[2 * i], S.BV[2 * i + 1], T);
             }
             __syncthreads();
 
             // C k and e_hat = Q k (:140,:160,:171): wave w covers columns j in its quarter, lanes cover rows
             const double* pp = from_prev ? pnext : part;
             if (!from_prev) {
-                const int jlo = (b * wave) >> 2, jhi = (b * (wave + 1)) >> 2;
-                for (int i = lane; i < b; i += 64) {
-                    double ac = 0.0, aq = 0.0;
-                    for (int j = jlo; j < jhi; ++j) {
-                        const double kj = kv[j];
-                        ac += S.C[i + (size_t)j * ld] * kj;
-                        aq += S.Q[i + (size_t)j * ld] * kj;
+                for (int quarter = wave; quarter < 4; quarter += SP_NTH >> 6) {     // one quarter per wave, or all four in turn
+                    const int jlo = (b * quarter) >> 2, jhi = (b * (quarter + 1)) >> 2;
+                    for (int i = lane; i < b; i += 64) {
+                        double ac = 0.0, aq = 0.0;
+                        for (int j = jlo; j < jhi; ++j) {
+                            const double kj = kv[j];
+                            ac += S.C[i + (size_t)j * ld] * kj;
+                            aq += S.Q[i + (size_t)j * ld] * kj;
+                        }
+                        part[(quarter * 2 + 0) * ld + i] = ac;
+                        part[(quarter * 2 + 1) * ld + i] = aq;
                     }
-                    part[(wave * 2 + 0) * ld + i] = ac;
-                    part[(wave * 2 + 1) * ld + i] = aq;
                 }
             }
             __syncthreads();
             double sums[4] = {0.0, 0.0, 0.0, 0.0};   // m[0..2] partial, (kCk, ke) handled in a second pass
             double dots[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int i = tid; i < b; i += SP_THREADS) {
+            for (int i = tid; i < b; i += SP_NTH) {
                 const double c_ = pp[0 * ld + i] + pp[2 * ld + i] + pp[4 * ld + i] + pp[6 * ld + i];
                 const double q_ = pp[1 * ld + i] + pp[3 * ld + i] + pp[5 * ld + i] + pp[7 * ld + i];
                 ck[i] = c_;
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
             if (gamma < eps_tol && capacity != -1) {
                 // sparse update (:155-163)
                 const double eta = 1 / (1 + gamma * rr);
-                for (int i = tid; i < b; i += SP_THREADS) {
+                for (int i = tid; i < b; i += SP_NTH) {
                     const double sh = ck[i] + eh[i];        // s_hat = C*k + e_hat
                     sv[i] = sh;
                     for (int c = 0; c < ny; ++c) S.alpha[c * ld + i] += sh * (qv[c] * eta);
@@ -455,25 +468,25 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                     // the basis does not change: the next point's k against it, and its mat-vecs out of this pass (Q is only read)
                     const int rn = A.perm ? A.perm[o + it + 1] : it + 1;
                     const double n0 = A.x0[o + rn], n1 = A.x1[o + rn];
-                    for (int i = tid; i < b; i += SP_THREADS) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
+                    for (int i = tid; i < b; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
                     sp_rmw_cq_next<false>(S.C, S.Q, ld, b, kvn, pnext, [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; });
                     have_next = true;
                 } else {
                     const int nn = b * b;
-                    for (int e0 = tid; e0 < nn; e0 += SP_THREADS * SP_RMW) {     // loads first, see sp_rmw_cq
+                    for (int e0 = tid; e0 < nn; e0 += SP_NTH * SP_RMW) {     // loads first, see sp_rmw_cq
                         double cv[SP_RMW];
                         int ii[SP_RMW], jj[SP_RMW];
 #pragma unroll
                         for (int u = 0; u < SP_RMW; ++u) {
-                            const int e = e0 + u * SP_THREADS, ec = e < nn ? e : e0;
+                            const int e = e0 + u * SP_NTH, ec = e < nn ? e : e0;
                             ii[u] = ec % b;
                             jj[u] = ec / b;
                             cv[u] = S.C[ii[u] + (size_t)jj[u] * ld];
                         }
 #pragma unroll
                         for (int u = 0; u < SP_RMW; ++u)
-                            if (e0 + u * SP_THREADS < nn) S.C[ii[u] + (size_t)jj[u] * ld] = cv[u] + (re * sv[ii[u]]) * sv[jj[u]];
+                            if (e0 + u * SP_NTH < nn) S.C[ii[u] + (size_t)jj[u] * ld] = cv[u] + (re * sv[ii[u]]) * sv[jj[u]];
                     }
                 }
                 __syncthreads();
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 have_next = more;
             } else {
                 // full update (:164-203)
-                for (int i = tid; i <= b; i += SP_THREADS) {
+                for (int i = tid; i <= b; i += SP_NTH) {
                     const double si = (i < b) ? ck[i] : (double)1.0f;
                     sv[i] = si;
                     if (i == b) eh[b] = (double)(-1.0f);
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                         S.alpha[c * ld + i] = a0 + qv[c] * si;
                     }
                 }
-                if (tid == 64) {
+                if (tid == 64 % SP_NTH) {
                     S.BV[2 * b] = px0;
                     S.BV[2 * b + 1] = px1;
                 }
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                     // the next point's k against the grown basis, and its mat-vecs out of this pass
                     const int rn = A.perm ? A.perm[o + it + 1] : it + 1;
                     const double n0 = A.x0[o + rn], n1 = A.x1[o + rn];
-                    for (int i = tid; i < nb; i += SP_THREADS) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
+                    for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
                     sp_rmw_cq_next(S.C, S.Q, ld, nb, kvn, pnext, grow);
                     have_next = true;
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 double best = 0.0;
                 int loc = 0x7fffffff;
                 bool have = false;
-                for (int i = tid; i < b; i += SP_THREADS) {
+                for (int i = tid; i < b; i += SP_NTH) {
                     double a2 = 0.0;
                     for (int c = 0; c < ny; ++c) { const double a = S.alpha[c * ld + i]; a2 += a * a; }
                     const double score = a2 / (S.Q[i + (size_t)i * ld] + S.C[i + (size_t)i * ld]);
@@ -553,7 +566,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                     double best = 0.0;
                     int loc = 0x7fffffff;
                     bool have = false;
-                    for (int i = tid; i < b; i += SP_THREADS) {
+                    for (int i = tid; i < b; i += SP_NTH) {
                         const double score = (double)1.0f / S.Q[i + (size_t)i * ld];
                         if (!have || score < best) { best = score; loc = i; have = true; }
                     }
@@ -1061,11 +1074,15 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     A.b = g->b; A.count = g->count; A.stat = g->stat; A.status_out = status;
     A.fuse_next = getenv("GPC_SPARSE_NO_FUSE") ? 0 : 1;
     const size_t lds = sp_add_lds(g->ld);
+    // capacity <= 64: one wave per patch (every row of the basis fits a lane; no cross-wave barriers, four times the patches
+    // in flight); otherwise four waves per patch.  Same results, bit for bit (GPC_SPARSE_WIDE forces the wide shape: tests).
+    const int nth = (g->prm.capacity > 0 && g->prm.capacity <= 64 && !getenv("GPC_SPARSE_WIDE")) ? 64 : SP_THREADS;
     int per_cu = (int)((160u * 1024u) / lds);
-    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    const int per_cu_max = nth == 64 ? 8 : 4;
+    per_cu = per_cu > per_cu_max ? per_cu_max : (per_cu < 1 ? 1 : per_cu);
     if (const char* e = getenv("GPC_SPARSE_PER_CU")) per_cu = std::max(1, atoi(e));   // diagnostic: resident-state experiments
     int grid = std::min(g->P, ctx->num_cus * per_cu);
-    hipLaunchKernelGGL(sparse_add_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
+    hipLaunchKernelGGL(sparse_add_kernel, dim3(grid), dim3(nth), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;
 }

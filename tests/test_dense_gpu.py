@@ -322,3 +322,37 @@ def test_dense_full_size_properties(gp, oracle, P, n, label):
     idx = np.concatenate([np.arange(off[i], off[i + 1]) for i in sample])
     fo, _, so = oracle.dense_fit_predict_batch(oracle.dense_params(), sub_off, x0[idx], x1[idx], y[:, idx], xs0, xs1)
     _close(fa[sample], fo, FTOL)
+
+
+def test_dense_does_not_read_stale_lds(gp, oracle):
+    """LDS keeps what the previous kernel on the CU left there.  A sparse exact-GP run on duplicated points fills it with
+    NaN / Inf; a dense batch whose sizes are not multiples of 32 must not let those leak into its predictive sums (the rows
+    between 16 ceil(n / 16) and the next multiple of 32 are never written by the solve; the sums once multiplied them by a
+    zero kernel factor instead of skipping them, and a whole patch came out NaN when the sparse tests had run first)."""
+    capi, ctx = gp
+    res, sz = 0.15, 20
+    # 1. poison: every CU runs sparse patches whose state degenerates to NaN / Inf (capacity -1, each point added twice)
+    Pp = 1024
+    off, x0, x1, y = synth.make_patches(Pp, 24, res=res, seed=5)
+    g = capi.Sparse(ctx, capi.default_params_sparse(1, sigmaf_sq=1.0, l_sq=(res / 8) ** 2, noise=1e-4, capacity=-1), Pp, 1)
+    g.add(off, x0, x1, y)
+    g.add(off, x0, x1, y)
+    al, C_, Q, BV = g.state()
+    assert not np.all(np.isfinite(C_[:, :4, :4]))                      # the poison is there
+    # ... and spread over the whole LDS by the kernels that stage C K products of that state in it
+    xs0, xs1 = synth.grid(res, sz)
+    g.predict(xs0, xs1)
+    g.likelihood(off, x0, x1, y)
+    g.close()
+    # 2. ragged dense batches on the register-resident and on the tiled kernel
+    for n_hi, P in ((200, 2048), (400, 1024)):
+        off, x0, x1, y = synth.make_patches(P, n_hi, res=res, seed=6, ragged=True, n_min=n_hi // 3)
+        p0 = capi.default_params_dense(sigmaf_sq=1.0, l_sq=(res / 4) ** 2, noise=1e-3)
+        f, st = ctx.dense_fit_predict_grid(p0, off, x0, x1, y, res, sz)
+        assert np.all(st == 0) and np.all(np.isfinite(f))
+        xs0, xs1 = oracle.grid(res, sz)
+        sel = np.arange(0, P, P // 16)
+        soff = np.concatenate([[0], np.cumsum(np.diff(off)[sel])]).astype(np.int32)
+        idx = np.concatenate([np.arange(off[i], off[i + 1]) for i in sel])
+        fo, _, so = oracle.dense_fit_predict_batch(oracle.dense_params(1.0, (res / 4) ** 2, 1e-3), soff, x0[idx], x1[idx], y[:, idx], xs0, xs1)
+        assert np.max(np.abs(f[sel] - fo)) <= 1e-8 * np.max(np.abs(fo))

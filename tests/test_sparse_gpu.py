@@ -433,3 +433,40 @@ def test_sparse_fused_next_matvec_is_bit_identical(gp, ny, cap, kernel, monkeypa
         assert np.array_equal(C0[i][:nb, :nb], C1[i][:nb, :nb], equal_nan=True)
         assert np.array_equal(Q0[i][:nb, :nb], Q1[i][:nb, :nb], equal_nan=True)
         assert np.array_equal(BV0[i][:nb], BV1[i][:nb], equal_nan=True)
+
+
+@pytest.mark.parametrize("ny,cap,kernel", [(1, 64, "fill"), (3, 50, "fill"), (1, 20, "default"), (3, 40, "mixed"), (1, 33, "geo"), (1, 1, "fill")])
+def test_sparse_one_wave_per_patch_is_bit_identical(gp, ny, cap, kernel, monkeypatch):
+    """capacity <= 64: the add kernel runs one wave per patch (every basis row has its lane; no cross-wave barriers, four times
+    as many patches in flight).  The reductions and the quarter-wise mat-vec sums keep the layout of the four-wave shape
+    (GPC_SPARSE_WIDE selects it): identical states, bit for bit, in every update regime."""
+    capi, ctx = gp
+    res, P, n = 0.15, 37, 200
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=3 + cap, ragged=True, ny=ny)
+    perm = synth.sattolo_perms(off, seed=9)
+    kw = dict(capacity=cap)
+    if kernel == "fill":
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 8) ** 2, noise=1e-4 if ny == 1 else 1.0)
+    if kernel == "geo":
+        kw.update(sigmaf_sq=1.0, l_sq=(res * 2) ** 2, noise=1e-6, eps_tol=1e-14)
+    if kernel == "mixed":
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 3) ** 2, noise=1e-3 if ny == 1 else 1.0, eps_tol=1e-3)
+    p = capi.default_params_sparse(ny, **kw)
+    results = []
+    for wide in (False, True):
+        if wide:
+            monkeypatch.setenv("GPC_SPARSE_WIDE", "1")
+        g = capi.Sparse(ctx, p, P, ny)
+        st1 = g.add(off, x0, x1, y, perm)
+        st2 = g.add(off, x0, x1, y)
+        results.append((st1, st2, g.sizes(), *g.state()))
+        g.close()
+    a, b_ = results
+    assert np.array_equal(a[0], b_[0]) and np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2])
+    for i in range(P):
+        nb = int(a[2][i])
+        (al0, C0, Q0, BV0), (al1, C1, Q1, BV1) = a[3:], b_[3:]
+        assert np.array_equal(al0[i][:, :nb], al1[i][:, :nb], equal_nan=True)
+        assert np.array_equal(C0[i][:nb, :nb], C1[i][:nb, :nb], equal_nan=True)
+        assert np.array_equal(Q0[i][:nb, :nb], Q1[i][:nb, :nb], equal_nan=True)
+        assert np.array_equal(BV0[i][:nb], BV1[i][:nb], equal_nan=True)
