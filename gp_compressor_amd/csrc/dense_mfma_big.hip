@@ -138,7 +138,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
             px0[i] = live ? q0 : 0.0;
             px1[i] = live ? q1 : 0.0;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) wv[c * BG_NPAD + i] = 0.0;
+            for (int c = 0; c < 3; ++c) { wv[c * BG_NPAD + i] = 0.0; av[c * BG_NPAD + i] = 0.0; }   // av: no stale LDS beyond the solved rows
         }
 #pragma unroll
         for (int o_ = 32; o_ > 0; o_ >>= 1) dev = __builtin_fmax(dev, __shfl_xor(dev, o_, 64));
