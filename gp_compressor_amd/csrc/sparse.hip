@@ -1075,10 +1075,14 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     A.fuse_next = getenv("GPC_SPARSE_NO_FUSE") ? 0 : 1;
     const size_t lds = sp_add_lds(g->ld);
     // capacity <= 64: one wave per patch (every row of the basis fits a lane; no cross-wave barriers, four times the patches
-    // in flight); otherwise four waves per patch.  Same results, bit for bit (GPC_SPARSE_WIDE forces the wide shape: tests).
-    const int nth = (g->prm.capacity > 0 && g->prm.capacity <= 64 && !getenv("GPC_SPARSE_WIDE")) ? 64 : SP_THREADS;
+    // in flight); capacity <= 100 (the reference's default): two waves, twice the patches in flight; otherwise four waves per
+    // patch.  While a thread owns at most one basis row the shapes give the same results, bit for bit (GPC_SPARSE_WIDE forces
+    // the four-wave shape: tests).  Measured at capacity 100: 465 k vs 268 k patches/s in the small-basis regime, 75 k vs 68 k
+    // with a full basis; at capacity 128 two waves lose (49 k vs 54 k).
+    const int cap_ = g->prm.capacity;
+    const int nth = (cap_ <= 0 || getenv("GPC_SPARSE_WIDE")) ? SP_THREADS : cap_ <= 64 ? 64 : cap_ <= 100 ? 128 : SP_THREADS;
     int per_cu = (int)((160u * 1024u) / lds);
-    const int per_cu_max = nth == 64 ? 8 : 4;
+    const int per_cu_max = 2 * SP_THREADS / nth;
     per_cu = per_cu > per_cu_max ? per_cu_max : (per_cu < 1 ? 1 : per_cu);
     if (const char* e = getenv("GPC_SPARSE_PER_CU")) per_cu = std::max(1, atoi(e));   // diagnostic: resident-state experiments
     int grid = std::min(g->P, ctx->num_cus * per_cu);

@@ -435,11 +435,12 @@ def test_sparse_fused_next_matvec_is_bit_identical(gp, ny, cap, kernel, monkeypa
         assert np.array_equal(BV0[i][:nb], BV1[i][:nb], equal_nan=True)
 
 
-@pytest.mark.parametrize("ny,cap,kernel", [(1, 64, "fill"), (3, 50, "fill"), (1, 20, "default"), (3, 40, "mixed"), (1, 33, "geo"), (1, 1, "fill")])
+@pytest.mark.parametrize("ny,cap,kernel", [(1, 64, "fill"), (3, 50, "fill"), (1, 20, "default"), (3, 40, "mixed"), (1, 33, "geo"), (1, 1, "fill"),
+                                            (1, 100, "fill"), (3, 100, "default"), (1, 90, "mixed"), (3, 65, "fill")])
 def test_sparse_one_wave_per_patch_is_bit_identical(gp, ny, cap, kernel, monkeypatch):
     """capacity <= 64: the add kernel runs one wave per patch (every basis row has its lane; no cross-wave barriers, four times
-    as many patches in flight).  The reductions and the quarter-wise mat-vec sums keep the layout of the four-wave shape
-    (GPC_SPARSE_WIDE selects it): identical states, bit for bit, in every update regime."""
+    as many patches in flight); capacity <= 100: two waves per patch.  The reductions and the quarter-wise mat-vec sums keep
+    the layout of the four-wave shape (GPC_SPARSE_WIDE selects it): identical states, bit for bit, in every update regime."""
     capi, ctx = gp
     res, P, n = 0.15, 37, 200
     off, x0, x1, y = synth.make_patches(P, n, res=res, seed=3 + cap, ragged=True, ny=ny)
