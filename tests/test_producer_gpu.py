@@ -219,3 +219,35 @@ def test_producer_feeds_the_sparse_gps_on_device(gp, oracle):
     for g in (gd, gc, hd, hc):
         g.close()
     pt.close()
+
+
+def test_device_buffer_helpers(gp):
+    """gpc_dev_malloc / gpc_dev_memcpy / gpc_dev_free: what a host built without the HIP toolchain chains the _dev entries with."""
+    import ctypes as C
+    capi, ctx = gp
+    L, h = ctx.lib, ctx.h
+    p = C.c_void_p()
+    assert L.gpc_dev_malloc(h, 1 << 20, C.byref(p)) == 0 and p.value
+    src = np.arange(1 << 17, dtype=np.float64)
+    dst = np.zeros_like(src)
+    q = C.c_void_p()
+    assert L.gpc_dev_malloc(h, 1 << 20, C.byref(q)) == 0
+    assert L.gpc_dev_memcpy(h, p, src.ctypes.data, src.nbytes, 1) == 0          # H2D
+    assert L.gpc_dev_memcpy(h, q, p, src.nbytes, 3) == 0                        # D2D
+    assert L.gpc_dev_memcpy(h, dst.ctypes.data, q, src.nbytes, 2) == 0          # D2H
+    assert np.array_equal(src, dst)
+    assert L.gpc_dev_memcpy(h, dst.ctypes.data, q, src.nbytes, 7) == capi.GPC_EINVAL
+    assert L.gpc_dev_memcpy(h, None, q, 8, 2) == capi.GPC_EINVAL
+    assert L.gpc_dev_memcpy(h, None, None, 0, 2) == 0                            # nothing to copy
+    assert L.gpc_dev_free(h, p) == 0 and L.gpc_dev_free(h, q) == 0 and L.gpc_dev_free(h, None) == 0
+    z = C.c_void_p()
+    assert L.gpc_dev_malloc(h, 0, C.byref(z)) == 0 and z.value and L.gpc_dev_free(h, z) == 0
+    # partial fetch of a patch batch: NULL outputs are skipped
+    xyz, rgb = synth.plane_cloud(5000, seed=3)
+    pt = ctx.project_cloud(ctx.make_cloud(xyz, rgb), 0.15, 8)
+    off = np.zeros(pt.view.P + 1, np.int32)
+    W = np.zeros((pt.view.P, 64), np.uint8)
+    assert L.gpc_patches_fetch(pt.h, off.ctypes.data, None, None, None, None, None, None, None, W.ctypes.data, None) == 0
+    full = pt.fetch()
+    assert np.array_equal(off, full["off"]) and np.array_equal(W, full["W"])
+    pt.close()
