@@ -164,6 +164,34 @@ void gpc_ctx_destroy(gpc_ctx* ctx)
 const char* gpc_last_error(const gpc_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 const char* gpc_last_dense_kernel(const gpc_ctx* ctx) { return ctx ? ctx->last_dense_kernel : ""; }
 
+// ------------------------------------------------------------------------------------------------ diagnostics
+
+__global__ __launch_bounds__(256) void gpc_poison_lds_kernel(int words)
+{
+    extern __shared__ unsigned long long lds_words[];
+    for (int i = threadIdx.x; i < words; i += 256) lds_words[i] = 0x7ff8dead0000beefull;      // a quiet NaN
+    __syncthreads();
+    // every workgroup takes a whole CU's LDS: hold it for a moment so that the first wave of workgroups covers all CUs
+    for (int k = 0; k < 64; ++k) __builtin_amdgcn_s_sleep(127);
+    if (lds_words[(threadIdx.x * 17) % words] == 0ull) lds_words[0] = 1ull;                  // keeps the stores alive
+}
+
+int gpc_debug_poison_lds(gpc_ctx* ctx)
+{
+    const bool on = getenv("GPC_POISON_LDS") != nullptr;       // read per call: a test can switch it on for itself
+    if (!on || !ctx) return GPC_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gpc_poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
+        attr_set = true;
+    }
+    const int bytes = 160 * 1024;
+    hipLaunchKernelGGL(gpc_poison_lds_kernel, dim3(ctx->num_cus * 2), dim3(256), bytes, ctx->stream, bytes / 8);
+    GPC_HIP(ctx, hipGetLastError());
+    return GPC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ dense path
 
 static int dense_check(gpc_ctx* ctx, const gpc_params* prm, int P, const void* off, int n_max, int n_total,
@@ -201,6 +229,10 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
     std::lock_guard<std::mutex> lk(ctx->mu);
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     if (!a.prm.want_variance) a.v_star = nullptr;
+    {
+        const int rcp = gpc_debug_poison_lds(ctx);
+        if (rcp != GPC_OK) return rcp;
+    }
     if (dense_mfma_supported(a) && !getenv("GPC_FORCE_GENERIC") && !getenv("GPC_FORCE_BIG")) return dense_mfma_launch(ctx, a);
     if ((dense_big_supported(a) || (getenv("GPC_FORCE_BIG") && a.n_max <= 1024 && !a.v_star)) && !getenv("GPC_FORCE_GENERIC")) {   // GPC_FORCE_BIG: diagnostic
         int grid_b = 0;

@@ -70,6 +70,11 @@ static inline int gpc_ws_reserve(gpc_ctx* ctx, size_t bytes)
     return GPC_OK;
 }
 
+// Diagnostic (GPC_POISON_LDS=1): before every kernel family runs, fill the LDS of every CU with NaN.  LDS keeps what the
+// previous kernel left there, so a read of a word the current kernel never wrote is otherwise a coin toss; with the poison it
+// is a NaN in the output and a failing test.  Enqueued on the context's stream; a no-op unless the variable is set.
+extern "C" int gpc_debug_poison_lds(gpc_ctx* ctx);
+
 // ---- launchers implemented in the kernel translation units -------------------------------------------------
 
 struct DenseArgs {

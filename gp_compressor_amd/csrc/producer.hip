@@ -639,6 +639,7 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
     if (sz < 1 || sz > 1024) return gpc_fail(ctx, GPC_EINVAL, "sz must be in [1, 1024]");
     std::lock_guard<std::mutex> lk(ctx->mu);
     GPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcp = gpc_debug_poison_lds(ctx)) return rcp;
     hipStream_t st = ctx->stream;
     gpc_patches* o = new gpc_patches;
     o->ctx = ctx;

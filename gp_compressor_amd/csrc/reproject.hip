@@ -99,6 +99,7 @@ int gpc_reproject_dev(gpc_ctx* ctx, int P, int m, const int32_t* bv_count, const
     if ((long long)P * (long long)m > 0x7fffffffLL) return gpc_fail(ctx, GPC_ERANGE, "P*m exceeds 2^31-1 points");
     std::lock_guard<std::mutex> lk(ctx->mu);
     GPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcp = gpc_debug_poison_lds(ctx)) return rcp;
     if (P == 0 || m == 0) {
         GPC_HIP(ctx, hipMemsetAsync(n_points, 0, sizeof(int32_t), ctx->stream));
         return GPC_OK;

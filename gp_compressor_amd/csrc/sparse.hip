@@ -1065,6 +1065,7 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     if (g->P == 0) return GPC_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcp = gpc_debug_poison_lds(ctx)) return rcp;
     SpAddParams A;
     A.prm = g->prm;
     A.c_exp = (double)(-0.5f) / g->prm.l_sq;
@@ -1101,6 +1102,7 @@ int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double
     if (g->P == 0 || m == 0) return GPC_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcp = gpc_debug_poison_lds(ctx)) return rcp;
     SpPredParams A;
     A.prm = g->prm;
     A.c_exp = (double)(-0.5f) / g->prm.l_sq;
@@ -1165,6 +1167,7 @@ int gpc_sparse_likelihood_dev(gpc_sparse* g, const int32_t* off, int n_total, co
     if (g->P == 0 || n_total == 0 || (!dX && !l)) return GPC_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcp = gpc_debug_poison_lds(ctx)) return rcp;
     return sp_likelihood_launch(g, off, n_total, x0, x1, y, dX, l, nullptr);
 }
 
@@ -1186,6 +1189,7 @@ int gpc_sparse_train_sigmaf_dev(gpc_sparse* g, const int32_t* off, int n_total, 
     if (g->P == 0) return GPC_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcp = gpc_debug_poison_lds(ctx)) return rcp;
     int rc = gpc_ws_reserve(ctx, sizeof(double) * 3 * (size_t)(n_total > 0 ? n_total : 1));
     if (rc != GPC_OK) return rc;
     double* raw = static_cast<double*>(ctx->ws);

@@ -324,14 +324,16 @@ def test_dense_full_size_properties(gp, oracle, P, n, label):
     _close(fa[sample], fo, FTOL)
 
 
-def test_dense_does_not_read_stale_lds(gp, oracle):
+def test_dense_does_not_read_stale_lds(gp, oracle, monkeypatch):
     """LDS keeps what the previous kernel on the CU left there.  A sparse exact-GP run on duplicated points fills it with
     NaN / Inf; a dense batch whose sizes are not multiples of 32 must not let those leak into its predictive sums (the rows
     between 16 ceil(n / 16) and the next multiple of 32 are never written by the solve; the sums once multiplied them by a
     zero kernel factor instead of skipping them, and a whole patch came out NaN when the sparse tests had run first)."""
     capi, ctx = gp
     res, sz = 0.15, 20
-    # 1. poison: every CU runs sparse patches whose state degenerates to NaN / Inf (capacity -1, each point added twice)
+    # 0. the library's own diagnostic: NaN in every LDS word of every CU before each kernel family (GPC_POISON_LDS)
+    monkeypatch.setenv("GPC_POISON_LDS", "1")
+    # 1. and the sequence that exposed the bug: every CU runs sparse patches whose state degenerates to NaN / Inf (capacity -1, each point added twice)
     Pp = 1024
     off, x0, x1, y = synth.make_patches(Pp, 24, res=res, seed=5)
     g = capi.Sparse(ctx, capi.default_params_sparse(1, sigmaf_sq=1.0, l_sq=(res / 8) ** 2, noise=1e-4, capacity=-1), Pp, 1)
