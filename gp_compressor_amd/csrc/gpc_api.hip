@@ -189,6 +189,8 @@ int gpc_debug_poison_lds(gpc_ctx* ctx)
     const int bytes = 160 * 1024;
     hipLaunchKernelGGL(gpc_poison_lds_kernel, dim3(ctx->num_cus * 2), dim3(256), bytes, ctx->stream, bytes / 8);
     GPC_HIP(ctx, hipGetLastError());
+    // the device workspace is per-call scratch as well: whatever the previous call left in it becomes NaN (all-ones doubles)
+    if (ctx->ws && ctx->ws_bytes) GPC_HIP(ctx, hipMemsetAsync(ctx->ws, 0xFF, ctx->ws_bytes, ctx->stream));
     return GPC_OK;
 }
 

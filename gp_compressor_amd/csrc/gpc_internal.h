@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -66,7 +67,7 @@ static inline int gpc_ws_reserve(gpc_ctx* ctx, size_t bytes)
     // recycled device memory holds arbitrary bit patterns; the kernels write every workspace element before they use it,
     // but their (clamped, unconditional) prefetches may touch elements they never consume: keep those reads free of
     // signalling patterns and the results independent of what ran before
-    GPC_HIP(ctx, hipMemsetAsync(ctx->ws, 0, bytes, ctx->stream));
+    GPC_HIP(ctx, hipMemsetAsync(ctx->ws, getenv("GPC_POISON_LDS") ? 0xFF : 0, bytes, ctx->stream));   // diagnostic runs: NaN instead of zero
     return GPC_OK;
 }
 
