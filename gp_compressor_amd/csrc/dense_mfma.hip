@@ -236,7 +236,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 if (c < ny) {
                     yc[c * MF_NPAD + i] = live ? A.y[(size_t)c * A.n_total + o + i] : 0.0;
                     wsum[c * MF_NPAD + i] = 0.0;
-                    av[c * MF_NPAD + i] = 0.0;          // no stale LDS beyond the rows the solve writes
                 }
             }
         }
