@@ -352,6 +352,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
     double* Qrep = part + 3 * ld;
     double* pnext = part + 8 * ld;                 // the NEXT point's mat-vec partials, formed inside the fused update pass
     double* kvn = pnext + 8 * ld;                  // ... and its k  [ld]
+    double* alphaL = kvn + ld;                     // alpha [ny][ld] and BV [ld][2] of the patch in flight: read and updated at every
+    double* BVL = alphaL + 3 * ld;                 // point, so they live here between the first and the last point of the call
     gpc_exp_table_init(T);
 
     const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, eps_tol = A.prm.eps_tol;
@@ -361,12 +363,20 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
         const int o = A.off[patch], n = A.off[patch + 1] - o;
         SpState S;
         S.ld = ld; S.ny = ny;
-        S.alpha = A.alpha + (size_t)patch * ny * ld;
+        double* const alphag = A.alpha + (size_t)patch * ny * ld;
+        double* const BVg = A.BV + (size_t)patch * ld * 2;
+        S.alpha = alphaL;
         S.C = A.C + (size_t)patch * ld * ld;
         S.Q = A.Q + (size_t)patch * ld * ld;
-        S.BV = A.BV + (size_t)patch * ld * 2;
+        S.BV = BVL;
         int b = A.b[patch];
         int st = A.stat[patch];
+        __syncthreads();
+        for (int i = tid; i < b; i += SP_NTH) {
+            BVL[2 * i] = BVg[2 * i];
+            BVL[2 * i + 1] = BVg[2 * i + 1];
+            for (int c = 0; c < ny; ++c) alphaL[c * ld + i] = alphag[c * ld + i];
+        }
         __syncthreads();
 
         bool have_next = false;                      // k and the mat-vec partials of this iteration's point were formed by the previous one
@@ -586,6 +596,12 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 const double c00 = S.C[0];
                 if (c00 != c00 && st == GPC_STATUS_OK) st = GPC_STATUS_NAN;
             }
+        }
+        __syncthreads();
+        for (int i = tid; i < b; i += SP_NTH) {
+            BVg[2 * i] = BVL[2 * i];
+            BVg[2 * i + 1] = BVL[2 * i + 1];
+            for (int c = 0; c < ny; ++c) alphag[c * ld + i] = alphaL[c * ld + i];
         }
         if (tid == 0) {
             A.b[patch] = b;
@@ -975,7 +991,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_train_kernel(SpTrainParams 
 
 // ------------------------------------------------------------------------------------------------ host side
 
-static size_t sp_add_lds(int ld) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (ld + 1) + 8 * ld + 9 * ld); }
+static size_t sp_add_lds(int ld) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (ld + 1) + 8 * ld + 9 * ld + 5 * ld); }
 static size_t sp_lik_lds(int ld, bool fast)
 {
     return sizeof(double) * (size_t)(64 + 5 * ld + SP_NQ * 8 * SP_PC + (size_t)ld * SP_PC * (fast ? 2 : 1));
