@@ -27,11 +27,13 @@ struct gpc_sparse {
     int P, ny, ld;
     double *alpha, *C, *Q, *BV;
     int32_t *b, *count, *stat;
+    int32_t* done_it;   // P: hand-over between the small-basis phase and the regular add kernel (allocated with the object)
 };
 
 struct SpState {
     double *alpha, *C, *Q, *BV;   // this patch
-    int ld, ny;
+    int ld, ny;                   // ld: stride of the alpha planes (and of the LDS vectors that go with them)
+    int ldm;                      // stride of C and Q (== ld in HBM; SP_BMAX when the small-basis kernel keeps them in LDS)
 };
 
 // The add kernel and its helpers run with 256 threads per patch, or with 64 (one wave per patch) when capacity <= 64 lets a
@@ -125,7 +127,7 @@ __device__ static inline void sp_rmw_cq(double* C, double* Q, int ld, int nb, F 
 #define SP_RMW_NEXT 8
 #endif
 template <bool WRITE_Q = true, class F>
-__device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int nb, const double* kvn, double* pnext, F f)
+__device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int lv, int nb, const double* kvn, double* pnext, F f)
 {
     const int lane = threadIdx.x & 63;
     for (int quarter = threadIdx.x >> 6; quarter < 4; quarter += SP_NTH >> 6) {     // one quarter per wave, or all four in turn
@@ -153,8 +155,8 @@ __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int n
                 }
             }
         }
-        pnext[(quarter * 2 + 0) * ld + i] = ac;
-        pnext[(quarter * 2 + 1) * ld + i] = aq;
+        pnext[(quarter * 2 + 0) * lv + i] = ac;
+        pnext[(quarter * 2 + 1) * lv + i] = aq;
     }
     }
 }
@@ -163,16 +165,16 @@ __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int n
 __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_bug, double* Cstar, double* Qstar,
                                    double* Crep, double* Qrep)
 {
-    const int tid = threadIdx.x, ld = S.ld, last = b - 1, ny = S.ny;
+    const int tid = threadIdx.x, ld = S.ld, ldm = S.ldm, last = b - 1, ny = S.ny;
     double alphastar[3];
     for (int c = 0; c < ny; ++c) alphastar[c] = S.alpha[c * ld + loc];
-    const double cstar = S.C[loc + (size_t)loc * ld];
-    const double qstar = S.Q[loc + (size_t)loc * ld];
+    const double cstar = S.C[loc + (size_t)loc * ldm];
+    const double qstar = S.Q[loc + (size_t)loc * ldm];
     for (int i = tid; i < b; i += SP_NTH) {
-        Cstar[i] = S.C[i + (size_t)loc * ld];
-        Qstar[i] = S.Q[i + (size_t)loc * ld];
-        Crep[i] = S.C[i + (size_t)last * ld];
-        Qrep[i] = S.Q[i + (size_t)last * ld];
+        Cstar[i] = S.C[i + (size_t)loc * ldm];
+        Qstar[i] = S.Q[i + (size_t)loc * ldm];
+        Crep[i] = S.C[i + (size_t)last * ldm];
+        Qrep[i] = S.Q[i + (size_t)last * ldm];
     }
     __syncthreads();
     if (tid == 0) {
@@ -184,10 +186,10 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
     __syncthreads();
     for (int i = tid; i < b; i += SP_NTH) {
         const double cr = Crep[i], qr = Qrep[i];
-        S.C[loc + (size_t)i * ld] = cr;   // C.row(loc) = Crep^T
-        S.C[i + (size_t)loc * ld] = cr;   // C.col(loc) = Crep
-        S.Q[loc + (size_t)i * ld] = qr;
-        S.Q[i + (size_t)loc * ld] = qr;
+        S.C[loc + (size_t)i * ldm] = cr;   // C.row(loc) = Crep^T
+        S.C[i + (size_t)loc * ldm] = cr;   // C.col(loc) = Crep
+        S.Q[loc + (size_t)i * ldm] = qr;
+        S.Q[i + (size_t)loc * ldm] = qr;
     }
     if (tid < ny) S.alpha[tid * ld + loc] = S.alpha[tid * ld + last];     // alpha(loc) = alpha(last)  (:257)
     if (tid == 32) {
@@ -206,7 +208,7 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
         }
     }
     // C += Qs Qs^T / qstar - (Qs+Cs)(Qs+Cs)^T / (qstar+cstar);  Q -= Qs Qs^T / qstar   (:286-288)
-    sp_rmw_cq(S.C, S.Q, ld, nb, [&](int i, int j, double& c, double& q) {
+    sp_rmw_cq(S.C, S.Q, ldm, nb, [&](int i, int j, double& c, double& q) {
         const double qq = (Qstar[i] * Qstar[j]) / qstar;
         const double cc = ((Qstar[i] + Cstar[i]) * (Qstar[j] + Cstar[j])) / qc_den;
         c += qq - cc;
@@ -230,7 +232,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
                                             double* Crep, double* Qrep, double* anew, double* sval, int* sidx,
                                             const double* nxt, double* kvn, double* pnext, double sf, double c_exp, const double* T)
 {
-    const int tid = threadIdx.x, ld = S.ld, ny = S.ny, last = b;
+    const int tid = threadIdx.x, ld = S.ld, ldm = S.ldm, ny = S.ny, last = b;
     const double ig = (double)1.0f / gamma;
     for (int i = tid; i <= b; i += SP_NTH) {
         const double si = (i < b) ? ck[i] : (double)1.0f;
@@ -249,7 +251,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
     for (int i = tid; i <= b; i += SP_NTH) {
         double a2 = 0.0;
         for (int c = 0; c < ny; ++c) { const double a = anew[c * ld + i]; a2 += a * a; }
-        const double c0 = (i < b) ? S.C[i + (size_t)i * ld] : 0.0, q0 = (i < b) ? S.Q[i + (size_t)i * ld] : 0.0;
+        const double c0 = (i < b) ? S.C[i + (size_t)i * ldm] : 0.0, q0 = (i < b) ? S.Q[i + (size_t)i * ldm] : 0.0;
         const double cd = c0 + (rr * sv[i]) * sv[i], qd = q0 + (ig * eh[i]) * eh[i];
         const double score = a2 / (qd + cd);
         if (!have || score < best) { best = score; loc = i; have = true; }
@@ -260,7 +262,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
     // columns loc and last of the updated matrices (delete_bv :259-278)
     for (int i = tid; i <= b; i += SP_NTH) {
         const bool old = (i < b) && (loc < b);
-        const double c0 = old ? S.C[i + (size_t)loc * ld] : 0.0, q0 = old ? S.Q[i + (size_t)loc * ld] : 0.0;
+        const double c0 = old ? S.C[i + (size_t)loc * ldm] : 0.0, q0 = old ? S.Q[i + (size_t)loc * ldm] : 0.0;
         Cstar[i] = c0 + (rr * sv[i]) * sv[loc];
         Qstar[i] = q0 + (ig * eh[i]) * eh[loc];
         Crep[i] = 0.0 + (rr * sv[i]) * sv[b];
@@ -312,9 +314,9 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
         const double n0 = nxt[0], n1 = nxt[1];
         for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
         __syncthreads();
-        sp_rmw_cq_next(S.C, S.Q, ld, nb, kvn, pnext, element);
+        sp_rmw_cq_next(S.C, S.Q, ldm, ld, nb, kvn, pnext, element);
     } else {
-        sp_rmw_cq(S.C, S.Q, ld, nb, element);
+        sp_rmw_cq(S.C, S.Q, ldm, nb, element);
     }
     __syncthreads();
     return nb;
@@ -330,13 +332,26 @@ struct SpAddParams {
     double *alpha, *C, *Q, *BV;
     int32_t *b, *count, *stat, *status_out;
     int fuse_next;   // 1: full-update passes also form the next point's mat-vecs (0 only through GPC_SPARSE_NO_FUSE, for the tests)
+    const int32_t* start_it;   // per patch: points of this call already consumed by the small-basis kernel (nullptr: 0)
+    int32_t* done_it;          // small-basis kernel only: how many points of this call it consumed
 };
 
+// Small-basis phase.  With the reference's default hyper-parameters the basis stays at a dozen vectors whatever the capacity,
+// and a point is a handful of short loops whose cost is the latency of C and Q in L2 / HBM.  sparse_add_kernel<true> runs one
+// wave per patch with C and Q (up to SP_BMAX x SP_BMAX) resident in LDS, and hands a patch over -- state written back, the
+// number of points consumed recorded in done_it -- at the first point that would grow its basis beyond SP_BMAX; the regular
+// kernel then continues from there (start_it).  Same operations in the same order: the two-phase run leaves the states of
+// a one-phase run, bit for bit.
+#define SP_BMAX 32
+
+template <bool SMALL>
 __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A)   // <= 256 VGPRs: at least two workgroups per CU
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ld = A.ld, ny = A.ny;
+    const int ldg = A.ld, ny = A.ny;               // ldg: strides of the state in global memory
+    const int ld = SMALL ? SP_BMAX + 1 : ldg;      // stride of the LDS vectors (and of alpha / BV while they live in LDS)
+    const int ldm = SMALL ? SP_BMAX : ldg;         // stride of C and Q where the update loops see them
     double* T = reinterpret_cast<double*>(smem);   // 64
     double* red = T + 64;                          // 16
     double* sval = red + 16;                       // 4
@@ -354,6 +369,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
     double* kvn = pnext + 8 * ld;                  // ... and its k  [ld]
     double* alphaL = kvn + ld;                     // alpha [ny][ld] and BV [ld][2] of the patch in flight: read and updated at every
     double* BVL = alphaL + 3 * ld;                 // point, so they live here between the first and the last point of the call
+    double* Cl = BVL + 2 * ld;                     // SMALL: C, Q [SP_BMAX][SP_BMAX]
+    double* Ql = Cl + SP_BMAX * SP_BMAX;
     gpc_exp_table_init(T);
 
     const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, eps_tol = A.prm.eps_tol;
@@ -362,25 +379,41 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
     for (int patch = blockIdx.x; patch < A.P; patch += gridDim.x) {
         const int o = A.off[patch], n = A.off[patch + 1] - o;
         SpState S;
-        S.ld = ld; S.ny = ny;
-        double* const alphag = A.alpha + (size_t)patch * ny * ld;
-        double* const BVg = A.BV + (size_t)patch * ld * 2;
+        S.ld = ld; S.ny = ny; S.ldm = ldm;
+        double* const alphag = A.alpha + (size_t)patch * ny * ldg;
+        double* const BVg = A.BV + (size_t)patch * ldg * 2;
+        double* const Cg = A.C + (size_t)patch * ldg * ldg;
+        double* const Qg = A.Q + (size_t)patch * ldg * ldg;
         S.alpha = alphaL;
-        S.C = A.C + (size_t)patch * ld * ld;
-        S.Q = A.Q + (size_t)patch * ld * ld;
+        S.C = SMALL ? Cl : Cg;
+        S.Q = SMALL ? Ql : Qg;
         S.BV = BVL;
         int b = A.b[patch];
         int st = A.stat[patch];
+        const int it0 = (!SMALL && A.start_it) ? A.start_it[patch] : 0;     // the small-basis phase already took these
         __syncthreads();
+        if (SMALL && (b > SP_BMAX || n == 0)) {          // too large from the start (or nothing to do): all of it is the regular kernel's
+            if (tid == 0) A.done_it[patch] = 0;
+            continue;
+        }
+        if (!SMALL && A.start_it && n > 0 && it0 >= n) continue;  // the small-basis phase finished this patch (and wrote its state and status)
         for (int i = tid; i < b; i += SP_NTH) {
             BVL[2 * i] = BVg[2 * i];
             BVL[2 * i + 1] = BVg[2 * i + 1];
-            for (int c = 0; c < ny; ++c) alphaL[c * ld + i] = alphag[c * ld + i];
+            for (int c = 0; c < ny; ++c) alphaL[c * ld + i] = alphag[c * ldg + i];
         }
+        if (SMALL) {
+            for (int e = tid; e < b * b; e += SP_NTH) {
+                const int i = e % b, j = e / b;
+                Cl[i + j * SP_BMAX] = Cg[i + (size_t)j * ldg];
+                Ql[i + j * SP_BMAX] = Qg[i + (size_t)j * ldg];
+            }
+        }
+        int it_end = n;                                  // SMALL: where this phase stopped
         __syncthreads();
 
         bool have_next = false;                      // k and the mat-vec partials of this iteration's point were formed by the previous one
-        for (int it = 0; it < n; ++it) {
+        for (int it = it0; it < n; ++it) {
             const int r = A.perm ? A.perm[o + it] : it;
             const double px0 = A.x0[o + r], px1 = A.x1[o + r];
             double yv[3];
@@ -420,8 +453,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                         double ac = 0.0, aq = 0.0;
                         for (int j = jlo; j < jhi; ++j) {
                             const double kj = kv[j];
-                            ac += S.C[i + (size_t)j * ld] * kj;
-                            aq += S.Q[i + (size_t)j * ld] * kj;
+                            ac += S.C[i + (size_t)j * ldm] * kj;
+                            aq += S.Q[i + (size_t)j * ldm] * kj;
                         }
                         part[(quarter * 2 + 0) * ld + i] = ac;
                         part[(quarter * 2 + 1) * ld + i] = aq;
@@ -480,7 +513,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                     const double n0 = A.x0[o + rn], n1 = A.x1[o + rn];
                     for (int i = tid; i < b; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
-                    sp_rmw_cq_next<false>(S.C, S.Q, ld, b, kvn, pnext, [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; });
+                    sp_rmw_cq_next<false>(S.C, S.Q, ldm, ld, b, kvn, pnext, [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; });
                     have_next = true;
                 } else {
                     const int nn = b * b;
@@ -492,15 +525,18 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                             const int e = e0 + u * SP_NTH, ec = e < nn ? e : e0;
                             ii[u] = ec % b;
                             jj[u] = ec / b;
-                            cv[u] = S.C[ii[u] + (size_t)jj[u] * ld];
+                            cv[u] = S.C[ii[u] + (size_t)jj[u] * ldm];
                         }
 #pragma unroll
                         for (int u = 0; u < SP_RMW; ++u)
-                            if (e0 + u * SP_NTH < nn) S.C[ii[u] + (size_t)jj[u] * ld] = cv[u] + (re * sv[ii[u]]) * sv[jj[u]];
+                            if (e0 + u * SP_NTH < nn) S.C[ii[u] + (size_t)jj[u] * ldm] = cv[u] + (re * sv[ii[u]]) * sv[jj[u]];
                     }
                 }
                 __syncthreads();
-            } else if (b >= ld) {
+            } else if (SMALL && b + 1 > SP_BMAX && !(capacity > 0 && capacity <= SP_BMAX)) {
+                it_end = it;                                // this point would grow the basis beyond the resident block: nothing of it
+                break;                                      // has been applied yet -- the regular kernel redoes it from the state as it is
+            } else if (b >= ldg) {
                 st = GPC_STATUS_OVERFLOW;                   // capacity == -1 and GPC_MAX_BV reached: skip the point
             } else if (capacity > 0 && b + 1 > capacity) {
                 // full update + the capacity deletion it forces, in one pass over C and Q
@@ -543,10 +579,10 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                     const double n0 = A.x0[o + rn], n1 = A.x1[o + rn];
                     for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
-                    sp_rmw_cq_next(S.C, S.Q, ld, nb, kvn, pnext, grow);
+                    sp_rmw_cq_next(S.C, S.Q, ldm, ld, nb, kvn, pnext, grow);
                     have_next = true;
                 } else {
-                    sp_rmw_cq(S.C, S.Q, ld, nb, grow);
+                    sp_rmw_cq(S.C, S.Q, ldm, nb, grow);
                 }
                 b = nb;
                 __syncthreads();
@@ -560,7 +596,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 for (int i = tid; i < b; i += SP_NTH) {
                     double a2 = 0.0;
                     for (int c = 0; c < ny; ++c) { const double a = S.alpha[c * ld + i]; a2 += a * a; }
-                    const double score = a2 / (S.Q[i + (size_t)i * ld] + S.C[i + (size_t)i * ld]);
+                    const double score = a2 / (S.Q[i + (size_t)i * ldm] + S.C[i + (size_t)i * ldm]);
                     if (!have || score < best) { best = score; loc = i; have = true; }
                 }
                 if (!have) best = __builtin_inf();
@@ -577,7 +613,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                     int loc = 0x7fffffff;
                     bool have = false;
                     for (int i = tid; i < b; i += SP_NTH) {
-                        const double score = (double)1.0f / S.Q[i + (size_t)i * ld];
+                        const double score = (double)1.0f / S.Q[i + (size_t)i * ldm];
                         if (!have || score < best) { best = score; loc = i; have = true; }
                     }
                     if (!have) best = __builtin_inf();
@@ -601,11 +637,19 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
         for (int i = tid; i < b; i += SP_NTH) {
             BVg[2 * i] = BVL[2 * i];
             BVg[2 * i + 1] = BVL[2 * i + 1];
-            for (int c = 0; c < ny; ++c) alphag[c * ld + i] = alphaL[c * ld + i];
+            for (int c = 0; c < ny; ++c) alphag[c * ldg + i] = alphaL[c * ld + i];
+        }
+        if (SMALL) {
+            for (int e = tid; e < b * b; e += SP_NTH) {
+                const int i = e % b, j = e / b;
+                Cg[i + (size_t)j * ldg] = Cl[i + j * SP_BMAX];
+                Qg[i + (size_t)j * ldg] = Ql[i + j * SP_BMAX];
+            }
+            if (tid == 0) A.done_it[patch] = it_end;
         }
         if (tid == 0) {
             A.b[patch] = b;
-            A.count[patch] += n;
+            A.count[patch] += (SMALL ? it_end : n) - it0;
             A.stat[patch] = st;
             if (A.status_out) A.status_out[patch] = st;
         }
@@ -991,6 +1035,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_train_kernel(SpTrainParams 
 
 // ------------------------------------------------------------------------------------------------ host side
 
+static size_t sp_add_lds_small() { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (SP_BMAX + 2) + 22 * (SP_BMAX + 1) + 2 * SP_BMAX * SP_BMAX); }
 static size_t sp_add_lds(int ld) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (ld + 1) + 8 * ld + 9 * ld + 5 * ld); }
 static size_t sp_lik_lds(int ld, bool fast)
 {
@@ -1021,6 +1066,7 @@ int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc
     g->ld = params->capacity == -1 ? GPC_MAX_BV : params->capacity + 1;
     g->alpha = g->C = g->Q = g->BV = nullptr;
     g->b = g->count = g->stat = nullptr;
+    g->done_it = nullptr;
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t ld = (size_t)g->ld, Pn = (size_t)(P > 0 ? P : 1);
     hipError_t e = hipSetDevice(ctx->device);
@@ -1031,12 +1077,13 @@ int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc
     if (e == hipSuccess) e = hipMalloc(&g->b, 4 * Pn);
     if (e == hipSuccess) e = hipMalloc(&g->count, 4 * Pn);
     if (e == hipSuccess) e = hipMalloc(&g->stat, 4 * Pn);
+    if (e == hipSuccess) e = hipMalloc(&g->done_it, 4 * Pn);
     if (e == hipSuccess) e = hipMemsetAsync(g->b, 0, 4 * Pn, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(g->count, 0, 4 * Pn, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(g->stat, 0, 4 * Pn, ctx->stream);
     if (e != hipSuccess) {
         int rc = gpc_fail(ctx, e == hipErrorOutOfMemory ? GPC_ENOMEM : GPC_EHIP, "gpc_sparse_create: %s", hipGetErrorString(e));
-        for (void* p : {(void*)g->alpha, (void*)g->C, (void*)g->Q, (void*)g->BV, (void*)g->b, (void*)g->count, (void*)g->stat})
+        for (void* p : {(void*)g->alpha, (void*)g->C, (void*)g->Q, (void*)g->BV, (void*)g->b, (void*)g->count, (void*)g->stat, (void*)g->done_it})
             if (p) (void)hipFree(p);
         delete g;
         return rc;
@@ -1050,7 +1097,7 @@ void gpc_sparse_destroy(gpc_sparse* g)
     if (!g) return;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
-    for (void* p : {(void*)g->alpha, (void*)g->C, (void*)g->Q, (void*)g->BV, (void*)g->b, (void*)g->count, (void*)g->stat})
+    for (void* p : {(void*)g->alpha, (void*)g->C, (void*)g->Q, (void*)g->BV, (void*)g->b, (void*)g->count, (void*)g->stat, (void*)g->done_it})
         if (p) (void)hipFree(p);
     delete g;
 }
@@ -1103,7 +1150,20 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     per_cu = per_cu > per_cu_max ? per_cu_max : (per_cu < 1 ? 1 : per_cu);
     if (const char* e = getenv("GPC_SPARSE_PER_CU")) per_cu = std::max(1, atoi(e));   // diagnostic: resident-state experiments
     int grid = std::min(g->P, ctx->num_cus * per_cu);
-    hipLaunchKernelGGL(sparse_add_kernel, dim3(grid), dim3(nth), lds, ctx->stream, A);
+    A.start_it = nullptr;
+    A.done_it = nullptr;
+    if (!getenv("GPC_SPARSE_NO_SMALL")) {
+        // small-basis phase first: one wave per patch, C and Q in LDS, until a patch outgrows SP_BMAX basis vectors
+        const size_t lds_s = sp_add_lds_small();
+        int per_cu_s = (int)((160u * 1024u) / lds_s);
+        per_cu_s = per_cu_s > 8 ? 8 : per_cu_s;
+        A.done_it = g->done_it;
+        hipLaunchKernelGGL(sparse_add_kernel<true>, dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
+        GPC_HIP(ctx, hipGetLastError());
+        A.start_it = g->done_it;
+        A.done_it = nullptr;
+    }
+    hipLaunchKernelGGL(sparse_add_kernel<false>, dim3(grid), dim3(nth), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;
 }

@@ -471,3 +471,51 @@ def test_sparse_one_wave_per_patch_is_bit_identical(gp, ny, cap, kernel, monkeyp
         assert np.array_equal(C0[i][:nb, :nb], C1[i][:nb, :nb], equal_nan=True)
         assert np.array_equal(Q0[i][:nb, :nb], Q1[i][:nb, :nb], equal_nan=True)
         assert np.array_equal(BV0[i][:nb], BV1[i][:nb], equal_nan=True)
+
+
+@pytest.mark.parametrize("ny,cap,kernel", [(1, 100, "default"), (3, 100, "default"), (1, 100, "fill"), (3, 60, "fill"), (1, 20, "fill"), (1, 32, "fill"),
+                                            (1, 200, "fill"), (1, 80, "mixed"), (3, 40, "mixed"), (1, 33, "geo"), (1, -1, "fill"), (1, 255, "default")])
+def test_sparse_small_basis_phase_is_bit_identical(gp, ny, cap, kernel, monkeypatch):
+    """The add runs in two phases: a small-basis kernel (one wave per patch, C and Q resident in LDS) takes every patch as far as
+    32 basis vectors, the regular kernel continues from the point where a patch outgrew it.  Same operations in the same order:
+    with and without the first phase (GPC_SPARSE_NO_SMALL) the states, the basis sizes, the per-patch status and the point
+    counts are identical -- patches that stay small, patches that cross over in the middle of a call, online growth over
+    several calls, empty patches, capacities below and above the block size."""
+    capi, ctx = gp
+    res, P, n = 0.15, 29, 180
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=11 + cap, ragged=True, ny=ny)
+    # an empty patch in the middle
+    cnt = np.diff(off)
+    keep = np.ones(off[-1], bool)
+    keep[off[7]:off[8]] = False
+    cnt[7] = 0
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    x0, x1, y = x0[keep], x1[keep], y[:, keep]
+    perm = synth.sattolo_perms(off, seed=4)
+    kw = dict(capacity=cap)
+    if kernel == "fill":
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 8) ** 2, noise=1e-4 if ny == 1 else 1.0)
+    if kernel == "geo":
+        kw.update(sigmaf_sq=1.0, l_sq=(res * 2) ** 2, noise=1e-6, eps_tol=1e-14)
+    if kernel == "mixed":
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 3) ** 2, noise=1e-3 if ny == 1 else 1.0, eps_tol=1e-3)
+    p = capi.default_params_sparse(ny, **kw)
+    results = []
+    for one_phase in (False, True):
+        if one_phase:
+            monkeypatch.setenv("GPC_SPARSE_NO_SMALL", "1")
+        g = capi.Sparse(ctx, p, P, ny)
+        st1 = g.add(off, x0, x1, y, perm)
+        st2 = g.add(off, x0, x1, y)                  # online growth: the second call starts from trained states
+        results.append((st1, st2, g.sizes(), *g.state()))
+        g.close()
+    a, b_ = results
+    assert np.array_equal(a[0], b_[0]) and np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2])
+    assert a[2][7] == 0 and a[0][7] == 0
+    for i in range(P):
+        nb = int(a[2][i])
+        (al0, C0, Q0, BV0), (al1, C1, Q1, BV1) = a[3:], b_[3:]
+        assert np.array_equal(al0[i][:, :nb], al1[i][:, :nb], equal_nan=True)
+        assert np.array_equal(C0[i][:nb, :nb], C1[i][:nb, :nb], equal_nan=True)
+        assert np.array_equal(Q0[i][:nb, :nb], Q1[i][:nb, :nb], equal_nan=True)
+        assert np.array_equal(BV0[i][:nb], BV1[i][:nb], equal_nan=True)
