@@ -413,11 +413,30 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
         __syncthreads();
 
         bool have_next = false;                      // k and the mat-vec partials of this iteration's point were formed by the previous one
-        for (int it = it0; it < n; ++it) {
-            const int r = A.perm ? A.perm[o + it] : it;
-            const double px0 = A.x0[o + r], px1 = A.x1[o + r];
-            double yv[3];
-            for (int c = 0; c < ny; ++c) yv[c] = A.y[(size_t)c * A.n_total + o + r];
+        // The coordinates and targets of a point sit behind two dependent global loads (insertion order, then the point): they
+        // are fetched one point ahead, and the index two ahead, so that nothing of a point waits on them (in the small-basis
+        // regime those round trips were a quarter of a point).
+        double cx0 = 0.0, cx1 = 0.0, cy[3] = {0.0, 0.0, 0.0};       // the current point
+        int r_nxt = 0;                                                // row of point it + 1
+        if (it0 < n) {
+            const int r0 = A.perm ? A.perm[o + it0] : it0;
+            cx0 = A.x0[o + r0];
+            cx1 = A.x1[o + r0];
+            for (int c = 0; c < ny; ++c) cy[c] = A.y[(size_t)c * A.n_total + o + r0];
+            if (it0 + 1 < n) r_nxt = A.perm ? A.perm[o + it0 + 1] : it0 + 1;
+        }
+        double nx0 = 0.0, nx1 = 0.0, nyv[3] = {0.0, 0.0, 0.0};      // point it + 1, in flight
+        int r_nxt2 = 0;
+        for (int it = it0; it < n; ++it, cx0 = nx0, cx1 = nx1, cy[0] = nyv[0], cy[1] = nyv[1], cy[2] = nyv[2], r_nxt = r_nxt2) {
+            const double px0 = cx0, px1 = cx1;
+            double yv[3] = {cy[0], cy[1], cy[2]};
+            const bool more_pts = it + 1 < n;
+            if (more_pts) {
+                nx0 = A.x0[o + r_nxt];
+                nx1 = A.x1[o + r_nxt];
+                for (int c = 0; c < ny; ++c) nyv[c] = A.y[(size_t)c * A.n_total + o + r_nxt];
+                if (it + 2 < n) r_nxt2 = A.perm ? A.perm[o + it + 2] : it + 2;
+            }
             const double kstar = sf;   // kernel_function(X, X) = p(0)*exp(0)  (:98)
 
             const bool from_prev = have_next;
@@ -509,8 +528,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 const double re = rr * eta;
                 if (A.fuse_next && it + 1 < n) {
                     // the basis does not change: the next point's k against it, and its mat-vecs out of this pass (Q is only read)
-                    const int rn = A.perm ? A.perm[o + it + 1] : it + 1;
-                    const double n0 = A.x0[o + rn], n1 = A.x1[o + rn];
+                    const double n0 = nx0, n1 = nx1;
                     for (int i = tid; i < b; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
                     sp_rmw_cq_next<false>(S.C, S.Q, ldm, ld, b, kvn, pnext, [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; });
@@ -543,9 +561,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 double nx[2] = {0.0, 0.0};
                 const bool more = A.fuse_next && it + 1 < n;
                 if (more) {
-                    const int rn = A.perm ? A.perm[o + it + 1] : it + 1;
-                    nx[0] = A.x0[o + rn];
-                    nx[1] = A.x1[o + rn];
+                    nx[0] = nx0;
+                    nx[1] = nx1;
                 }
                 b = sp_full_update_delete(S, b, rr, gamma, qv, px0, px1, A.prm.ref_field_delete_bug, ck, eh, sv, Cstar, Qstar, Crep,
                                           Qrep, part + 4 * ld, sval, sidx, more ? nx : nullptr, kvn, pnext, sf, A.c_exp, T);
@@ -575,8 +592,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 };
                 if (A.fuse_next && it + 1 < n) {
                     // the next point's k against the grown basis, and its mat-vecs out of this pass
-                    const int rn = A.perm ? A.perm[o + it + 1] : it + 1;
-                    const double n0 = A.x0[o + rn], n1 = A.x1[o + rn];
+                    const double n0 = nx0, n1 = nx1;
                     for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
                     sp_rmw_cq_next(S.C, S.Q, ldm, ld, nb, kvn, pnext, grow);
