@@ -91,15 +91,15 @@ __device__ static inline void sp_block_argmin(double& val, int& idx, double* sva
 // flight per thread (the update was 50-60 % of the time of a point).  f(i, j, c, q) updates the two values in place; the
 // element order does not matter (they are independent).
 #define SP_RMW 8
-template <class F>
+template <int RB = SP_RMW, class F>
 __device__ static inline void sp_rmw_cq(double* C, double* Q, int ld, int nb, F f)
 {
     const int nn = nb * nb;
-    for (int e0 = threadIdx.x; e0 < nn; e0 += SP_NTH * SP_RMW) {
-        double c[SP_RMW], q[SP_RMW];
-        int ii[SP_RMW], jj[SP_RMW];
+    for (int e0 = threadIdx.x; e0 < nn; e0 += SP_NTH * RB) {
+        double c[RB], q[RB];
+        int ii[RB], jj[RB];
 #pragma unroll
-        for (int u = 0; u < SP_RMW; ++u) {
+        for (int u = 0; u < RB; ++u) {
             const int e = e0 + u * SP_NTH;
             const int ec = e < nn ? e : e0;                      // clamped: the load is unconditional
             ii[u] = ec % nb;
@@ -108,7 +108,7 @@ __device__ static inline void sp_rmw_cq(double* C, double* Q, int ld, int nb, F 
             q[u] = Q[ii[u] + (size_t)jj[u] * ld];
         }
 #pragma unroll
-        for (int u = 0; u < SP_RMW; ++u) {
+        for (int u = 0; u < RB; ++u) {
             if (e0 + u * SP_NTH < nn) {
                 f(ii[u], jj[u], c[u], q[u]);
                 C[ii[u] + (size_t)jj[u] * ld] = c[u];
@@ -126,7 +126,7 @@ __device__ static inline void sp_rmw_cq(double* C, double* Q, int ld, int nb, F 
 #ifndef SP_RMW_NEXT
 #define SP_RMW_NEXT 8
 #endif
-template <bool WRITE_Q = true, class F>
+template <bool WRITE_Q = true, int RB = SP_RMW_NEXT, class F>
 __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int lv, int nb, const double* kvn, double* pnext, F f)
 {
     const int lane = threadIdx.x & 63;
@@ -134,16 +134,16 @@ __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int l
     const int jlo = (nb * quarter) >> 2, jhi = (nb * (quarter + 1)) >> 2;
     for (int i = lane; i < nb; i += 64) {
         double ac = 0.0, aq = 0.0;
-        for (int j0 = jlo; j0 < jhi; j0 += SP_RMW_NEXT) {
-            double c[SP_RMW_NEXT], q[SP_RMW_NEXT];
+        for (int j0 = jlo; j0 < jhi; j0 += RB) {
+            double c[RB], q[RB];
 #pragma unroll
-            for (int u = 0; u < SP_RMW_NEXT; ++u) {
+            for (int u = 0; u < RB; ++u) {
                 const int j = (j0 + u < jhi) ? j0 + u : jhi - 1;      // clamped: the loads are unconditional and come first
                 c[u] = C[i + (size_t)j * ld];
                 q[u] = Q[i + (size_t)j * ld];
             }
 #pragma unroll
-            for (int u = 0; u < SP_RMW_NEXT; ++u) {
+            for (int u = 0; u < RB; ++u) {
                 const int j = j0 + u;
                 if (j < jhi) {
                     f(i, j, c[u], q[u]);
@@ -162,6 +162,7 @@ __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int l
 }
 
 // delete_bv(loc): sparse_gp.hpp:252-295 / sparse_gp_field.hpp:219-263.  b is workgroup-uniform; returns b-1.
+template <int RB>
 __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_bug, double* Cstar, double* Qstar,
                                    double* Crep, double* Qrep)
 {
@@ -208,7 +209,7 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
         }
     }
     // C += Qs Qs^T / qstar - (Qs+Cs)(Qs+Cs)^T / (qstar+cstar);  Q -= Qs Qs^T / qstar   (:286-288)
-    sp_rmw_cq(S.C, S.Q, ldm, nb, [&](int i, int j, double& c, double& q) {
+    sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, [&](int i, int j, double& c, double& q) {
         const double qq = (Qstar[i] * Qstar[j]) / qstar;
         const double cc = ((Qstar[i] + Cstar[i]) * (Qstar[j] + Cstar[j])) / qc_den;
         c += qq - cc;
@@ -227,6 +228,7 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
 // in the same order as the two-pass form, so the result is the same to the last bit; only the intermediate (b+1) x (b+1)
 // matrices never reach memory.  b == capacity on entry and on return.
 // When the coordinates of the NEXT point are known (nxt != nullptr) the pass also forms that point's mat-vecs (sp_rmw_cq_next).
+template <int RB>
 __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, double gamma, const double* qv, double px0, double px1,
                                             int field_bug, const double* ck, double* eh, double* sv, double* Cstar, double* Qstar,
                                             double* Crep, double* Qrep, double* anew, double* sval, int* sidx,
@@ -314,9 +316,9 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
         const double n0 = nxt[0], n1 = nxt[1];
         for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
         __syncthreads();
-        sp_rmw_cq_next(S.C, S.Q, ldm, ld, nb, kvn, pnext, element);
+        sp_rmw_cq_next<true, RB>(S.C, S.Q, ldm, ld, nb, kvn, pnext, element);
     } else {
-        sp_rmw_cq(S.C, S.Q, ldm, nb, element);
+        sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, element);
     }
     __syncthreads();
     return nb;
@@ -342,16 +344,17 @@ struct SpAddParams {
 // number of points consumed recorded in done_it -- at the first point that would grow its basis beyond SP_BMAX; the regular
 // kernel then continues from there (start_it).  Same operations in the same order: the two-phase run leaves the states of
 // a one-phase run, bit for bit.
-#define SP_BMAX 32
+#define SP_BMAX 24
 
 template <bool SMALL>
-__global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A)   // <= 256 VGPRs: at least two workgroups per CU
+__global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse_add_kernel(SpAddParams A)   // <= 256 VGPRs (128 for the small-basis phase)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ldg = A.ld, ny = A.ny;               // ldg: strides of the state in global memory
     const int ld = SMALL ? SP_BMAX + 1 : ldg;      // stride of the LDS vectors (and of alpha / BV while they live in LDS)
     const int ldm = SMALL ? SP_BMAX : ldg;         // stride of C and Q where the update loops see them
+    constexpr int RB = SMALL ? 2 : SP_RMW;         // elements per thread and trip of the update passes (LDS needs no deep batches)
     double* T = reinterpret_cast<double*>(smem);   // 64
     double* red = T + 64;                          // 16
     double* sval = red + 16;                       // 4
@@ -531,22 +534,22 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                     const double n0 = nx0, n1 = nx1;
                     for (int i = tid; i < b; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
-                    sp_rmw_cq_next<false>(S.C, S.Q, ldm, ld, b, kvn, pnext, [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; });
+                    sp_rmw_cq_next<false, RB>(S.C, S.Q, ldm, ld, b, kvn, pnext, [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; });
                     have_next = true;
                 } else {
                     const int nn = b * b;
-                    for (int e0 = tid; e0 < nn; e0 += SP_NTH * SP_RMW) {     // loads first, see sp_rmw_cq
-                        double cv[SP_RMW];
-                        int ii[SP_RMW], jj[SP_RMW];
+                    for (int e0 = tid; e0 < nn; e0 += SP_NTH * RB) {     // loads first, see sp_rmw_cq
+                        double cv[RB];
+                        int ii[RB], jj[RB];
 #pragma unroll
-                        for (int u = 0; u < SP_RMW; ++u) {
+                        for (int u = 0; u < RB; ++u) {
                             const int e = e0 + u * SP_NTH, ec = e < nn ? e : e0;
                             ii[u] = ec % b;
                             jj[u] = ec / b;
                             cv[u] = S.C[ii[u] + (size_t)jj[u] * ldm];
                         }
 #pragma unroll
-                        for (int u = 0; u < SP_RMW; ++u)
+                        for (int u = 0; u < RB; ++u)
                             if (e0 + u * SP_NTH < nn) S.C[ii[u] + (size_t)jj[u] * ldm] = cv[u] + (re * sv[ii[u]]) * sv[jj[u]];
                     }
                 }
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                     nx[0] = nx0;
                     nx[1] = nx1;
                 }
-                b = sp_full_update_delete(S, b, rr, gamma, qv, px0, px1, A.prm.ref_field_delete_bug, ck, eh, sv, Cstar, Qstar, Crep,
+                b = sp_full_update_delete<RB>(S, b, rr, gamma, qv, px0, px1, A.prm.ref_field_delete_bug, ck, eh, sv, Cstar, Qstar, Crep,
                                           Qrep, part + 4 * ld, sval, sidx, more ? nx : nullptr, kvn, pnext, sf, A.c_exp, T);
                 have_next = more;
             } else {
@@ -595,10 +598,10 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                     const double n0 = nx0, n1 = nx1;
                     for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
-                    sp_rmw_cq_next(S.C, S.Q, ldm, ld, nb, kvn, pnext, grow);
+                    sp_rmw_cq_next<true, RB>(S.C, S.Q, ldm, ld, nb, kvn, pnext, grow);
                     have_next = true;
                 } else {
-                    sp_rmw_cq(S.C, S.Q, ldm, nb, grow);
+                    sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, grow);
                 }
                 b = nb;
                 __syncthreads();
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                 if (!have) best = __builtin_inf();
                 sp_block_argmin(best, loc, sval, sidx);
                 if (loc < 0 || loc >= b) loc = 0;          // all-NaN scores: the reference keeps minloc = 0
-                b = sp_delete_bv(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
+                b = sp_delete_bv<RB>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
                 have_next = false;
             }
             // Delete for geometric reasons (:226-242)
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void sparse_add_kernel(SpAddParams A
                     if (loc < 0 || loc >= b) loc = 0;
                     minscore = best;
                     if (minscore < (double)1e-9f) {
-                        b = sp_delete_bv(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
+                        b = sp_delete_bv<RB>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
                         have_next = false;              // the matrices and the basis changed after the pass
                     }
                     else if (!(minscore >= (double)1e-9f)) break;   // NaN: `minscore < 1e-9f` is false in the reference too
@@ -1172,7 +1175,7 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
         // small-basis phase first: one wave per patch, C and Q in LDS, until a patch outgrows SP_BMAX basis vectors
         const size_t lds_s = sp_add_lds_small();
         int per_cu_s = (int)((160u * 1024u) / lds_s);
-        per_cu_s = per_cu_s > 8 ? 8 : per_cu_s;
+        per_cu_s = per_cu_s > 16 ? 16 : per_cu_s;
         A.done_it = g->done_it;
         hipLaunchKernelGGL(sparse_add_kernel<true>, dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
         GPC_HIP(ctx, hipGetLastError());
