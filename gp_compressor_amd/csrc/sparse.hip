@@ -340,7 +340,7 @@ struct SpAddParams {
 
 // Small-basis phase.  With the reference's default hyper-parameters the basis stays at a dozen vectors whatever the capacity,
 // and a point is a handful of short loops whose cost is the latency of C and Q in L2 / HBM.  sparse_add_kernel<true> runs one
-// wave per patch with C and Q (up to SP_BMAX x SP_BMAX) resident in LDS, and hands a patch over -- state written back, the
+// wave per patch with C and Q (up to SP_BMAX x SP_BMAX) resident in LDS, ten patches per CU, and hands a patch over -- state written back, the
 // number of points consumed recorded in done_it -- at the first point that would grow its basis beyond SP_BMAX; the regular
 // kernel then continues from there (start_it).  Same operations in the same order: the two-phase run leaves the states of
 // a one-phase run, bit for bit.

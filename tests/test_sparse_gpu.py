@@ -477,7 +477,7 @@ def test_sparse_one_wave_per_patch_is_bit_identical(gp, ny, cap, kernel, monkeyp
                                             (1, 200, "fill"), (1, 80, "mixed"), (3, 40, "mixed"), (1, 33, "geo"), (1, -1, "fill"), (1, 255, "default")])
 def test_sparse_small_basis_phase_is_bit_identical(gp, ny, cap, kernel, monkeypatch):
     """The add runs in two phases: a small-basis kernel (one wave per patch, C and Q resident in LDS) takes every patch as far as
-    32 basis vectors, the regular kernel continues from the point where a patch outgrew it.  Same operations in the same order:
+    24 basis vectors, the regular kernel continues from the point where a patch outgrew it.  Same operations in the same order:
     with and without the first phase (GPC_SPARSE_NO_SMALL) the states, the basis sizes, the per-patch status and the point
     counts are identical -- patches that stay small, patches that cross over in the middle of a call, online growth over
     several calls, empty patches, capacities below and above the block size."""
