@@ -28,6 +28,11 @@ class Params(C.Structure):
                 ("ref_field_delete_bug", C.c_int32), ("want_variance", C.c_int32), ("reserved", C.c_int32)]
 
 
+class IrlsParams(C.Structure):
+    """struct gpc_irls_params (include/gpc.h)."""
+    _fields_ = [("max_iter", C.c_int32), ("reserved", C.c_int32), ("tol", C.c_double), ("f_init", C.c_double)]
+
+
 class PatchesView(C.Structure):
     """struct gpc_patches_view (include/gpc.h): sizes + device addresses of a patch batch."""
     _fields_ = [("P", C.c_int32), ("n_total", C.c_int32), ("n_max", C.c_int32), ("m", C.c_int32)] + \
@@ -61,6 +66,12 @@ PROTOTYPES = {
     "gpc_dense_fit_predict_grid": (C.c_int, [_vp, C.POINTER(Params), _i, _vp, _vp, _vp, _vp, _i, _d, _i, _vp, _vp, _vp]),
     "gpc_dense_fit_predict_grid_dev": (C.c_int, [_vp, C.POINTER(Params), _i, _vp, _i, _i, _vp, _vp, _vp, _i, _d, _i,
                                                  _vp, _vp, _vp]),
+    "gpc_default_params_irls": (None, [C.POINTER(IrlsParams)]),
+    "gpc_dense_irls_fit_predict": (C.c_int, [_vp, C.POINTER(Params), C.POINTER(IrlsParams), _i, _vp, _vp, _vp, _vp, _i, _vp, _vp,
+                                             _d, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gpc_dense_irls_fit_predict_dev": (C.c_int, [_vp, C.POINTER(Params), C.POINTER(IrlsParams), _i, _vp, _i, _i, _vp, _vp, _vp, _i,
+                                                 _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gpc_noise_eval": (C.c_int, [_vp, _i, _d, _i, _vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_create": (C.c_int, [_vp, C.POINTER(Params), _i, _i, C.POINTER(_vp)]),
     "gpc_sparse_destroy": (None, [_vp]),
     "gpc_sparse_reset": (C.c_int, [_vp]),
@@ -145,6 +156,14 @@ def default_params_sparse(ny=1, **kw):
     return p
 
 
+def default_params_irls(**kw):
+    p = IrlsParams()
+    load().gpc_default_params_irls(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
 class Context:
     """gpc_ctx: one per process per GPU."""
 
@@ -213,6 +232,45 @@ class Context:
         self._check(self.lib.gpc_dense_fit_predict_grid(self.h, C.byref(params), P, _ptr(off), _ptr(x0), _ptr(x1), _ptr(y),
                                                         ny, float(res), int(sz), _ptr(f), _ptr(al), _ptr(st)))
         return (f, st, al) if want_alpha else (f, st)
+
+    # ---- dense GP + probit functor, Newton / IRLS loop (BASELINE config 5) ---------------------------------------------
+    def dense_irls_fit_predict(self, params, irls, off, x0, x1, y, xs0=None, xs1=None, res=0.0, sz=0):
+        """Host-pointer entry (gpc_dense_irls_fit_predict).  y: (N,) labels +-1.  X* point-wise (xs0, xs1) or the sz x sz grid.
+        Returns f_star (P, m), alpha (N,), fhat (N,), iters (P,), status (P,)."""
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        if xs0 is not None:
+            xs0 = np.ascontiguousarray(xs0, dtype=np.float64)
+            xs1 = np.ascontiguousarray(xs1, dtype=np.float64)
+            m = xs0.shape[0]
+        else:
+            m = sz * sz
+        P = off.shape[0] - 1
+        f = np.full((P, m), np.nan)
+        al = np.full_like(y, np.nan)
+        fh = np.full_like(y, np.nan)
+        it = np.full(P, -1, dtype=np.int32)
+        st = np.full(P, -1, dtype=np.int32)
+        self._check(self.lib.gpc_dense_irls_fit_predict(self.h, C.byref(params), C.byref(irls), P, _ptr(off), _ptr(x0), _ptr(x1), _ptr(y),
+                                                        m, _ptr(xs0), _ptr(xs1), float(res), int(sz), _ptr(f), _ptr(al), _ptr(fh),
+                                                        _ptr(it), _ptr(st)))
+        return f, al, fh, it, st
+
+    def dense_irls_fit_predict_dev(self, params, irls, P, off, n_max, n_total, x0, x1, y, m, xs0, xs1, res, sz, f_star,
+                                   alpha_out=None, fhat_out=None, iters=None, status=None):
+        self._check(self.lib.gpc_dense_irls_fit_predict_dev(self.h, C.byref(params), C.byref(irls), P, _ptr(off), n_max, n_total,
+                                                            _ptr(x0), _ptr(x1), _ptr(y), m, _ptr(xs0), _ptr(xs1), float(res), int(sz),
+                                                            _ptr(f_star), _ptr(alpha_out), _ptr(fhat_out), _ptr(iters), _ptr(status)))
+
+    def noise_eval(self, noise_model, s20, y, x, sigma_x):
+        """gpc_noise_eval: the device's dx_ln / dx2_ln on arrays of (y, x, sigma_x) -> q, r"""
+        y, x, sx = (np.ascontiguousarray(a, dtype=np.float64).reshape(-1) for a in (y, x, sigma_x))
+        q = np.full_like(y, np.nan)
+        r = np.full_like(y, np.nan)
+        self._check(self.lib.gpc_noise_eval(self.h, int(noise_model), float(s20), len(y), _ptr(y), _ptr(x), _ptr(sx), _ptr(q), _ptr(r)))
+        return q, r
 
     # ---- reprojection + colour clamp (row f3): predicted grids -> pcl::PointXYZRGB records ------------------------------
     POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"),

@@ -366,12 +366,9 @@ int dense_generic_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
     g.mpad = (a.m + 63) & ~63;
     g.slot = (size_t)g.ld * g.ld + (a.v_star ? (size_t)a.n_max * g.mpad : 0);
     const size_t lds = gen_lds_bytes(a);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_generic_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
+    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_generic_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(dense_generic_kernel, dim3(grid), dim3(GEN_THREADS), lds, ctx->stream, g);
     GPC_HIP(ctx, hipGetLastError());
     ctx->last_dense_kernel = "dense_generic";

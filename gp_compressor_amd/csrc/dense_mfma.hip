@@ -843,12 +843,9 @@ template <int NT>
 static int launch_nt(gpc_ctx* ctx, const MfmaParams& g, int grid, const char* name)
 {
     const size_t lds = sizeof(double) * (size_t)L_TOTAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_mfma_kernel<NT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
+    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_mfma_kernel<NT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(dense_mfma_kernel<NT>, dim3(grid), dim3(MF_THREADS), lds, ctx->stream, g);
     GPC_HIP(ctx, hipGetLastError());
     ctx->last_dense_kernel = name;

@@ -41,6 +41,12 @@ struct BigParams {
     size_t slot;   // doubles per workgroup slot
     int ntw;       // tile columns of a slot = ceil(n_max / 16)
     unsigned long long* stamps;   // diagnostic (GPC_BIG_STAMPS=1): [phase][wave] cycle sums over all patches, else nullptr
+    // IRLS instantiation only (BASELINE config 5, gpc_dense_irls_fit_predict): the Newton loop around the factorisation
+    int irls_model;               // GPC_NOISE_PROBIT_REF / GPC_NOISE_PROBIT_STD
+    int irls_max_iter;
+    double irls_tol, irls_f_init;
+    int32_t* irls_iters;          // [P] solves performed, or nullptr
+    double* irls_fhat;            // [n_total] latent mode at the training points, or nullptr
 };
 #define BG_NPH 6
 #define BG_STAMP(ph)                                                                                                 \
@@ -65,7 +71,17 @@ __device__ static __forceinline__ d4 bg_mfma4_neg(d4 a, d4 b, d4 acc)
 }
 
 // BG_WAVES waves per workgroup and BG_NPAD padded points: <8, 1024> (one workgroup per CU) for 256 < n <= 1024.
-template <int BG_WAVES, int BG_NPAD, int BG_RMAX, int BG_OCC>
+//
+// BG_IRLS: the same factorisation inside a Newton / IRLS loop for a non-Gaussian likelihood (probit_noise,
+// /root/reference/src/probit_noise.cpp:11-31; BASELINE config 5).  Every Newton step of the Laplace mode search is one dense
+// GP regression fit with per-point noise d_i = 1 / W_i and working targets t_i = f_i + g_i d_i (W = -dx2_ln, g = dx_ln of the
+// functor at sigma_x = 0):  a = (K + diag d)^-1 t,  f_new = K a = t - d o a  -- so the loop re-runs the tiled Cholesky with the
+// diagonal and the right-hand-side row taken from LDS vectors instead of the scalar noise and y, and needs no mat-vec with
+// K at all.  What is factored is the symmetrically scaled matrix B = I + W^1/2 K W^1/2 (Rasmussen & Williams eq. 3.26:
+// eigenvalues >= 1 however far the weights spread; the tile TRSMs here multiply by explicit 16 x 16 inverses, which is only
+// as accurate as the tiles are well conditioned): u = B^-1 W^1/2 t, a = W^1/2 u -- the same Newton iterate.  Definition and stopping rule: oracle/gpc_oracle.c (orc_dense_irls_fit).  ny == 1; the unused colour planes of
+// the solve vectors hold f, d, t and the labels.
+template <int BG_WAVES, int BG_NPAD, int BG_RMAX, int BG_OCC, bool BG_IRLS = false>
 __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigParams g)
 {
     static_assert(BG_RMAX == 1 || BG_RMAX == 2, "one copy of the update loop per possible row count");
@@ -88,6 +104,13 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
     double* L10 = lds + B_L10;
     double* red = lds + B_RED;
     double* Hand = red;                // 3 x 256: hand-over of the diagonal-block tiles to wave 0 (the reduction buffer is idle then)
+    // IRLS (ny == 1): planes 1, 2 of the solve vectors are free
+    [[maybe_unused]] double* fv = zv + BG_NPAD;         // latent f
+    [[maybe_unused]] double* dv = zv + 2 * BG_NPAD;     // W^-1/2
+    [[maybe_unused]] double* sv = av + BG_NPAD;         // W^1/2
+    [[maybe_unused]] double* tv = wv + BG_NPAD;         // working targets
+    [[maybe_unused]] double* yl = wv + 2 * BG_NPAD;     // labels
+    [[maybe_unused]] unsigned long long* delta_bits = reinterpret_cast<unsigned long long*>(lds + B_FLAG + 4);   // max |f_new - f| of the step, as bits
     int* h0 = flag + 2;                // k + 1 once tile (k, k) of the step is handed over
     int* h1 = flag + 3;                // k + 1 once tiles (k+1, k), (k+1, k+1) are handed over
     const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
@@ -173,9 +196,14 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                 const int pj_ = MF_TS * (kc_) + lg + 4 * q_;                                                         \
                 double v_ = small_gram ? gpc_rbf_small(sf, cexp, xi0_, xi1_, px0[pj_], px1[pj_])                      \
                                        : gpc_rbf_neg(sf, cexp, xi0_, xi1_, px0[pj_], px1[pj_], T);                   \
+                if constexpr (BG_IRLS) v_ = (v_ * sv[pi_]) * sv[pj_];                                                \
                 if (pi_ == pj_) {                                                                                    \
-                    v_ += noise;                              /* covariance_matrix(..., training)  :59-61 */         \
-                    if (A.prm.ref_double_noise) v_ += noise;  /* C.diagonal() += sigman_sq        :21 */             \
+                    if constexpr (BG_IRLS) {                                                                         \
+                        v_ += 1.0;                                /* B = I + W^1/2 K W^1/2 */                        \
+                    } else {                                                                                         \
+                        v_ += noise;                              /* covariance_matrix(..., training)  :59-61 */     \
+                        if (A.prm.ref_double_noise) v_ += noise;  /* C.diagonal() += sigman_sq        :21 */         \
+                    }                                                                                                \
                 }                                                                                                    \
                 if (pi_ >= n || pj_ >= n) v_ = (pi_ == pj_) ? 1.0 : 0.0;     /* identity padding */                  \
                 (dst)[q_] = v_;                                                                                      \
@@ -183,7 +211,8 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         } else {   /* right-hand sides: row c = channel, columns = the points of tile column kc_ */                  \
             _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
                 const int pj_ = MF_TS * (kc_) + lg + 4 * q_;                                                         \
-                (dst)[q_] = (lr < ny && pj_ < n) ? A.y[(size_t)lr * A.n_total + o + pj_] : 0.0;                      \
+                if constexpr (BG_IRLS) (dst)[q_] = (lr == 0 && pj_ < n) ? sv[pj_] * tv[pj_] : 0.0;                   \
+                else (dst)[q_] = (lr < ny && pj_ < n) ? A.y[(size_t)lr * A.n_total + o + pj_] : 0.0;                 \
             }                                                                                                        \
         }                                                                                                            \
     } while (0)
@@ -192,6 +221,49 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
       __builtin_amdgcn_mfma_f64_16x16x4f64((lv_)[1], (src_)[1], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0)) +                  \
      (__builtin_amdgcn_mfma_f64_16x16x4f64((lv_)[2], (src_)[2], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0) +                   \
       __builtin_amdgcn_mfma_f64_16x16x4f64((lv_)[3], (src_)[3], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0)))
+        if constexpr (BG_IRLS) {
+            for (int i = tid; i < BG_NPAD; i += BG_THREADS) {
+                const double lab = (i < n) ? A.y[o + i] : 0.0;
+                yl[i] = lab;
+                fv[i] = lab * g.irls_f_init;
+            }
+            if (tid == 0) flag[4] = 0;
+            __syncthreads();
+        }
+        int iter = 0;
+        bool nan_w = false;
+        for (;;) {     // Newton / IRLS iterations (BG_IRLS); a single pass otherwise
+        if constexpr (BG_IRLS) {
+            // weights and working targets from the functor at the current f (sigma_x = 0); reset the step's hand-over words
+            int badw = 0;
+            for (int i = tid; i < BG_NPAD; i += BG_THREADS) {
+                double rs = 0.0, ss = 0.0, tt = 0.0;
+                if (i < n) {
+                    double q_, r_;
+                    gpc_probit_q_r(g.irls_model, noise, yl[i], fv[i], 0.0, &q_, &r_);
+                    const double W = -r_;
+                    if (!(W > 0.0) || !(W < __builtin_inf()) || q_ != q_) badw = 1;
+                    tt = fv[i] + q_ * (1.0 / W);
+                    ss = sqrt(W);
+                    rs = 1.0 / ss;
+                }
+                dv[i] = rs;
+                sv[i] = ss;
+                tv[i] = tt;
+                wv[i] = 0.0;
+            }
+            if (badw) flag[4] = 1;
+            if (tid == 0) {
+                flag[0] = 0;
+                flag[1] = -1;
+                flag[2] = 0;
+                flag[3] = 0;
+                *delta_bits = 0ull;
+            }
+            __syncthreads();
+            nan_w = flag[4] != 0;
+            if (nan_w) break;
+        }
         for (int k = 0; k < nt; k += 2) {
             const bool has2 = k + 1 < nt;
             const int k1 = has2 ? k + 1 : k;                               // second column of the pair (== k when absent)
@@ -337,16 +409,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
             bad = flag[0] != 0;
             if (bad) break;
         }
-        if (bad) {
-            __syncthreads();
-            for (int p = tid; p < m * ny; p += BG_THREADS) fs[p] = __builtin_nan("");
-            if (A.alpha_out)
-                for (int i = tid; i < n * ny; i += BG_THREADS)
-                    A.alpha_out[(size_t)(i / n) * A.n_total + o + (i % n)] = __builtin_nan("");
-            if (tid == 0 && A.status) A.status[patch] = GPC_STATUS_NOT_SPD;
-            continue;
-        }
-
+        if (bad) break;
         BG_STAMP(1);
         // z_k^T = tile (nt, k): lane l, slot s = z_(l&15)[16 k + (l>>4) + 4 s]
         for (int k = wave; k < nt; k += BG_WAVES) {
@@ -429,11 +492,61 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                 lt_cur = lt_nxt;
             }
         }
+        if constexpr (!BG_IRLS) break;
+        if constexpr (BG_IRLS) {
+            // the solve gave u = B^-1 W^1/2 t:  a = W^1/2 u,  f_new = K a = t - W^-1 a = t - W^-1/2 u;  the step's max |f_new - f|
+            // decides (workgroup-uniform, through LDS)
+            double dmax = 0.0;
+            for (int i = tid; i < n; i += BG_THREADS) {
+                const double u_ = av[i];
+                av[i] = sv[i] * u_;
+                const double fn = tv[i] - dv[i] * u_;
+                const double df = __builtin_fabs(fn - fv[i]);
+                dmax = (df > dmax || df != df) ? df : dmax;
+                fv[i] = fn;
+            }
+            // non-negative doubles (and NaN, above every finite value) order like their bit patterns
+            unsigned long long db = (unsigned long long)__double_as_longlong(dmax);
+#pragma unroll
+            for (int o_ = 32; o_ > 0; o_ >>= 1) {
+                const unsigned long long ob = (unsigned long long)__shfl_xor((long long)db, o_, 64);
+                db = ob > db ? ob : db;
+            }
+            if (lane == 0) atomicMax(delta_bits, db);
+            __syncthreads();
+            const double delta = __longlong_as_double((long long)*delta_bits);
+            ++iter;
+            if (delta != delta) { nan_w = true; break; }
+            if (delta <= g.irls_tol || iter >= g.irls_max_iter) break;
+            __syncthreads();   // delta_bits is reset by the next prologue
+        }
+        }   // Newton / IRLS iterations
+        if (bad || nan_w) {
+            __syncthreads();
+            if constexpr (BG_IRLS) {
+                if (g.irls_fhat)
+                    for (int i = tid; i < n; i += BG_THREADS) g.irls_fhat[o + i] = __builtin_nan("");
+                if (tid == 0 && g.irls_iters) g.irls_iters[patch] = iter;
+            }
+            for (int p = tid; p < m * ny; p += BG_THREADS) fs[p] = __builtin_nan("");
+            if (A.alpha_out)
+                for (int i = tid; i < n * ny; i += BG_THREADS)
+                    A.alpha_out[(size_t)(i / n) * A.n_total + o + (i % n)] = __builtin_nan("");
+            if (tid == 0 && A.status) A.status[patch] = nan_w ? GPC_STATUS_NAN : GPC_STATUS_NOT_SPD;
+            continue;
+        }
+
         if (A.alpha_out)
             for (int i = tid; i < n; i += BG_THREADS)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     if (c < ny) A.alpha_out[(size_t)c * A.n_total + o + i] = av[c * BG_NPAD + i];
+
+        if constexpr (BG_IRLS) {
+            if (g.irls_fhat)
+                for (int i = tid; i < n; i += BG_THREADS) g.irls_fhat[o + i] = fv[i];
+            if (tid == 0 && g.irls_iters) g.irls_iters[patch] = iter;
+        }
 
         BG_STAMP(3);
         // ---- predictive mean ----
@@ -552,19 +665,43 @@ size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
     return sizeof(double) * big_slot_doubles(ntw) * (size_t)grid;
 }
 
-template <int W, int NP, int RM, int OC>
+template <int W, int NP, int RM, int OC, bool IRLS = false>
 static int big_launch_t(gpc_ctx* ctx, const BigParams& g, int grid)
 {
     const size_t lds = sizeof(double) * (size_t)bg_lds_doubles(NP, W);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_big_kernel<W, NP, RM, OC>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((dense_big_kernel<W, NP, RM, OC>), dim3(grid), dim3(W * 64), lds, ctx->stream, g);
+    // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
+    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_big_kernel<W, NP, RM, OC, IRLS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((dense_big_kernel<W, NP, RM, OC, IRLS>), dim3(grid), dim3(W * 64), lds, ctx->stream, g);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;
+}
+
+// BASELINE config 5: the Newton / IRLS loop around the tiled factorisation (any n <= 1024; the 4-wave shape for n <= 256)
+int dense_irls_launch(gpc_ctx* ctx, const DenseArgs& a, const IrlsArgs& ir, int grid)
+{
+    BigParams g;
+    g.a = a;
+    g.c_exp = (double)(-0.5f) / a.prm.l_sq;
+    g.pivot_tol = GPC_PIVOT_RTOL;                        // B = I + W^1/2 K W^1/2: every pivot is >= 1 in exact arithmetic
+    g.ws = static_cast<double*>(ctx->ws);
+    g.ntw = (a.n_max + MF_TS - 1) / MF_TS;
+    g.slot = big_slot_doubles(g.ntw);
+    g.stamps = nullptr;
+    g.irls_model = a.prm.noise_model;
+    g.irls_max_iter = ir.max_iter;
+    g.irls_tol = ir.tol;
+    g.irls_f_init = ir.f_init;
+    g.irls_iters = ir.iters;
+    g.irls_fhat = ir.fhat;
+    int waves, npad, per_cu;
+    big_shape(a, &waves, &npad, &per_cu);
+    if (waves == 4) {
+        ctx->last_dense_kernel = "dense_mfma_big_w4_irls";
+        return big_launch_t<4, 256, 2, 2, true>(ctx, g, grid);
+    }
+    ctx->last_dense_kernel = "dense_mfma_big_irls";
+    return big_launch_t<8, 1024, 2, 2, true>(ctx, g, grid);
 }
 
 int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
@@ -579,6 +716,7 @@ int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
     int waves, npad, per_cu;
     big_shape(a, &waves, &npad, &per_cu);
     g.stamps = nullptr;
+    g.irls_model = 0; g.irls_max_iter = 0; g.irls_tol = 0.0; g.irls_f_init = 0.0; g.irls_iters = nullptr; g.irls_fhat = nullptr;
     struct StampDump {
         gpc_ctx* ctx; unsigned long long* d; int P, waves;
         ~StampDump()

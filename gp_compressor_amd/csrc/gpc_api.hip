@@ -103,7 +103,7 @@ int gpc_ctx_create(gpc_ctx** out, int device)
 
 int gpc_ctx_set_stream(gpc_ctx* ctx, void* hip_stream)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->stream = (hip_stream == GPC_STREAM_OWN) ? ctx->own_stream : static_cast<hipStream_t>(hip_stream);
     return GPC_OK;
@@ -111,7 +111,7 @@ int gpc_ctx_set_stream(gpc_ctx* ctx, void* hip_stream)
 
 int gpc_ctx_synchronize(gpc_ctx* ctx)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GPC_OK;
@@ -119,7 +119,7 @@ int gpc_ctx_synchronize(gpc_ctx* ctx)
 
 int gpc_dev_malloc(gpc_ctx* ctx, size_t bytes, void** out)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     if (!out) return gpc_fail(ctx, GPC_EINVAL, "out is NULL");
     *out = nullptr;
     GPC_HIP(ctx, hipSetDevice(ctx->device));
@@ -129,7 +129,7 @@ int gpc_dev_malloc(gpc_ctx* ctx, size_t bytes, void** out)
 
 int gpc_dev_free(gpc_ctx* ctx, void* p)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     if (!p) return GPC_OK;
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));     // nothing enqueued may still be using it
@@ -139,7 +139,7 @@ int gpc_dev_free(gpc_ctx* ctx, void* p)
 
 int gpc_dev_memcpy(gpc_ctx* ctx, void* dst, const void* src, size_t bytes, int kind)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     if (bytes == 0) return GPC_OK;
     if (!dst || !src) return gpc_fail(ctx, GPC_EINVAL, "dst/src is NULL");
     const hipMemcpyKind k = kind == GPC_COPY_H2D ? hipMemcpyHostToDevice : kind == GPC_COPY_D2H ? hipMemcpyDeviceToHost
@@ -151,14 +151,25 @@ int gpc_dev_memcpy(gpc_ctx* ctx, void* dst, const void* src, size_t bytes, int k
     return GPC_OK;
 }
 
+// Children (gpc_sparse, gpc_patches) may outlive the context: the device resources go now, the struct when the last
+// child is destroyed.  A child of a dead context can only be destroyed; every other call on it returns GPC_EINVAL.
 void gpc_ctx_destroy(gpc_ctx* ctx)
 {
-    if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->ws) (void)hipFree(ctx->ws);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
-    delete ctx;
+    if (!ctx || ctx->dead.load()) return;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->ws) (void)hipFree(ctx->ws);
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+        ctx->own_stream = nullptr;
+        ctx->stream = nullptr;
+        snprintf(ctx->err, sizeof(ctx->err), "the context has been destroyed");
+        ctx->dead.store(true);
+    }
+    gpc_ctx_unref(ctx);
 }
 
 const char* gpc_last_error(const gpc_ctx* ctx) { return ctx ? ctx->err : "null context"; }
@@ -180,12 +191,9 @@ int gpc_debug_poison_lds(gpc_ctx* ctx)
 {
     const bool on = getenv("GPC_POISON_LDS") != nullptr;       // read per call: a test can switch it on for itself
     if (!on || !ctx) return GPC_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gpc_poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-        attr_set = true;
-    }
+    // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
+    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gpc_poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
     const int bytes = 160 * 1024;
     hipLaunchKernelGGL(gpc_poison_lds_kernel, dim3(ctx->num_cus * 2), dim3(256), bytes, ctx->stream, bytes / 8);
     GPC_HIP(ctx, hipGetLastError());
@@ -199,7 +207,7 @@ int gpc_debug_poison_lds(gpc_ctx* ctx)
 static int dense_check(gpc_ctx* ctx, const gpc_params* prm, int P, const void* off, int n_max, int n_total,
                        const void* x0, const void* x1, const void* y, int ny, int m, const void* f_star)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     if (!prm) return gpc_fail(ctx, GPC_EINVAL, "params is NULL");
     if (P < 0 || m < 0 || n_total < 0 || n_max < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
     if (ny != 1 && ny != 3) return gpc_fail(ctx, GPC_EINVAL, "ny must be 1 (depth) or 3 (RGB), got %d", ny);
@@ -309,7 +317,7 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
                       int m, const double* xs0, const double* xs1, double res, int sz, bool grid,
                       double* f_star, double* v_star, double* alpha_out, int32_t* status)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     if (P < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
     if (P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
     int n_max = 0, n_total = 0;
@@ -377,6 +385,148 @@ int gpc_dense_fit_predict_grid(gpc_ctx* ctx, const gpc_params* params, int P, co
     if (ctx && (sz < 0 || sz > 1024)) return gpc_fail(ctx, GPC_EINVAL, "sz out of range");
     return dense_host(ctx, params, P, off, x0, x1, y, ny, sz * sz, nullptr, nullptr, res, sz, true, f_star, nullptr,
                       alpha_out, status);
+}
+
+// ------------------------------------------------------------------------------------------------ probit / IRLS (config 5)
+
+void gpc_default_params_irls(gpc_irls_params* p)
+{
+    if (!p) return;
+    p->max_iter = 20;
+    p->reserved = 0;
+    p->tol = 1e-9;
+    p->f_init = 0.0;
+}
+
+int gpc_dense_irls_fit_predict_dev(gpc_ctx* ctx, const gpc_params* params, const gpc_irls_params* irls, int P, const int32_t* off,
+                                   int n_max, int n_total, const double* x0, const double* x1, const double* y, int m,
+                                   const double* xs0, const double* xs1, double res, int sz, double* f_star, double* alpha_out,
+                                   double* fhat_out, int32_t* iters, int32_t* status)
+{
+    const bool grid = (xs0 == nullptr);
+    if (ctx && grid && (sz < 0 || sz > 1024)) return gpc_fail(ctx, GPC_EINVAL, "sz out of range");
+    if (grid) m = sz * sz;
+    int rc = dense_check(ctx, params, P, off, n_max, n_total, x0, x1, y, 1, m, f_star);
+    if (rc != GPC_OK) return rc;
+    if (!irls) return gpc_fail(ctx, GPC_EINVAL, "irls is NULL");
+    if (params->noise_model != 1 && params->noise_model != 2)
+        return gpc_fail(ctx, GPC_EINVAL, "the IRLS loop needs a probit noise_model (1 or 2), got %d", params->noise_model);
+    if (irls->max_iter < 1 || !(irls->tol >= 0.0) || !(irls->f_init == irls->f_init))
+        return gpc_fail(ctx, GPC_EINVAL, "irls parameters out of range");
+    if (!(params->noise > 0.0)) return gpc_fail(ctx, GPC_EINVAL, "s20 (params->noise) must be positive");
+    if (!grid && m > 0 && !xs1) return gpc_fail(ctx, GPC_EINVAL, "xs1 is NULL");
+    if (P == 0) return GPC_OK;
+    DenseArgs a{};
+    a.prm = *params;
+    a.prm.want_variance = 0;
+    a.P = P; a.n_max = n_max < 1 ? 1 : n_max; a.n_total = n_total; a.ny = 1; a.m = m;
+    a.off = off; a.x0 = x0; a.x1 = x1; a.y = y; a.xs0 = xs0; a.xs1 = xs1;
+    a.grid_res = grid ? res : 0.0; a.grid_sz = grid ? sz : 0;
+    a.f_star = f_star; a.v_star = nullptr; a.alpha_out = alpha_out; a.status = status;
+    IrlsArgs ir{irls->max_iter, irls->tol, irls->f_init, iters, fhat_out};
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcp = gpc_debug_poison_lds(ctx)) return rcp;
+    int grid_b = 0;
+    const size_t bytes = dense_big_ws_bytes(ctx, a, &grid_b);
+    rc = gpc_ws_reserve(ctx, bytes);
+    if (rc != GPC_OK) return rc;
+    return dense_irls_launch(ctx, a, ir, grid_b);
+}
+
+int gpc_dense_irls_fit_predict(gpc_ctx* ctx, const gpc_params* params, const gpc_irls_params* irls, int P, const int32_t* off,
+                               const double* x0, const double* x1, const double* y, int m, const double* xs0, const double* xs1,
+                               double res, int sz, double* f_star, double* alpha_out, double* fhat_out, int32_t* iters,
+                               int32_t* status)
+{
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
+    if (P < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
+    if (P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    const bool grid = (xs0 == nullptr);
+    if (grid) {
+        if (sz < 0 || sz > 1024) return gpc_fail(ctx, GPC_EINVAL, "sz out of range");
+        m = sz * sz;
+    }
+    int n_max = 0, n_total = 0;
+    int rc = host_n_max(ctx, P, off, &n_max, &n_total);
+    if (rc != GPC_OK) return rc;
+    rc = dense_check(ctx, params, P, off, n_max, n_total, x0, x1, y, 1, m, f_star);
+    if (rc != GPC_OK) return rc;
+    if (P == 0) return GPC_OK;
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf d_off, d_x0, d_x1, d_y, d_xs0, d_xs1, d_f, d_al, d_fh, d_it, d_st;
+    const size_t N = (size_t)n_total;
+    if ((rc = d_off.alloc(ctx, sizeof(int32_t) * (P + 1))) || (rc = d_x0.alloc(ctx, 8 * N)) || (rc = d_x1.alloc(ctx, 8 * N)) ||
+        (rc = d_y.alloc(ctx, 8 * N)) || (rc = d_f.alloc(ctx, 8 * (size_t)P * m)) || (rc = d_al.alloc(ctx, 8 * N)) ||
+        (rc = d_fh.alloc(ctx, 8 * N)) || (rc = d_it.alloc(ctx, sizeof(int32_t) * P)) || (rc = d_st.alloc(ctx, sizeof(int32_t) * P)))
+        return rc;
+    if (!grid && ((rc = d_xs0.alloc(ctx, 8 * (size_t)m)) || (rc = d_xs1.alloc(ctx, 8 * (size_t)m)))) return rc;
+    hipStream_t s = ctx->stream;
+    GPC_HIP(ctx, hipMemcpyAsync(d_off.p, off, sizeof(int32_t) * (P + 1), hipMemcpyHostToDevice, s));
+    if (N) {
+        GPC_HIP(ctx, hipMemcpyAsync(d_x0.p, x0, 8 * N, hipMemcpyHostToDevice, s));
+        GPC_HIP(ctx, hipMemcpyAsync(d_x1.p, x1, 8 * N, hipMemcpyHostToDevice, s));
+        GPC_HIP(ctx, hipMemcpyAsync(d_y.p, y, 8 * N, hipMemcpyHostToDevice, s));
+    }
+    if (!grid && m) {
+        if (!xs1) return gpc_fail(ctx, GPC_EINVAL, "xs1 is NULL");
+        GPC_HIP(ctx, hipMemcpyAsync(d_xs0.p, xs0, 8 * (size_t)m, hipMemcpyHostToDevice, s));
+        GPC_HIP(ctx, hipMemcpyAsync(d_xs1.p, xs1, 8 * (size_t)m, hipMemcpyHostToDevice, s));
+    }
+    rc = gpc_dense_irls_fit_predict_dev(ctx, params, irls, P, d_off.as<int32_t>(), n_max, n_total, d_x0.as<double>(), d_x1.as<double>(),
+                                        d_y.as<double>(), m, grid ? nullptr : d_xs0.as<double>(), grid ? nullptr : d_xs1.as<double>(),
+                                        res, sz, d_f.as<double>(), d_al.as<double>(), d_fh.as<double>(), d_it.as<int32_t>(),
+                                        d_st.as<int32_t>());
+    if (rc != GPC_OK) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    if (m) GPC_HIP(ctx, hipMemcpyAsync(f_star, d_f.p, 8 * (size_t)P * m, hipMemcpyDeviceToHost, s));
+    if (alpha_out && N) GPC_HIP(ctx, hipMemcpyAsync(alpha_out, d_al.p, 8 * N, hipMemcpyDeviceToHost, s));
+    if (fhat_out && N) GPC_HIP(ctx, hipMemcpyAsync(fhat_out, d_fh.p, 8 * N, hipMemcpyDeviceToHost, s));
+    if (iters) GPC_HIP(ctx, hipMemcpyAsync(iters, d_it.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, s));
+    if (status) GPC_HIP(ctx, hipMemcpyAsync(status, d_st.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, s));
+    GPC_HIP(ctx, hipStreamSynchronize(s));
+    return GPC_OK;
+}
+
+__global__ void gpc_noise_eval_kernel(int model, double s20, int n, const double* y, const double* x, const double* sx, double* q, double* r)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double qq, rr;
+    if (model == GPC_NOISE_GAUSSIAN) gpc_gaussian_q_r(s20, y[i], x[i], sx[i], &qq, &rr);
+    else gpc_probit_q_r(model, s20, y[i], x[i], sx[i], &qq, &rr);
+    q[i] = qq;
+    r[i] = rr;
+}
+
+int gpc_noise_eval(gpc_ctx* ctx, int noise_model, double s20, int n, const double* y, const double* x, const double* sigma_x,
+                   double* q, double* r)
+{
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
+    if (noise_model < 0 || noise_model > 2) return gpc_fail(ctx, GPC_EINVAL, "noise_model must be 0, 1 or 2");
+    if (n < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
+    if (n == 0) return GPC_OK;
+    if (!y || !x || !sigma_x || !q || !r) return gpc_fail(ctx, GPC_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf d;
+    const size_t nb = 8 * (size_t)n;
+    int rc = d.alloc(ctx, 5 * nb);
+    if (rc != GPC_OK) return rc;
+    char* b = d.as<char>();
+    hipStream_t s = ctx->stream;
+    GPC_HIP(ctx, hipMemcpyAsync(b, y, nb, hipMemcpyHostToDevice, s));
+    GPC_HIP(ctx, hipMemcpyAsync(b + nb, x, nb, hipMemcpyHostToDevice, s));
+    GPC_HIP(ctx, hipMemcpyAsync(b + 2 * nb, sigma_x, nb, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(gpc_noise_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, s, noise_model, s20, n, (const double*)b,
+                       (const double*)(b + nb), (const double*)(b + 2 * nb), (double*)(b + 3 * nb), (double*)(b + 4 * nb));
+    GPC_HIP(ctx, hipGetLastError());
+    GPC_HIP(ctx, hipMemcpyAsync(q, b + 3 * nb, nb, hipMemcpyDeviceToHost, s));
+    GPC_HIP(ctx, hipMemcpyAsync(r, b + 4 * nb, nb, hipMemcpyDeviceToHost, s));
+    GPC_HIP(ctx, hipStreamSynchronize(s));
+    return GPC_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ partition

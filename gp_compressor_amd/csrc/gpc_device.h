@@ -140,3 +140,37 @@ __device__ static inline double gpc_block_sum(double v, double* scratch)
     for (int i = 0; i < nw; ++i) s += scratch[i];
     return s;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Noise functors: the duck-typed Noise contract of the reference, q = dx_ln(y, x, sigma_x) = d/dx ln P(y|x) and
+// r = dx2_ln(y, x, sigma_x) = d2/dx2 ln P(y|x)   (/root/reference/src/gaussian_noise.h:7-10, src/probit_noise.h).
+// One definition for every kernel that needs them (sparse add, the dense IRLS loop, gpc_noise_eval).
+// ---------------------------------------------------------------------------------------------------------
+#define GPC_NOISE_GAUSSIAN 0
+#define GPC_NOISE_PROBIT_REF 1   // probit_noise as written: "Phi"(z) = erf(z) / (2.0f*sqrt(2.0f))   (src/probit_noise.cpp:15,26)
+#define GPC_NOISE_PROBIT_STD 2   // the fix: Phi(z) = (1 + erf(z / sqrt 2)) / 2, a CDF; everything else as upstream
+
+// gaussian_noise::dx_ln / dx2_ln   (/root/reference/src/gaussian_noise.cpp:9-18)
+__device__ static inline void gpc_gaussian_q_r(double s20, double y, double x, double sigma_x, double* q, double* r)
+{
+    *q = (y - x) / (s20 + sigma_x);
+    *r = (double)(-1.0f) / (s20 + sigma_x);
+}
+
+// probit_noise::dx_ln / dx2_ln   (/root/reference/src/probit_noise.cpp:11-31), operation for operation.  `2.0f*sqrt(2.0f)`
+// is a float product upstream (the sqrt(float) overload), checked against the compiled reference object in
+// tests/golden/noise_ref.json; exp(-z*z/2) and sqrt(2.0f*M_PI) are double.  model == GPC_NOISE_PROBIT_STD swaps the
+// one expression that is wrong upstream (ef) and keeps the rest.
+__device__ static inline void gpc_probit_q_r(int model, double s20, double y, double x, double sigma_x, double* q, double* r)
+{
+    const double sigma2 = s20 + sigma_x;
+    const double sigma = sqrt(sigma2);
+    const double z = y * x / sigma;
+    const double ef = (model == GPC_NOISE_PROBIT_STD) ? 0.5 * erfc(-z * 0.70710678118654752440)
+                                                      : erf(z) / (double)(2.0f * 1.41421354f);
+    const double efprim = exp(-z * z / 2.0) / sqrt(2.0 * 3.14159265358979323846);
+    *q = y / sigma * efprim / ef;                                 // :17
+    const double efprimprim = -z * efprim;                        // :28
+    const double first = efprim / ef;                             // :29
+    *r = (efprimprim / ef - first * first) / sigma2;              // :30
+}

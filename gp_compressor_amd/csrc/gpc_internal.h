@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 
@@ -30,7 +31,18 @@ struct gpc_ctx {
     std::mutex mu;
     char err[512] = {0};
     const char* last_dense_kernel = "";
+    // Ownership (include/gpc.h): every object created from the context (gpc_sparse, gpc_patches) holds one reference.
+    // gpc_ctx_destroy releases the device resources and the caller's reference; the struct itself lives until the last
+    // child has been destroyed, so a child destroyed AFTER its context finds a `dead` context instead of freed memory.
+    std::atomic<int> refs{1};
+    std::atomic<bool> dead{false};
 };
+
+static inline void gpc_ctx_ref(gpc_ctx* ctx) { ctx->refs.fetch_add(1, std::memory_order_relaxed); }
+static inline void gpc_ctx_unref(gpc_ctx* ctx)
+{
+    if (ctx->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete ctx;
+}
 
 static inline int gpc_fail(gpc_ctx* ctx, int code, const char* fmt, ...)
 {
@@ -106,3 +118,11 @@ int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a);
 bool dense_big_supported(const DenseArgs& a);
 size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out);
 int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid);
+// the same kernel inside the Newton / IRLS loop of the probit variant (BASELINE config 5; any n <= 1024, ny == 1)
+struct IrlsArgs {
+    int max_iter;
+    double tol, f_init;
+    int32_t* iters;   // [P] or nullptr
+    double* fhat;     // [n_total] or nullptr
+};
+int dense_irls_launch(gpc_ctx* ctx, const DenseArgs& a, const IrlsArgs& ir, int grid);

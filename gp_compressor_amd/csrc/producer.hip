@@ -621,16 +621,20 @@ size_t carve_scratch(Carver& c, Scratch& s, size_t n, size_t pb, size_t prim_byt
 
 extern "C" {
 
+// Safe in either order with gpc_ctx_destroy (the batch holds a reference on its context; hipFree synchronises the device).
 void gpc_patches_destroy(gpc_patches* o)
 {
     if (!o) return;
+    gpc_ctx* ctx = o->ctx;
+    if (ctx) (void)hipSetDevice(ctx->device);
     if (o->block) (void)hipFree(o->block);
     delete o;
+    if (ctx) gpc_ctx_unref(ctx);
 }
 
 int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, double res, int sz, gpc_patches** out)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     if (!out) return gpc_fail(ctx, GPC_EINVAL, "out is NULL");
     *out = nullptr;
     if (n < 0) return gpc_fail(ctx, GPC_EINVAL, "negative point count");
@@ -643,6 +647,7 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
     hipStream_t st = ctx->stream;
     gpc_patches* o = new gpc_patches;
     o->ctx = ctx;
+    gpc_ctx_ref(ctx);
     o->v.m = sz * sz;
     if (n == 0) {
         PC_HIP(hipMalloc(&o->block, 256));
@@ -790,7 +795,7 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
 
 int gpc_project_cloud(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, double res, int sz, gpc_patches** out)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     if (!out) return gpc_fail(ctx, GPC_EINVAL, "out is NULL");
     *out = nullptr;
     if (n < 0) return gpc_fail(ctx, GPC_EINVAL, "negative point count");
@@ -825,6 +830,7 @@ int gpc_patches_fetch(const gpc_patches* p, int32_t* off, double* x0, double* x1
 {
     if (!p) return GPC_EINVAL;
     gpc_ctx* ctx = p->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the batch can only be destroyed
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     const gpc_patches_view& v = p->v;
     const size_t P = (size_t)v.P, N = (size_t)v.n_total;

@@ -90,7 +90,7 @@ int gpc_reproject_dev(gpc_ctx* ctx, int P, int m, const int32_t* bv_count, const
                       const double* f_star, const double* c_star, const double* rotations, const double* means,
                       const double* rgb_means, gpc_point_xyzrgb* cloud, int32_t* n_points)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     if (P < 0 || m < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
     if (!n_points) return gpc_fail(ctx, GPC_EINVAL, "n_points is NULL");
     if (P > 0 && m > 0 && (!xs0 || !xs1 || !f_star || !rotations || !means || !cloud))
@@ -122,7 +122,7 @@ int gpc_reproject(gpc_ctx* ctx, int P, int m, const int32_t* bv_count, const dou
                   const double* c_star, const double* rotations, const double* means, const double* rgb_means,
                   gpc_point_xyzrgb* cloud, int32_t* n_points)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     if (P < 0 || m < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
     if (!n_points) return gpc_fail(ctx, GPC_EINVAL, "n_points is NULL");
     *n_points = 0;

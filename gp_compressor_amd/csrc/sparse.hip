@@ -505,15 +505,8 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
             // r = noise.dx2_ln, q = noise.dx_ln  (/root/reference/src/gaussian_noise.cpp:9-18, gaussian_noise_3d.cpp:11-20,
             // probit_noise.cpp:11-31)
             double rr, qv[3];
-            if (A.prm.noise_model == 1 && ny == 1) {
-                const double sigma2 = s20 + s2, sigma = sqrt(sigma2);
-                const double z = yv[0] * sums[0] / sigma;
-                const double two_sqrt2 = (double)(2.0f * 1.41421354f);   // float product, see oracle/gpc_oracle.c
-                const double ef = erf(z) / two_sqrt2;
-                const double efprim = exp(-z * z / 2.0) / sqrt(2.0 * M_PI);
-                qv[0] = yv[0] / sigma * efprim / ef;
-                const double first = efprim / ef;
-                rr = ((-z * efprim) / ef - first * first) / sigma2;
+            if (A.prm.noise_model != GPC_NOISE_GAUSSIAN && ny == 1) {
+                gpc_probit_q_r(A.prm.noise_model, s20, yv[0], sums[0], s2, &qv[0], &rr);
             } else {
                 rr = (double)(-1.0f) / (s20 + s2);
                 for (int c = 0; c < ny; ++c) qv[c] = (yv[c] - sums[c]) / (s20 + s2);
@@ -1069,7 +1062,7 @@ extern "C" {
 
 int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc_sparse** out)
 {
-    if (!ctx) return GPC_EINVAL;
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     if (!out) return gpc_fail(ctx, GPC_EINVAL, "out is NULL");
     *out = nullptr;
     if (!params) return gpc_fail(ctx, GPC_EINVAL, "params is NULL");
@@ -1077,7 +1070,8 @@ int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc
     if (ny != 1 && ny != 3) return gpc_fail(ctx, GPC_EINVAL, "ny must be 1 (sparse_gp) or 3 (sparse_gp_field), got %d", ny);
     if (params->capacity == 0 || params->capacity < -1) return gpc_fail(ctx, GPC_EINVAL, "capacity must be > 0 or -1");
     if (params->capacity > GPC_MAX_BV - 1) return gpc_fail(ctx, GPC_ERANGE, "capacity %d > %d", params->capacity, GPC_MAX_BV - 1);
-    if (params->noise_model == 1 && ny != 1) return gpc_fail(ctx, GPC_EINVAL, "probit noise needs ny == 1");
+    if (params->noise_model < 0 || params->noise_model > 2) return gpc_fail(ctx, GPC_EINVAL, "noise_model must be 0, 1 or 2");
+    if (params->noise_model != 0 && ny != 1) return gpc_fail(ctx, GPC_EINVAL, "probit noise needs ny == 1");
     if (!(params->l_sq > 0.0) || !(params->sigmaf_sq > 0.0)) return gpc_fail(ctx, GPC_EINVAL, "kernel parameters out of range");
     gpc_sparse* g = new (std::nothrow) gpc_sparse();
     if (!g) return GPC_ENOMEM;
@@ -1107,18 +1101,26 @@ int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc
         delete g;
         return rc;
     }
+    gpc_ctx_ref(ctx);
     *out = g;
     return GPC_OK;
 }
 
+// Safe in either order with gpc_ctx_destroy: a context destroyed first has synchronised its stream already and stays
+// allocated (dead) until its last child is gone.
 void gpc_sparse_destroy(gpc_sparse* g)
 {
     if (!g) return;
-    (void)hipSetDevice(g->ctx->device);
-    (void)hipStreamSynchronize(g->ctx->stream);
+    gpc_ctx* ctx = g->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (!ctx->dead.load()) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!ctx->dead.load()) (void)hipStreamSynchronize(ctx->stream);
+    }
     for (void* p : {(void*)g->alpha, (void*)g->C, (void*)g->Q, (void*)g->BV, (void*)g->b, (void*)g->count, (void*)g->stat, (void*)g->done_it})
         if (p) (void)hipFree(p);
     delete g;
+    gpc_ctx_unref(ctx);
 }
 
 int gpc_sparse_ld(const gpc_sparse* g) { return g ? g->ld : GPC_EINVAL; }
@@ -1127,6 +1129,7 @@ int gpc_sparse_reset(gpc_sparse* g)
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     std::lock_guard<std::mutex> lk(ctx->mu);
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t Pn = (size_t)(g->P > 0 ? g->P : 1);
@@ -1141,6 +1144,7 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     if (g->P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
     if (n_total < 0 || n_max < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
     if (n_total > 0 && (!x0 || !x1 || !y)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/y is NULL");
@@ -1192,6 +1196,7 @@ int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     if (m < 0) return gpc_fail(ctx, GPC_EINVAL, "negative m");
     if (m > 0 && (!xs0 || !xs1 || !f_star)) return gpc_fail(ctx, GPC_EINVAL, "xs0/xs1/f_star is NULL");
     if (g->P == 0 || m == 0) return GPC_OK;
@@ -1206,12 +1211,9 @@ int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double
     A.f_star = f_star; A.sigma = sigma; A.status_out = status; A.stat = g->stat;
     A.fast = (sigma != nullptr && sp_pred_lds(g->ld, true, true) <= 160u * 1024u) ? 1 : 0;
     const size_t lds = sp_pred_lds(g->ld, sigma != nullptr, A.fast != 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_predict_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
+    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_predict_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int per_cu = (int)((160u * 1024u) / lds);
     per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
     int grid = std::min(g->P, ctx->num_cus * per_cu);
@@ -1225,6 +1227,7 @@ static int sp_likelihood_launch(gpc_sparse* g, const int32_t* off, int n_total, 
                                 double* dX, double* l, double* raw)
 {
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     SpLikParams A;
     A.prm = g->prm;
     A.raw = raw;
@@ -1236,12 +1239,9 @@ static int sp_likelihood_launch(gpc_sparse* g, const int32_t* off, int n_total, 
     A.dX = dX; A.l = l;
     A.fast = (sp_lik_lds(g->ld, true) <= 160u * 1024u) ? 1 : 0;
     const size_t lds = sp_lik_lds(g->ld, A.fast != 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_likelihood_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
+    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_likelihood_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int per_cu = (int)((160u * 1024u) / lds);
     per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
     int grid = std::min(g->P, ctx->num_cus * per_cu);
@@ -1255,6 +1255,7 @@ int gpc_sparse_likelihood_dev(gpc_sparse* g, const int32_t* off, int n_total, co
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     if (g->P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
     if (n_total < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
     if (n_total > 0 && (!x0 || !x1 || !y)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/y is NULL");
@@ -1273,6 +1274,7 @@ int gpc_sparse_train_sigmaf_dev(gpc_sparse* g, const int32_t* off, int n_total, 
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     if (g->ny != 1) return gpc_fail(ctx, GPC_EINVAL, "train_parameters exists for sparse_gp (ny == 1) only");
     if (g->prm.noise_model != 0) return gpc_fail(ctx, GPC_EINVAL, "likelihoods are defined for the Gaussian noise model");
     if (g->P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
@@ -1308,6 +1310,7 @@ int gpc_sparse_train_sigmaf(gpc_sparse* g, const int32_t* off, const double* x0,
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     const int P = g->P;
     if (P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
     if (P == 0) return GPC_OK;
@@ -1361,6 +1364,7 @@ int gpc_sparse_likelihood(gpc_sparse* g, const int32_t* off, const double* x0, c
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     const int P = g->P;
     if (P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
     if (P == 0) return GPC_OK;
@@ -1408,6 +1412,7 @@ int gpc_sparse_add(gpc_sparse* g, const int32_t* off, const double* x0, const do
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     const int P = g->P;
     if (P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
     if (P == 0) return GPC_OK;
@@ -1463,6 +1468,7 @@ int gpc_sparse_predict(gpc_sparse* g, int m, const double* xs0, const double* xs
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     if (m < 0) return gpc_fail(ctx, GPC_EINVAL, "negative m");
     if (m > 0 && (!xs0 || !xs1 || !f_star)) return gpc_fail(ctx, GPC_EINVAL, "xs0/xs1/f_star is NULL");
     const int P = g->P;
@@ -1503,6 +1509,7 @@ int gpc_sparse_sizes(gpc_sparse* g, int32_t* bv_count)
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     if (!bv_count) return gpc_fail(ctx, GPC_EINVAL, "bv_count is NULL");
     if (g->P == 0) return GPC_OK;
     GPC_HIP(ctx, hipSetDevice(ctx->device));
@@ -1515,6 +1522,7 @@ int gpc_sparse_get_state(gpc_sparse* g, double* alpha, double* C, double* Q, dou
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     if (g->P == 0) return GPC_OK;
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t ld = (size_t)g->ld, P = (size_t)g->P;
@@ -1535,6 +1543,7 @@ int gpc_sparse_set_state(gpc_sparse* g, const int32_t* bv_count, const double* a
 {
     if (!g) return GPC_EINVAL;
     gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
     if (g->P == 0) return GPC_OK;
     if (!bv_count || !alpha || !BV) return gpc_fail(ctx, GPC_EINVAL, "bv_count/alpha/BV is NULL");
     for (int i = 0; i < g->P; ++i)

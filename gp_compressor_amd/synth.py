@@ -115,3 +115,11 @@ def _texture(a, b, c):
     g = np.clip(127 + 100 * np.cos(7 * b), 0, 255)
     bl = np.clip(127 + 60 * np.sin(5 * c), 0, 255)
     return np.stack([r, g, bl], 1).astype(np.uint8)
+
+
+def occupancy_labels(off, y):
+    """BASELINE config 5: labels y = sign(depth - surface) in {+1, -1}.  The patch frame removes the mean
+    depth, so the reference surface is depth 0: a sample above the fitted plane is +1, below -1 (ray samples either side of the
+    surface; sensor noise makes the boundary ragged).  y: the depth plane of make_patches (N,)."""
+    lab = np.where(np.asarray(y, dtype=np.float64).reshape(-1) >= 0.0, 1.0, -1.0)
+    return np.ascontiguousarray(lab)

@@ -64,7 +64,9 @@ typedef struct gpc_params {
     double noise;                 /* dense: sigman_sq (src/gaussian_process.h:21);  sparse: s20 (src/sparse_gp.h:48) */
     double eps_tol;               /* sparse only: src/sparse_gp.hpp:30 (1e-6f), src/sparse_gp_field.hpp:16 (1e-4f) */
     int32_t capacity;             /* sparse only: max basis vectors; -1 = exact GP (src/sparse_gp.hpp:155,206) */
-    int32_t noise_model;          /* 0 gaussian_noise(_3d), 1 probit_noise (ny == 1 only; never instantiated upstream) */
+    int32_t noise_model;          /* 0 gaussian_noise(_3d); 1 probit_noise as written (src/probit_noise.cpp:11-31; its "Phi" is
+                                     erf(z)/(2.0f*sqrt(2.0f)), not a CDF); 2 probit_noise with Phi(z) = (1 + erf(z/sqrt 2))/2,
+                                     everything else as upstream.  1 and 2: ny == 1 only; never instantiated upstream */
     int32_t ref_double_noise;     /* dense: 1 = add sigman_sq twice like src/gaussian_process.cpp:19-22,59-61 */
     int32_t ref_field_delete_bug; /* sparse ny==3: 1 = multiply like src/sparse_gp_field.hpp:250-253, 0 = divide */
     int32_t want_variance;        /* dense: also compute V_star (src/gaussian_process.cpp:35-43) */
@@ -80,6 +82,12 @@ void gpc_default_params_sparse(gpc_params* p, int ny);
 int gpc_version(void);
 
 /* ---- context: one per process per GPU (owns the device workspace; thread-safe per context) ---------------- */
+/* Ownership: objects created from a context (gpc_sparse, gpc_patches) hold a reference on it and may be destroyed before
+ * OR after gpc_ctx_destroy, in any order -- neither order aborts or touches freed memory.  gpc_ctx_destroy synchronises
+ * the stream and releases the device workspace at once; from then on every call that takes the context, or one of its
+ * surviving children, returns GPC_EINVAL, except the children's own destroy functions, which release their device
+ * buffers as usual (the last one releases the context's host struct).  The context pointer itself must not be used
+ * again once it AND all its children have been destroyed. */
 typedef struct gpc_ctx gpc_ctx;
 int gpc_ctx_create(gpc_ctx** out, int device);
 /* hip_stream: a hipStream_t passed as void*, used as is (NULL is HIP's default stream); GPC_STREAM_OWN selects the
@@ -126,6 +134,44 @@ int gpc_dense_fit_predict_grid(gpc_ctx* ctx, const gpc_params* params, int P, co
 int gpc_dense_fit_predict_grid_dev(gpc_ctx* ctx, const gpc_params* params, int P, const int32_t* off, int n_max,
                                    int n_total, const double* x0, const double* x1, const double* y, int ny,
                                    double res, int sz, double* f_star, double* alpha_out, int32_t* status);
+
+/* ---- dense GP with the probit functor: Newton / IRLS loop on the GPU (BASELINE config 5) ---------------------------- */
+/* The reference never instantiates probit_noise and holds no IRLS loop (its occupancy map is a ray-cast boolean mask,
+ * src/gp_mapping.cpp:154-211): what it fixes is the Noise contract, q = dx_ln(y, x, sigma_x), r = dx2_ln(y, x, sigma_x)
+ * (src/probit_noise.cpp:11-31), and the kernel.  This entry runs the textbook loop those plug into -- Newton's method for
+ * the mode of p(f | y) with labels y = +-1 (Rasmussen & Williams 2006, Alg. 3.1) in IRLS form: with W = -r, g = q at
+ * sigma_x = 0, every step is one gaussian_process::add_measurements-style fit (src/gaussian_process.cpp:15-26) with
+ * per-point noise 1 / W_i and working targets t_i = f_i + g_i / W_i:
+ *     a = (K + W^-1)^-1 t,   f <- K a = t - W^-1 a;    start f = y * f_init;   stop: max_iter solves or max|df| <= tol.
+ * params: sigmaf_sq, l_sq (rbf_kernel, src/rbf_kernel.cpp:15-18), noise = s20 of the functor, noise_model = 1 (as written;
+ * singular at f = 0, needs f_init > 0) or 2 (proper CDF; f_init = 0 is the textbook start).  y: N labels.
+ * Prediction: latent mean f* = K*^T a on X* -- point-wise (xs0, xs1, m) or, when xs0 == NULL, the sz x sz grid of
+ * gp_compressor::load_compressed (res, sz; m is ignored).  f_star [P][m]; alpha_out [N] (= a), fhat_out [N] (the mode at the
+ * training points), iters [P] (solves performed) and status [P] may be NULL.  Status GPC_STATUS_NAN: a weight W_i was not
+ * finite and positive (with noise_model 1 this is the normal outcome when a step crosses f = 0); outputs of the patch are NaN.
+ * Definition and CPU restatement: oracle/gpc_oracle.c (orc_dense_irls_fit). */
+typedef struct gpc_irls_params {
+    int32_t max_iter;   /* >= 1 */
+    int32_t reserved;
+    double tol;         /* on max_i |f_new_i - f_i| */
+    double f_init;      /* f_i = y_i * f_init before the first step */
+} gpc_irls_params;
+/* max_iter 20, tol 1e-9, f_init 0 */
+void gpc_default_params_irls(gpc_irls_params* p);
+int gpc_dense_irls_fit_predict(gpc_ctx* ctx, const gpc_params* params, const gpc_irls_params* irls, int P, const int32_t* off,
+                               const double* x0, const double* x1, const double* y, int m, const double* xs0, const double* xs1,
+                               double res, int sz, double* f_star, double* alpha_out, double* fhat_out, int32_t* iters,
+                               int32_t* status);
+int gpc_dense_irls_fit_predict_dev(gpc_ctx* ctx, const gpc_params* params, const gpc_irls_params* irls, int P, const int32_t* off,
+                                   int n_max, int n_total, const double* x0, const double* x1, const double* y, int m,
+                                   const double* xs0, const double* xs1, double res, int sz, double* f_star, double* alpha_out,
+                                   double* fhat_out, int32_t* iters, int32_t* status);
+/* The Noise contract itself, evaluated on the DEVICE by the very functions the kernels inline (csrc/gpc_device.h):
+ * q[i] = dx_ln(y[i], x[i], sigma_x[i]), r[i] = dx2_ln(...) for noise_model 0 (src/gaussian_noise.cpp:9-18), 1 or 2
+ * (src/probit_noise.cpp:11-31).  Host pointers, n triples.  This is what pins the device functors to the compiled
+ * reference objects (tests/golden/noise_ref.json). */
+int gpc_noise_eval(gpc_ctx* ctx, int noise_model, double s20, int n, const double* y, const double* x, const double* sigma_x,
+                   double* q, double* r);
 
 /* ---- sparse online GP: sparse_gp<rbf_kernel, gaussian_noise> / sparse_gp_field<rbf_kernel, gaussian_noise_3d> */
 /* One handle holds the persistent state (alpha, C, Q, BV, current_size) of P independent patch GPs on the

@@ -94,6 +94,29 @@ double orc_probit_dx2_ln(double s20, double y, double x, double sigma_x)
     return (efprimprim / ef - first * first) / sigma2;
 }
 
+/* The fixed variant (noise_model 2): probit_noise with Phi(z) = (1 + erf(z / sqrt 2)) / 2 -- a CDF -- in place of
+ * erf(z)/(2.0f*sqrt(2.0f)) (src/probit_noise.cpp:15,26); every other operation as upstream. */
+double orc_probit_std_dx_ln(double s20, double y, double x, double sigma_x)
+{
+    double sigma = sqrt(s20 + sigma_x);
+    double z = y * x / sigma;
+    double ef = 0.5 * erfc(-z * 0.70710678118654752440);
+    double efprim = exp(-z * z / 2) / sqrt((double)2.0f * M_PI);
+    return y / sigma * efprim / ef;
+}
+
+double orc_probit_std_dx2_ln(double s20, double y, double x, double sigma_x)
+{
+    double sigma2 = s20 + sigma_x;
+    double sigma = sqrt(sigma2);
+    double z = y * x / sigma;
+    double ef = 0.5 * erfc(-z * 0.70710678118654752440);
+    double efprim = exp(-z * z / (double)2.0f) / sqrt((double)2.0f * M_PI);
+    double efprimprim = -z * efprim;
+    double first = efprim / ef;
+    return (efprimprim / ef - first * first) / sigma2;
+}
+
 /* ------------------------------------------------------------------ a6 - a8: dense GP */
 
 void orc_dense_default_params(orc_dense_params* p)
@@ -227,6 +250,126 @@ int orc_dense_fit_predict_batch(const orc_dense_params* p, int P, const int32_t*
         orc_dense_predict(p, n, x0 + o, x1 + o, L, alpha, ny, m, xs0, xs1, fs, v_star ? v_star + (size_t)i * m : NULL);
     }
     free(L); free(alpha); free(yb);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ C5: dense GP with the probit functor, IRLS loop
+ *
+ * BASELINE config 5 ("probit_noise occupancy-GP variant, IRLS inner loop").  The reference never instantiates
+ * probit_noise and holds no such loop: what it fixes is the Noise contract -- q = dx_ln(y, x, sigma_x) =
+ * d/dx ln P(y|x), r = dx2_ln(y, x, sigma_x) = d2/dx2 ln P(y|x) (src/probit_noise.cpp:11-31) -- and the kernel
+ * (src/rbf_kernel.cpp:15-18).  The loop below is the textbook one those two plug into: Newton's method for the mode of
+ * p(f | y) ~ prod_i P(y_i | f_i) N(f | 0, K), Rasmussen & Williams (2006) eq. 3.18, in its iteratively-reweighted
+ * least-squares form.  With W = -diag(r), g = q:
+ *        f_new = (K^-1 + W)^-1 (W f + g) = K (K + W^-1)^-1 (f + W^-1 g)
+ * i.e. every Newton step is ONE dense GP regression fit (gaussian_process::add_measurements, src/gaussian_process.cpp:15-26)
+ * with per-point noise d_i = 1 / W_i on the diagonal and working targets t_i = f_i + g_i d_i:
+ *        a = (K + diag d)^-1 t,   f_new = K a = t - d o a.
+ * The functor is called with sigma_x = 0 (Laplace: the latent value itself, no predictive variance), so sigma^2 = s20.
+ * Start f_i = y_i * f_init (f_init = 0 is R&W's start; the reference's "Phi" is singular at 0 and needs f_init > 0).
+ * Stop after max_iter solves or when max_i |f_new_i - f_i| <= tol.  A weight that is not finite and positive ends the
+ * patch with status 2 (the same NaN the reference's recursion would print, src/sparse_gp.hpp:245).
+ * Predictive latent mean: f* = K*^T a  (R&W eq. 3.21: k*^T grad log p(y | f^) = k*^T a at the mode).
+ * Returns 0 ok, 1 + j non-SPD pivot j, -2 NaN weight. */
+int orc_dense_irls_fit(const orc_dense_params* p, int noise_model, int n, const double* x0, const double* x1, const double* y,
+                       int max_iter, double tol, double f_init, double* alpha, double* fhat, int32_t* iters)
+{
+    *iters = 0;
+    if (n <= 0) return 0;
+    const size_t ld = (size_t)n;
+    double* K = (double*)malloc(sizeof(double) * ld * ld);      /* row-major lower triangle of the kernel matrix */
+    double* L = (double*)malloc(sizeof(double) * ld * ld);      /* row-major Cholesky factor */
+    double* d = (double*)malloc(sizeof(double) * ld * 2);
+    double* t = d + n;
+    if (!K || !L || !d) { free(K); free(L); free(d); return -12; }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) K[i * ld + j] = squared_exp_distance(p, x0[i], x1[i], x0[j], x1[j]);
+    for (int i = 0; i < n; ++i) fhat[i] = y[i] * f_init;
+    int rc = 0;
+    for (int it = 0; it < max_iter; ++it) {
+        for (int i = 0; i < n; ++i) {
+            double q, r;
+            if (noise_model == 2) {
+                q = orc_probit_std_dx_ln(p->sigman_sq, y[i], fhat[i], 0.0);
+                r = orc_probit_std_dx2_ln(p->sigman_sq, y[i], fhat[i], 0.0);
+            } else {
+                q = orc_probit_dx_ln(p->sigman_sq, y[i], fhat[i], 0.0);
+                r = orc_probit_dx2_ln(p->sigman_sq, y[i], fhat[i], 0.0);
+            }
+            const double W = -r;
+            if (!(W > 0.0) || !(W < INFINITY) || q != q) { rc = -2; break; }
+            d[i] = 1.0 / W;
+            t[i] = fhat[i] + q * d[i];
+        }
+        if (rc) break;
+        /* (K + diag d) = L L^T, row by row (Cholesky-Crout; dot products over contiguous rows) */
+        for (int i = 0; i < n && !rc; ++i) {
+            for (int j = 0; j <= i; ++j) {
+                double s = K[i * ld + j];
+                if (i == j) s += d[i];
+                const double* li = L + i * ld;
+                const double* lj = L + j * ld;
+                for (int k = 0; k < j; ++k) s -= li[k] * lj[k];
+                if (i == j) {
+                    if (!(s > 0.0)) { rc = 1 + i; break; }
+                    L[i * ld + i] = sqrt(s);
+                } else {
+                    L[i * ld + j] = s / L[j * ld + j];
+                }
+            }
+        }
+        if (rc) break;
+        for (int i = 0; i < n; ++i) {                              /* L z = t */
+            double s = t[i];
+            for (int k = 0; k < i; ++k) s -= L[i * ld + k] * alpha[k];
+            alpha[i] = s / L[i * ld + i];
+        }
+        for (int i = n - 1; i >= 0; --i) {                         /* L^T a = z */
+            double s = alpha[i];
+            for (int k = i + 1; k < n; ++k) s -= L[k * ld + i] * alpha[k];
+            alpha[i] = s / L[i * ld + i];
+        }
+        double delta = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double fn = t[i] - d[i] * alpha[i];
+            const double df = fabs(fn - fhat[i]);
+            if (df > delta || df != df) delta = df;
+            fhat[i] = fn;
+        }
+        *iters = it + 1;
+        if (delta != delta) { rc = -2; break; }
+        if (delta <= tol) break;
+    }
+    if (rc)
+        for (int i = 0; i < n; ++i) alpha[i] = fhat[i] = NAN;
+    free(K); free(L); free(d);
+    return rc;
+}
+
+/* batch driver, same shape as gpc_dense_irls_fit_predict (include/gpc.h); status: 0 ok, 1 non-SPD, 2 NaN */
+int orc_dense_irls_fit_predict_batch(const orc_dense_params* p, int noise_model, int max_iter, double tol, double f_init,
+                                     int P, const int32_t* off, const double* x0, const double* x1, const double* y,
+                                     int m, const double* xs0, const double* xs1, double* f_star, double* alpha_out,
+                                     double* fhat_out, int32_t* iters, int32_t* status)
+{
+    int nmax = 0;
+    for (int i = 0; i < P; ++i)
+        if (off[i + 1] - off[i] > nmax) nmax = off[i + 1] - off[i];
+    double* a = (double*)malloc(sizeof(double) * (size_t)(2 * nmax + 2));
+    if (!a) return -12;
+    double* fh = a + nmax + 1;
+    for (int i = 0; i < P; ++i) {
+        const int o = off[i], n = off[i + 1] - o;
+        int32_t it = 0;
+        const int rc = orc_dense_irls_fit(p, noise_model, n, x0 + o, x1 + o, y + o, max_iter, tol, f_init, a, fh, &it);
+        if (rc == -12) { free(a); return -12; }
+        if (status) status[i] = rc == 0 ? 0 : (rc > 0 ? 1 : 2);
+        if (iters) iters[i] = it;
+        if (alpha_out) memcpy(alpha_out + o, a, sizeof(double) * (size_t)n);
+        if (fhat_out) memcpy(fhat_out + o, fh, sizeof(double) * (size_t)n);
+        if (m > 0) orc_dense_predict(p, n, x0 + o, x1 + o, NULL, a, 1, m, xs0, xs1, f_star + (size_t)i * m, NULL);
+    }
+    free(a);
     return 0;
 }
 
@@ -417,6 +560,9 @@ void orc_sparse_add(orc_sparse* g, double x0, double x1, const double* y)
     if (ny == 1 && P->noise_model == 1) {
         r = orc_probit_dx2_ln(P->s20, y[0], m[0], s2);
         q[0] = orc_probit_dx_ln(P->s20, y[0], m[0], s2);
+    } else if (ny == 1 && P->noise_model == 2) {
+        r = orc_probit_std_dx2_ln(P->s20, y[0], m[0], s2);
+        q[0] = orc_probit_std_dx_ln(P->s20, y[0], m[0], s2);
     } else if (ny == 1) {
         r = orc_gaussian_dx2_ln(P->s20, y[0], m[0], s2);
         q[0] = orc_gaussian_dx_ln(P->s20, y[0], m[0], s2);

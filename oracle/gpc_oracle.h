@@ -73,6 +73,17 @@ void orc_dense_predict(const orc_dense_params* p, int n, const double* x0, const
                        const double* L, const double* alpha, int ny,
                        int m, const double* xs0, const double* xs1, double* f_star, double* v_star);
 
+/* ---- C5: dense GP + probit functor, Newton / IRLS loop (extension; definition in gpc_oracle.c).
+ * p->sigman_sq is s20 of the functor; noise_model 1 = probit_noise as written, 2 = with a proper CDF. */
+double orc_probit_std_dx_ln(double s20, double y, double x, double sigma_x);
+double orc_probit_std_dx2_ln(double s20, double y, double x, double sigma_x);
+int orc_dense_irls_fit(const orc_dense_params* p, int noise_model, int n, const double* x0, const double* x1, const double* y,
+                       int max_iter, double tol, double f_init, double* alpha, double* fhat, int32_t* iters);
+int orc_dense_irls_fit_predict_batch(const orc_dense_params* p, int noise_model, int max_iter, double tol, double f_init,
+                                     int P, const int32_t* off, const double* x0, const double* x1, const double* y,
+                                     int m, const double* xs0, const double* xs1, double* f_star, double* alpha_out,
+                                     double* fhat_out, int32_t* iters, int32_t* status);
+
 /* ---- a9-a13: sparse_gp / sparse_gp_field (src/sparse_gp.hpp, src/sparse_gp_field.hpp) */
 typedef struct {
     double p0, p1;        /* rbf_kernel params: sigmaf_sq, l_sq (rbf_kernel.h:24: 100, 1) */
@@ -80,7 +91,7 @@ typedef struct {
     double eps_tol;       /* sparse_gp.hpp:30 (1e-6f) / sparse_gp_field.hpp:16 (1e-4f) */
     int capacity;         /* 100 default; -1 = never sparse-update, never delete (exact GP) */
     int ny;               /* 1 = sparse_gp, 3 = sparse_gp_field */
-    int noise_model;      /* 0 gaussian, 1 probit (ny==1 only; F6 extension) */
+    int noise_model;      /* 0 gaussian, 1 probit as written, 2 probit with a proper CDF (ny==1 only; F6 extension) */
     int field_delete_bug; /* 1 = reproduce sparse_gp_field.hpp:250-253 (F8); only used when ny>1 */
 } orc_sparse_params;
 

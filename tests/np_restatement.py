@@ -229,3 +229,47 @@ def train_sigmaf_np(p0, p1, s20, alpha, Cm, BV, q0, q1, y, step, max_counter):
         if not np.sqrt(delta @ delta) > np.float64(np.float32(1e-2)):
             break
     return p0, it, ls, delta
+
+
+# ---------------------------------------------------------------- C5: Laplace mode of the probit GP, Rasmussen & Williams Alg. 3.1
+
+def probit_functor(y, f, s20, std_phi):
+    """q = dx_ln, r = dx2_ln of src/probit_noise.cpp:11-31 with sigma_x = 0 (vectorised); std_phi swaps in a proper CDF."""
+    from scipy.special import erf, erfc
+    sigma2 = s20
+    sigma = np.sqrt(sigma2)
+    z = y * f / sigma
+    if std_phi:
+        ef = 0.5 * erfc(-z / np.sqrt(2.0))
+    else:
+        ef = erf(z) / float(np.float32(2.0) * np.sqrt(np.float32(2.0)))
+    efp = np.exp(-z * z / 2) / np.sqrt(2.0 * np.pi)
+    first = efp / ef
+    return y / sigma * first, (-z * first - first * first) / sigma2
+
+
+def laplace_mode_rw(X, y, p0, p1, s20, std_phi=True, f_init=0.0, max_iter=20, tol=1e-9):
+    """Algorithm 3.1 of Rasmussen & Williams (2006) as printed -- B = I + W^1/2 K W^1/2, b = W f + grad,
+    a = b - W^1/2 B^-1 W^1/2 K b, f = K a -- i.e. a DIFFERENT algebraic route to the Newton iterate than the
+    (K + W^-1)^-1 form of the oracle and the GPU kernel.  Same start (f = y f_init) and stopping rule.
+    Returns fhat, a, iters."""
+    from scipy.linalg import cho_factor, cho_solve
+    n = X.shape[0]
+    K = rbf(p0, p1, X, X)
+    f = y * f_init
+    a = np.zeros(n)
+    it = 0
+    for it in range(1, max_iter + 1):
+        g, r = probit_functor(y, f, s20, std_phi)
+        W = -r
+        sW = np.sqrt(W)
+        B = np.eye(n) + sW[:, None] * K * sW[None, :]
+        cf = cho_factor(B, lower=True)
+        b = W * f + g
+        a = b - sW * cho_solve(cf, sW * (K @ b))
+        fn = K @ a
+        delta = np.max(np.abs(fn - f))
+        f = fn
+        if delta <= tol:
+            break
+    return f, a, it

@@ -91,10 +91,14 @@ def _bind(L):
     L.orc_rbf_kernel.argtypes = [d] * 6
     L.orc_rbf_construct_covariance_fast.restype = None
     L.orc_rbf_construct_covariance_fast.argtypes = [d, d, C.c_int, c_dp, c_dp, C.c_int, c_dp, c_dp]
-    for n in ("orc_gaussian_dx_ln", "orc_gaussian_dx2_ln", "orc_probit_dx_ln", "orc_probit_dx2_ln"):
+    for n in ("orc_gaussian_dx_ln", "orc_gaussian_dx2_ln", "orc_probit_dx_ln", "orc_probit_dx2_ln",
+              "orc_probit_std_dx_ln", "orc_probit_std_dx2_ln"):
         f = getattr(L, n)
         f.restype = d
         f.argtypes = [d] * 4
+    L.orc_dense_irls_fit_predict_batch.restype = C.c_int
+    L.orc_dense_irls_fit_predict_batch.argtypes = [C.POINTER(DenseParams), C.c_int, C.c_int, d, d, C.c_int, c_ip, c_dp, c_dp, c_dp,
+                                                   C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip]
     L.orc_gaussian3d_dx_ln.restype = None
     L.orc_gaussian3d_dx_ln.argtypes = [d, C.c_int, c_dp, c_dp, d, c_dp]
     L.orc_gaussian3d_dx2_ln.restype = d
@@ -205,6 +209,26 @@ def dense_fit_predict_batch(p, off, x0, x1, y, xs0, xs1, variance=False, fast=Fa
     if want_alpha:
         return f, v, st, al
     return f, v, st
+
+
+def dense_irls_fit_predict_batch(p, noise_model, off, x0, x1, y, xs0, xs1, max_iter=20, tol=1e-9, f_init=0.0, fast=False):
+    """BASELINE config 5 (dense GP + probit functor, Newton / IRLS loop; oracle/gpc_oracle.c).  p.sigman_sq is s20.
+    y: (N,) labels.  Returns f_star (P, m), alpha (N,), fhat (N,), iters (P,), status (P,)."""
+    off = np.ascontiguousarray(off, dtype=np.int32)
+    P = off.shape[0] - 1
+    y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+    m = xs0.shape[0]
+    f = np.zeros((P, m))
+    al = np.zeros_like(y)
+    fh = np.zeros_like(y)
+    it = np.zeros(P, dtype=np.int32)
+    st = np.zeros(P, dtype=np.int32)
+    rc = lib(fast).orc_dense_irls_fit_predict_batch(C.byref(p), int(noise_model), int(max_iter), float(tol), float(f_init), P,
+                                                    _ip(off), _dp(np.ascontiguousarray(x0)), _dp(np.ascontiguousarray(x1)), _dp(y), m,
+                                                    _dp(np.ascontiguousarray(xs0)), _dp(np.ascontiguousarray(xs1)), _dp(f), _dp(al),
+                                                    _dp(fh), _ip(it), _ip(st))
+    assert rc == 0
+    return f, al, fh, it, st
 
 
 class Sparse:

@@ -473,3 +473,57 @@ def test_sparse_train_sigmaf(oracle):
     g.add_measurements(x0, x1, y[None, :])
     po, it, ls, delta = g.train_sigmaf(x0, x1, y)
     assert (po, it) == (1.0, 0) and np.all(ls == 0)
+
+
+# ------------------------------------------------------------------ C5: dense GP + probit functor, Newton / IRLS loop
+
+@pytest.mark.parametrize("model,f_init", [(2, 0.0), (2, 0.5), (1, 0.25)])
+def test_irls_oracle_vs_rasmussen_williams_alg31(oracle, model, f_init):
+    """The IRLS form of the oracle, a = (K + W^-1)^-1 (f + W^-1 g), against Algorithm 3.1 of Rasmussen & Williams as
+    printed (B = I + W^1/2 K W^1/2; NumPy / LAPACK): a different algebraic route to the same Newton iterates.  Same
+    iteration counts, mode and a to 1e-10; the mode is a fixed point f = K g(f)."""
+    res = 0.15
+    xs0, xs1 = oracle.grid(res, 20)
+    for n in (1, 37, 128, 300):
+        off, x0, x1, y = synth.make_patches(2, n, res=res, seed=5 + n)
+        lab = synth.occupancy_labels(off, y[0])
+        p = oracle.dense_params(sigmaf_sq=1.0, l_sq=(res / 3) ** 2, sigman_sq=0.25)
+        f, al, fh, it, st = oracle.dense_irls_fit_predict_batch(p, model, off, x0, x1, lab, xs0, xs1, max_iter=30, tol=1e-10, f_init=f_init)
+        assert np.all(st == 0)
+        for i in range(2):
+            sl = slice(off[i], off[i + 1])
+            X = np.stack([x0[sl], x1[sl]], 1)
+            fr, ar, ir = R.laplace_mode_rw(X, lab[sl], 1.0, (res / 3) ** 2, 0.25, std_phi=(model == 2), f_init=f_init, max_iter=30, tol=1e-10)
+            assert ir == it[i]
+            assert np.max(np.abs(fr - fh[sl])) <= 1e-10 * np.max(np.abs(fr))
+            assert np.max(np.abs(ar - al[sl])) <= 1e-9 * np.max(np.abs(ar))
+            g, _ = R.probit_functor(lab[sl], fh[sl], 0.25, model == 2)
+            K = R.rbf(1.0, (res / 3) ** 2, X, X)
+            assert np.max(np.abs(K @ g - fh[sl])) <= 1e-8 * np.max(np.abs(fh[sl]))
+            Ks = R.rbf(1.0, (res / 3) ** 2, X, np.stack([xs0, xs1], 1))
+            assert np.max(np.abs(al[sl] @ Ks - f[i])) <= 1e-12 * max(np.max(np.abs(f[i])), 1e-9)
+
+
+def test_irls_oracle_edge_cases(oracle):
+    """empty patch; the reference's "Phi" from the textbook start f = 0 is singular (erf(0) = 0): status 2, NaN outputs;
+    the CDF functor against scipy's log_ndtr derivative."""
+    from scipy.special import log_ndtr
+    res = 0.15
+    xs0, xs1 = oracle.grid(res, 4)
+    off, x0, x1, y = synth.make_patches(2, 20, res=res, seed=3)
+    lab = synth.occupancy_labels(off, y[0])
+    off2 = np.array([0, 0, 20, 40], dtype=np.int32)
+    p = oracle.dense_params(sigmaf_sq=1.0, l_sq=(res / 3) ** 2, sigman_sq=0.25)
+    f, al, fh, it, st = oracle.dense_irls_fit_predict_batch(p, 2, off2, x0, x1, lab, xs0, xs1)
+    assert st.tolist() == [0, 0, 0] and it[0] == 0 and np.all(f[0] == 0)
+    f, al, fh, it, st = oracle.dense_irls_fit_predict_batch(p, 1, off, x0, x1, lab, xs0, xs1, f_init=0.0)
+    assert st.tolist() == [2, 2] and np.all(np.isnan(f))
+    L = oracle.lib()
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        yy, x, sx, s20 = rng.choice([-1.0, 1.0]), rng.normal(0, 2), rng.uniform(0, 2), rng.uniform(0.05, 2)
+        sig, h = np.sqrt(s20 + sx), 1e-5
+        fd = (log_ndtr(yy * (x + h) / sig) - log_ndtr(yy * (x - h) / sig)) / (2 * h)
+        fd2 = (log_ndtr(yy * (x + h) / sig) - 2 * log_ndtr(yy * x / sig) + log_ndtr(yy * (x - h) / sig)) / (h * h)
+        assert abs(L.orc_probit_std_dx_ln(s20, yy, x, sx) - fd) <= 1e-6 * max(abs(fd), 1e-3)
+        assert abs(L.orc_probit_std_dx2_ln(s20, yy, x, sx) - fd2) <= 1e-4 * max(abs(fd2), 1e-2)

@@ -1,0 +1,365 @@
+"""GPU parity tests of the probit path (BASELINE config 5) through the C-ABI.
+
+Three layers, from the only reference-pinned numbers outwards:
+  1. the device's own dx_ln / dx2_ln (csrc/gpc_device.h, the functions every kernel inlines) against the outputs of the
+     reference's compiled gaussian_noise.cpp / probit_noise.cpp objects held in tests/golden/noise_ref.json.
+     Stated tolerance: Gaussian bit-exact (two IEEE operations); probit <= 8 ulp (the device's erf / exp are ocml's, the
+     reference's are glibc's: each is faithful to ~1 ulp and the quotient chain of src/probit_noise.cpp:15-17 carries them).
+  2. sparse_gp<rbf_kernel, probit_noise> -- the plug point of SURVEY F6 -- on the GPU against oracle.Sparse(noise_model):
+     identical basis bookkeeping and f*, sigma within 2e-5 (the sparse tolerance of tests/test_sparse_gpu.py) wherever the
+     recursion stays finite; where it does not (with the reference's "Phi" it NaNs within a few points, tests/test_oracle.py)
+     the GPU must report GPC_STATUS_NAN for exactly the patches whose oracle state is NaN.
+  3. the dense Newton / IRLS loop (gpc_dense_irls_fit_predict) against oracle orc_dense_irls_fit and, at the full
+     config-5 size, through size-independent properties: the mode is a fixed point f = K g(f), a = g(f).
+     Stated tolerance: f*, fhat, alpha within 1e-8 of their max-norm (Newton contracts rounding differences; the
+     oracle itself agrees with an independent R&W Alg. 3.1 restatement to 1e-11, tests/test_oracle.py).
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gp_compressor_amd import synth
+import np_restatement as R
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RES = 0.15
+
+
+@pytest.fixture(scope="module")
+def gp():
+    from gp_compressor_amd import capi
+    capi.load()
+    ctx = capi.Context(0)
+    yield capi, ctx
+    ctx.close()
+
+
+def _ulps(a, b):
+    return np.abs(a - b) / np.spacing(np.maximum(np.abs(a), np.abs(b)))
+
+
+# ------------------------------------------------------------------ 1. device functors vs the compiled reference objects
+
+def test_device_noise_functors_match_reference_golden(gp):
+    capi, ctx = gp
+    with open(os.path.join(GOLD, "noise_ref.json")) as f:
+        rows = json.load(f)["rows"]
+    cols = {k: np.array([float.fromhex(r[k]) for r in rows]) for k in
+            ("s20", "y", "x", "sigma_x", "gaussian_dx_ln", "gaussian_dx2_ln", "probit_dx_ln", "probit_dx2_ln")}
+    worst = 0.0
+    for s20 in np.unique(cols["s20"]):
+        sel = cols["s20"] == s20
+        y, x, sx = cols["y"][sel], cols["x"][sel], cols["sigma_x"][sel]
+        q, r = ctx.noise_eval(0, s20, y, x, sx)
+        assert np.array_equal(q, cols["gaussian_dx_ln"][sel]) and np.array_equal(r, cols["gaussian_dx2_ln"][sel])
+        q, r = ctx.noise_eval(1, s20, y, x, sx)
+        assert np.all(np.isfinite(q)) and np.all(np.isfinite(r))
+        worst = max(worst, float(np.max(_ulps(q, cols["probit_dx_ln"][sel]))), float(np.max(_ulps(r, cols["probit_dx2_ln"][sel]))))
+    print(f"probit functors on the device vs the compiled reference objects: worst {worst:.1f} ulp over {len(rows)} rows")
+    assert worst <= 8.0
+
+
+def test_device_probit_std_functor_vs_oracle_and_scipy(gp, oracle):
+    """noise_model 2 (the CDF fix) has no reference object: the device against the oracle's C and against scipy's log_ndtr
+    derivatives (d/dx ln Phi(y x / sigma))."""
+    from scipy.special import log_ndtr
+    capi, ctx = gp
+    rng = np.random.default_rng(3)
+    n = 4000
+    y = rng.choice([-1.0, 1.0], n)
+    x = rng.normal(0, 2.0, n)
+    sx = rng.uniform(0, 3, n)
+    s20 = 0.3
+    q, r = ctx.noise_eval(2, s20, y, x, sx)
+    L = oracle.lib()
+    qo = np.array([L.orc_probit_std_dx_ln(s20, y[i], x[i], sx[i]) for i in range(n)])
+    ro = np.array([L.orc_probit_std_dx2_ln(s20, y[i], x[i], sx[i]) for i in range(n)])
+    assert np.max(_ulps(q, qo)) <= 8 and np.max(np.abs(r - ro) / np.abs(ro)) <= 1e-12   # r cancels z*first against first^2
+    sig = np.sqrt(s20 + sx)
+    h = 1e-5
+    fd = (log_ndtr(y * (x + h) / sig) - log_ndtr(y * (x - h) / sig)) / (2 * h)
+    assert np.max(np.abs(q - fd) / np.maximum(np.abs(fd), 1e-3)) <= 1e-6
+
+
+# ------------------------------------------------------------------ 2. sparse_gp<rbf_kernel, probit_noise> on the GPU
+
+def _labels(off, y):
+    return synth.occupancy_labels(off, y[0])
+
+
+def _oracle_sparse(oracle, kw, cap, x0, x1, lab, perm=None):
+    g = oracle.Sparse(oracle.sparse_params(1, **kw), cap + 2)
+    g.add_measurements(x0, x1, lab[None, :], perm)
+    return g
+
+
+@pytest.mark.parametrize("cap,lfac,s20", [(10, 4, 0.05), (20, 2, 1.0), (40, 6, 0.5)])
+def test_sparse_probit_std_vs_oracle(gp, oracle, cap, lfac, s20):
+    """the CDF variant stays finite: full parity (bookkeeping exact, values to the sparse tolerance), two add calls"""
+    capi, ctx = gp
+    P, n = 12, 96
+    off, x0, x1, y = synth.make_patches(P, n, res=RES, seed=41 + cap, ragged=True)
+    lab = _labels(off, y)
+    perm = synth.sattolo_perms(off, seed=5)
+    kw = dict(p0=1.0, p1=(RES / lfac) ** 2, s20=s20, capacity=cap, noise_model=2)
+    p = capi.default_params_sparse(1, sigmaf_sq=1.0, l_sq=kw["p1"], noise=s20, capacity=cap, noise_model=2)
+    g = capi.Sparse(ctx, p, P, 1)
+    st = g.add(off, x0, x1, lab[None, :], perm)
+    xs0, xs1 = synth.grid(RES, 20)
+    f, s, st2 = g.predict(xs0, xs1)
+    sizes = g.sizes()
+    alpha, Cm, Qm, BV = g.state()
+    assert np.all(st == 0)
+    for i in range(P):
+        sl = slice(off[i], off[i + 1])
+        h = _oracle_sparse(oracle, kw, cap, x0[sl], x1[sl], lab[sl], perm[sl])
+        b = h.size()
+        assert sizes[i] == b
+        fo, so = h.predict(xs0, xs1)
+        ao, Co, Qo, BVo = h.state()
+        assert np.array_equal(BV[i, :b], BVo)
+        scale = max(np.max(np.abs(fo)), 1e-6)
+        assert np.max(np.abs(f[i] - fo)) <= 2e-5 * scale
+        assert np.max(np.abs(s[i] - so)) <= 2e-5 * max(np.max(so), 1.0)
+        assert np.max(np.abs(alpha[i, 0, :b] - ao[0])) <= 2e-5 * np.max(np.abs(ao))
+    g.close()
+
+
+def _first_nonfinite(oracle, kw, cap, x0, x1, lab):
+    h = oracle.Sparse(oracle.sparse_params(1, **kw), cap + 2)
+    for j in range(len(x0)):
+        h.add(x0[j], x1[j], lab[j])
+        if not np.all(np.isfinite(h.state()[0])):
+            return j
+    return len(x0)
+
+
+def test_sparse_probit_ref_nan_status_matches_oracle(gp, oracle):
+    """probit_noise as written: its "Phi" = erf(z)/(2 sqrt 2) is not a CDF and the recursion NaNs within a few
+    points.  (a) In a well-conditioned regime the GPU reports GPC_STATUS_NAN for exactly the patches whose oracle state went
+    NaN (all of them) and its state is NaN too; (b) the finite prefixes -- every point before the one that breaks the oracle
+    -- agree with the oracle state like any other sparse case; (c) the few sequences that survive all 64 points (constant
+    labels, the regime of the reference's default hyper-parameters) finish with status OK and the same f* to the 1e-2
+    of test_sparse_golden[defaults]: there the sparse-vs-full branch flips on rounding noise, so basis counts are not compared."""
+    capi, ctx = gp
+    P, n, cap = 16, 64, 10
+    xs0, xs1 = synth.grid(RES, 20)
+    # (a) + (b): well-conditioned, mixed labels
+    kw = dict(p0=1.0, p1=(RES / 4) ** 2, s20=0.05, capacity=cap, noise_model=1)
+    off, x0, x1, y = synth.make_patches(P, n, res=RES, seed=100)
+    lab = _labels(off, y)
+    p = capi.default_params_sparse(1, sigmaf_sq=kw["p0"], l_sq=kw["p1"], noise=kw["s20"], capacity=cap, noise_model=1)
+    g = capi.Sparse(ctx, p, P, 1)
+    st = g.add(off, x0, x1, lab[None, :])
+    alpha = g.state()[0]
+    sizes = g.sizes()
+    first_bad = np.zeros(P, dtype=np.int64)
+    for i in range(P):
+        sl = slice(off[i], off[i + 1])
+        first_bad[i] = _first_nonfinite(oracle, kw, cap, x0[sl], x1[sl], lab[sl])
+        nan_oracle = first_bad[i] < n
+        assert (st[i] == capi.STATUS_NAN) == nan_oracle, (i, st[i], first_bad[i])
+        if nan_oracle:
+            assert not np.all(np.isfinite(alpha[i, 0, :max(int(sizes[i]), 1)]))
+    assert np.sum(first_bad < n) >= P - 2 and first_bad.max() <= 8      # within a few points, as tests/test_oracle.py found
+    g.close()
+    keep = np.maximum(first_bad, 1)
+    off2 = np.zeros(P + 1, dtype=np.int32)
+    off2[1:] = np.cumsum(keep)
+    idx = np.concatenate([np.arange(off[i], off[i] + keep[i]) for i in range(P)])
+    g = capi.Sparse(ctx, p, P, 1)
+    st = g.add(off2, x0[idx], x1[idx], lab[idx][None, :])
+    alpha, Cm, Qm, BV = g.state()
+    sizes = g.sizes()
+    for i in range(P):
+        sl = idx[off2[i]:off2[i + 1]]
+        h = _oracle_sparse(oracle, kw, cap, x0[sl], x1[sl], lab[sl])
+        ao, Co, Qo, BVo = h.state()
+        b = h.size()
+        assert st[i] == capi.STATUS_OK and sizes[i] == b and np.all(np.isfinite(ao))
+        assert np.max(np.abs(alpha[i, 0, :b] - ao[0])) <= 1e-9 * np.max(np.abs(ao))
+        assert np.max(np.abs(Cm[i, :b, :b] - Co)) <= 1e-9 * np.max(np.abs(Co))
+        assert np.array_equal(BV[i, :b], BVo)
+    g.close()
+    # (c) survivors
+    cap = 16
+    kw = dict(p0=100.0, p1=(RES / 0.15) ** 2, s20=0.1, capacity=cap, noise_model=1)
+    lab = np.ones(P * n)
+    p = capi.default_params_sparse(1, sigmaf_sq=kw["p0"], l_sq=kw["p1"], noise=kw["s20"], capacity=cap, noise_model=1)
+    g = capi.Sparse(ctx, p, P, 1)
+    st = g.add(off, x0, x1, lab[None, :])
+    f, s, _ = g.predict(xs0, xs1)
+    n_fin = 0
+    for i in range(P):
+        sl = slice(off[i], off[i + 1])
+        if _first_nonfinite(oracle, kw, cap, x0[sl], x1[sl], lab[sl]) < n:
+            continue
+        n_fin += 1
+        h = _oracle_sparse(oracle, kw, cap, x0[sl], x1[sl], lab[sl])
+        fo, so = h.predict(xs0, xs1)
+        assert st[i] == capi.STATUS_OK
+        assert np.max(np.abs(f[i] - fo)) <= 1e-2 * max(np.max(np.abs(fo)), 1e-6)
+    assert n_fin >= 1
+    g.close()
+
+
+# ------------------------------------------------------------------ 3. the dense Newton / IRLS loop (BASELINE config 5)
+
+def _irls_inputs(P, n, seed, ragged=False):
+    off, x0, x1, y = synth.make_patches(P, n, res=RES, seed=seed, ragged=ragged)
+    return off, x0, x1, synth.occupancy_labels(off, y[0])
+
+
+@pytest.mark.parametrize("n,model,f_init", [(1, 2, 0.0), (37, 2, 0.0), (128, 2, 0.0), (256, 2, 0.25), (300, 2, 0.0), (600, 2, 0.0),
+                                            (37, 1, 0.25), (300, 1, 0.25)])
+def test_irls_vs_oracle(gp, oracle, n, model, f_init):
+    capi, ctx = gp
+    P = 6
+    off, x0, x1, lab = _irls_inputs(P, n, seed=7 + n, ragged=n > 40)
+    s20, l_sq = 0.25, (RES / 3) ** 2
+    p = capi.default_params_dense(sigmaf_sq=1.0, l_sq=l_sq, noise=s20, noise_model=model)
+    # model 1: 1 / W reaches 1e4 at well-classified points, so f_new = t - d o a cancels to ~1e-9 absolute -- a tolerance below
+    # that noise floor is met or missed by rounding luck (the oracle meets 1e-10 here, the GPU does not)
+    tol = 1e-10 if model == 2 else 1e-7
+    ir = capi.default_params_irls(max_iter=30, tol=tol, f_init=f_init)
+    xs0, xs1 = synth.grid(RES, 20)
+    f, al, fh, it, st = ctx.dense_irls_fit_predict(p, ir, off, x0, x1, lab, res=RES, sz=20)
+    assert ctx.last_dense_kernel().endswith("_irls")
+    op = oracle.dense_params(sigmaf_sq=1.0, l_sq=l_sq, sigman_sq=s20)
+    fo, alo, fho, ito, sto = oracle.dense_irls_fit_predict_batch(op, model, off, x0, x1, lab, xs0, xs1, max_iter=30, tol=tol,
+                                                                 f_init=f_init)
+    assert np.array_equal(st, sto)
+    ok = sto == 0
+    assert np.all(np.abs(it[ok] - ito[ok]) <= 1) and ok.sum() >= P - 1
+    for i in np.nonzero(ok)[0]:
+        sl = slice(off[i], off[i + 1])
+        ftol = 1e-8 if model == 2 else 1e-6
+        assert np.max(np.abs(f[i] - fo[i])) <= ftol * max(np.max(np.abs(fo[i])), 1e-6)
+        assert np.max(np.abs(fh[sl] - fho[sl])) <= ftol * np.max(np.abs(fho[sl]))
+        assert np.max(np.abs(al[sl] - alo[sl])) <= ftol * np.max(np.abs(alo[sl]))
+    # point-wise X* entry gives the same latent mean as the separable grid
+    f2, *_ = ctx.dense_irls_fit_predict(p, ir, off, x0, x1, lab, xs0=xs0, xs1=xs1)
+    assert np.nanmax(np.abs(f2 - f)) <= 1e-11 * max(np.nanmax(np.abs(f)), 1e-6)
+
+
+def test_irls_known_answers(gp):
+    """closed forms: (i) one point: the mode solves f = k g(f) (scalar, bisection); (ii) max_iter = 1 from f = 0 with the
+    CDF variant is ONE Gaussian regression with noise pi/2 s20 and targets sqrt(pi/2) sigma y -- compared with the Gaussian
+    dense entry of the same library (which has its own oracle parity) and LAPACK."""
+    from scipy.special import erfc
+    capi, ctx = gp
+    s20, l_sq, sf = 0.5, (RES / 2) ** 2, 2.0
+    p = capi.default_params_dense(sigmaf_sq=sf, l_sq=l_sq, noise=s20, noise_model=2)
+    # (i)
+    off = np.array([0, 1], dtype=np.int32)
+    x0, x1, lab = np.array([0.01]), np.array([-0.02]), np.array([1.0])
+    f, al, fh, it, st = ctx.dense_irls_fit_predict(p, capi.default_params_irls(max_iter=50, tol=1e-14), off, x0, x1, lab,
+                                                   xs0=x0.copy(), xs1=x1.copy())
+    sig = np.sqrt(s20)
+
+    def g(fv):
+        z = fv / sig
+        return np.exp(-z * z / 2) / np.sqrt(2 * np.pi) / (0.5 * erfc(-z / np.sqrt(2))) / sig
+    lo, hi = 0.0, 10.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if mid - sf * g(mid) < 0 else (lo, mid)
+    assert st[0] == 0 and abs(fh[0] - lo) <= 1e-12 and abs(f[0, 0] - lo) <= 1e-12 and abs(al[0] - g(lo)) <= 1e-12
+    # (ii)
+    off, x0, x1, lab = _irls_inputs(3, 200, seed=12)
+    f, al, fh, it, st = ctx.dense_irls_fit_predict(p, capi.default_params_irls(max_iter=1, tol=0.0), off, x0, x1, lab, res=RES, sz=20)
+    assert np.all(it == 1) and np.all(st == 0)
+    pg = capi.default_params_dense(sigmaf_sq=sf, l_sq=l_sq, noise=np.pi / 2 * s20, ref_double_noise=0)
+    fg, stg = ctx.dense_fit_predict_grid(pg, off, x0, x1, (np.sqrt(np.pi / 2) * sig * lab)[None, :], RES, 20)
+    assert np.max(np.abs(f - fg[:, 0, :])) <= 1e-10 * np.max(np.abs(fg))
+    X = np.stack([x0[:200], x1[:200]], 1)
+    K = R.rbf(sf, l_sq, X, X)
+    a = np.linalg.solve(K + np.pi / 2 * s20 * np.eye(200), np.sqrt(np.pi / 2) * sig * lab[:200])
+    assert np.max(np.abs(al[:200] - a)) <= 1e-9 * np.max(np.abs(a))
+
+
+def test_irls_full_config5_properties(gp, oracle):
+    """BASELINE config 5 at full size: 4096 patches x 1024 labelled points, CDF variant.  Size-independent properties on
+    every patch (status, iteration count, y f > 0 for most points), the fixed-point conditions on a sample
+    (f = K g(f) and a = g(f), evaluated in NumPy from the kernel definition), and the oracle on two patches."""
+    capi, ctx = gp
+    import torch
+    P, n = 4096, 1024
+    off, x0, x1, lab = _irls_inputs(P, n, seed=5)
+    s20, l_sq, sf = 0.25, (RES / 3) ** 2, 1.0
+    p = capi.default_params_dense(sigmaf_sq=sf, l_sq=l_sq, noise=s20, noise_model=2)
+    ir = capi.default_params_irls(max_iter=20, tol=1e-9)
+    dev = torch.device("cuda:0")
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    d_off, d_x0, d_x1, d_y = t(off, torch.int32), t(x0, torch.float64), t(x1, torch.float64), t(lab, torch.float64)
+    d_f = torch.empty(P * 400, dtype=torch.float64, device=dev)
+    d_al = torch.empty(P * n, dtype=torch.float64, device=dev)
+    d_fh = torch.empty(P * n, dtype=torch.float64, device=dev)
+    d_it = torch.empty(P, dtype=torch.int32, device=dev)
+    d_st = torch.empty(P, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.dense_irls_fit_predict_dev(p, ir, P, d_off, n, P * n, d_x0, d_x1, d_y, 400, None, None, RES, 20, d_f, d_al, d_fh, d_it, d_st)
+    ctx.synchronize()
+    assert ctx.last_dense_kernel() == "dense_mfma_big_irls"
+    f, al, fh = d_f.cpu().numpy().reshape(P, 400), d_al.cpu().numpy(), d_fh.cpu().numpy()
+    it, st = d_it.cpu().numpy(), d_st.cpu().numpy()
+    assert np.all(st == 0) and np.all(np.isfinite(f)) and np.all(np.isfinite(al))
+    assert it.min() >= 3 and it.max() < 20, (it.min(), it.max())       # converged before the cap everywhere
+    assert np.mean(lab * fh > 0) > 0.8                                  # the mode sides with its labels
+    xs0, xs1 = synth.grid(RES, 20)
+    for i in (0, 1, 1777, 4095):
+        sl = slice(off[i], off[i + 1])
+        X = np.stack([x0[sl], x1[sl]], 1)
+        gq, _ = R.probit_functor(lab[sl], fh[sl], s20, True)
+        K = R.rbf(sf, l_sq, X, X)
+        assert np.max(np.abs(al[sl] - gq)) <= 1e-7 * np.max(np.abs(gq))               # a = grad log p(y | f) at the mode
+        assert np.max(np.abs(K @ gq - fh[sl])) <= 1e-7 * np.max(np.abs(fh[sl]))       # f = K grad log p(y | f)
+        Ks = R.rbf(sf, l_sq, X, np.stack([xs0, xs1], 1))
+        assert np.max(np.abs(al[sl] @ Ks - f[i])) <= 1e-10 * np.max(np.abs(f[i]))     # f* = K*^T a
+    sel = np.array([3, 2048])
+    op = oracle.dense_params(sigmaf_sq=sf, l_sq=l_sq, sigman_sq=s20)
+    off_s = np.array([0, n, 2 * n], dtype=np.int32)
+    idx = np.concatenate([np.arange(off[i], off[i + 1]) for i in sel])
+    fo, alo, fho, ito, sto = oracle.dense_irls_fit_predict_batch(op, 2, off_s, x0[idx], x1[idx], lab[idx], xs0, xs1, max_iter=20, tol=1e-9,
+                                                                 fast=True)
+    for k, i in enumerate(sel):
+        assert sto[k] == 0 and abs(int(ito[k]) - int(it[i])) <= 1
+        assert np.max(np.abs(f[i] - fo[k])) <= 1e-8 * np.max(np.abs(fo[k]))
+
+
+# ------------------------------------------------------------------ destroy order through the raw C-ABI
+
+def test_destroy_context_before_its_children_is_safe(gp):
+    """The failure of round 1 (gpurun_out/pytest_r1d.log: abort inside gpc_sparse_destroy after its context was freed):
+    through raw ctypes, bypassing the Python wrapper's bookkeeping, destroy the context FIRST, then use and destroy the
+    children.  Calls on orphans return GPC_EINVAL; nothing aborts."""
+    capi, _ = gp
+    lib = capi.load()
+    h = C.c_void_p()
+    assert lib.gpc_ctx_create(C.byref(h), 0) == 0
+    p = capi.default_params_sparse(1, capacity=8)
+    g1, g2 = C.c_void_p(), C.c_void_p()
+    assert lib.gpc_sparse_create(h, C.byref(p), 4, 1, C.byref(g1)) == 0
+    assert lib.gpc_sparse_create(h, C.byref(p), 2, 1, C.byref(g2)) == 0
+    cloud = np.zeros(64, dtype=capi.Context.POINT_DTYPE)
+    cloud["x"] = np.linspace(0, 1, 64)
+    pt = C.c_void_p()
+    assert lib.gpc_project_cloud(h, cloud.ctypes.data, 64, 0.15, 20, C.byref(pt)) == 0
+    off = np.array([0, 1, 2, 3, 4], dtype=np.int32)
+    v = np.zeros(4)
+    assert lib.gpc_sparse_add(g1, off.ctypes.data, v.ctypes.data, v.ctypes.data, v.ctypes.data, None, None) == 0
+    lib.gpc_sparse_destroy(g2)                 # the right order for one child ...
+    lib.gpc_ctx_destroy(h)                     # ... the context before the other two
+    sizes = np.zeros(4, dtype=np.int32)
+    assert lib.gpc_sparse_sizes(g1, sizes.ctypes.data) == capi.GPC_EINVAL
+    assert lib.gpc_sparse_add(g1, off.ctypes.data, v.ctypes.data, v.ctypes.data, v.ctypes.data, None, None) == capi.GPC_EINVAL
+    assert lib.gpc_patches_fetch(pt, *([None] * 10)) == capi.GPC_EINVAL
+    g3 = C.c_void_p()
+    assert lib.gpc_sparse_create(h, C.byref(p), 1, 1, C.byref(g3)) == capi.GPC_EINVAL
+    lib.gpc_ctx_destroy(h)                     # a second destroy of a context that still has children is a no-op
+    lib.gpc_sparse_destroy(g1)
+    lib.gpc_patches_destroy(pt)                # the last child releases the context struct
