@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the per-patch GP hot path on MI355X (contract: see the task's bench section).
 
-Workload (BASELINE.json configs[1], "C2"): a 1M-point synthetic room scan = 8192 octree-leaf patches x 256 points
-per GPU, RBF kernel + Gaussian noise, batched Cholesky fit and predictive mean on the 20 x 20 decompression grid
-(m = 400) -- i.e. gp_compressor::train_processes + the patch loop of load_compressed
+Headline workload (BASELINE.json configs[1], "C2"): a 1M-point synthetic room scan = 8192 octree-leaf patches x 256
+points per GPU, RBF kernel + Gaussian noise, batched Cholesky fit and predictive mean on the 20 x 20 decompression
+grid (m = 400) -- i.e. gp_compressor::train_processes + the patch loop of load_compressed
 (/root/reference/src/gp_compressor.cpp:121-175, 298-380) with the dense gaussian_process model
 (/root/reference/src/gaussian_process.cpp:15-45) on every patch.
 
-A "step" is one pass of the hot path over the whole batch: one launch of the fused fit+predict kernel through the
-C-ABI (gpc_dense_fit_predict_grid_dev) with the patch buffers already resident in HBM, followed -- when N > 1 -- by
-the single RCCL all-gather that reassembles the decompressed grid values of all ranks.  Patches shard across ranks
-with no other exchange (weak scaling: 8192 patches per GPU).
+A "step" is one pass of the hot path over the whole batch through the C-ABI with the patch buffers resident in HBM.
+  N = 1: one launch of gpc_dense_fit_predict_grid_dev.
+  N > 1: the north-star path -- the job's batch (N x 8192 patches, rank-seeded shards) is partitioned over the ranks by
+         gpc_partition_patches (longest-processing-time, fixed-size padded slots), every rank fits + predicts its slots,
+         ONE RCCL all-gather reassembles f_star, a device gather un-permutes it to patch order; the result is checked
+         against the rank's own slots.  Weak scaling (8192 patches per GPU); the gather of step k overlaps the kernel of k+1.
+
+Besides the headline the same JSON line carries "secondary": driver-timed records of the other BASELINE configurations,
+each with its own config.workload, roofline and (N = 1) cpu_baseline:
+  N = 1: C3-per-GPU (8192 x 512 dense), C4 (sparse online, 32768 x 256 in 4 chunks, capacity 200: the basis-filling
+         kernel and the reference's default hyper-parameters), C5 (probit IRLS, 4096 x 1024).
+  N > 1: C3 (N x 8192 patches x 512 points -- 65536 at N = 8, BASELINE configs[2]) through the same sharded path.
 
     python bench.py                       # N = 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -28,11 +36,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix == vector peak, AMD public spec (256 CUs x 4 SIMD x 32 FLOP/clk x 2.4 GHz)
+HBM_PEAK_GBPS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+RES, SZ = 0.15, 20
+M = SZ * SZ
 
 
 def algorithmic_flops(n, m):
     """dense fit + predictive mean, kernel evaluation = 7 flops, symmetric K counted once."""
     return 3.5 * n * n + n ** 3 / 3.0 + 2.0 * n * n + 9.0 * n * m
+
+
+def irls_flops(n, m, iters):
+    """config 5: every Newton step is one Gram build + factorisation + two triangular solves; one predictive mean at the end"""
+    return iters * (3.5 * n * n + n ** 3 / 3.0 + 2.0 * n * n) + 9.0 * n * m
 
 
 def host_cores():
@@ -48,46 +64,330 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("GPC_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(off, x0, x1, y, res, sz, f_gpu, budget_s=12.0):
+def _traffic(key):
+    """HBM bytes per launch from the PMC passes (profiles/traffic.json, collected and corrected as the microarch guide
+    prescribes; tools/collect_profiles.py) or None"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    O.build()
+    return O
+
+
+def _timed_threads(fn, n_items, cores, budget_s, probe=2):
+    """Runs fn(lo, hi) over a bounded sample: one probe on a single thread (the per-item cost, which is also how the
+    reference itself runs -- it has no threads), then one chunk per thread sized for ~budget_s.  Returns
+    (outputs, items_done, wall_s, single_thread_items_per_s)."""
+    from concurrent.futures import ThreadPoolExecutor
+    fn(0, 1)                                   # warm-up (library load, page faults)
+    probe = max(1, min(probe, n_items))
+    t0 = time.perf_counter()
+    fn(0, probe)
+    per_item = (time.perf_counter() - t0) / probe
+    per_thread = max(1, min(n_items // cores, int(budget_s / max(per_item, 1e-9))))
+    chunks = [(i * per_thread, (i + 1) * per_thread) for i in range(cores) if (i + 1) * per_thread <= n_items]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(len(chunks)) as ex:
+        outs = list(ex.map(lambda c: fn(*c), chunks))
+    dt = time.perf_counter() - t0
+    return outs, per_thread * len(chunks), dt, 1.0 / per_item
+
+
+def cpu_baseline_dense(off, x0, x1, y, f_gpu, budget_s):
     """Times the CPU oracle (oracle/gpc_oracle.c, -O3 -march=native build; kind "port": the reference's own Eigen code
     cannot be built here) on a bounded sample of the same workload, one thread per host core, and returns
     the baseline record plus the RMSE of the GPU result against it on that sample."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    from concurrent.futures import ThreadPoolExecutor
-    O.build()
+    O = _oracle()
     p = O.dense_params()
-    xs0, xs1 = O.grid(res, sz)
+    xs0, xs1 = O.grid(RES, SZ)
     P = len(off) - 1
     n = int(off[1] - off[0])
 
     def run(lo, hi):
         sub = (off[lo:hi + 1] - off[lo]).astype(np.int32)
         sl = slice(int(off[lo]), int(off[hi]))
-        f, _, st = O.dense_fit_predict_batch(p, sub, np.ascontiguousarray(x0[sl]), np.ascontiguousarray(x1[sl]),
-                                             np.ascontiguousarray(y[:, sl]), xs0, xs1, fast=True)
-        return f
-
-    run(0, 2)                                  # warm-up (library load, page faults)
-    n1 = min(64, P)
-    t0 = time.perf_counter()
-    run(0, n1)
-    per_patch = (time.perf_counter() - t0) / n1    # single thread: how the reference itself runs (it has no threads)
+        return O.dense_fit_predict_batch(p, sub, np.ascontiguousarray(x0[sl]), np.ascontiguousarray(x1[sl]),
+                                         np.ascontiguousarray(y[:, sl]), xs0, xs1, fast=True)[0]
     cores = host_cores()
-    per_thread = max(2, min(P // cores, int(budget_s / per_patch)))
-    chunks = [(i * per_thread, (i + 1) * per_thread) for i in range(cores)]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        outs = list(ex.map(lambda c: run(*c), chunks))
-    dt = time.perf_counter() - t0
-    done = per_thread * cores
+    outs, done, dt, single = _timed_threads(run, P, cores, budget_s, probe=min(64, max(2, 4096 // n)))
     f_cpu = np.concatenate(outs, axis=0)
     diff = f_gpu[:done] - f_cpu
-    rmse = float(np.sqrt(np.mean(diff * diff)))
-    rec = {"value": done / dt, "unit": "patches/s", "cores": cores, "kind": "port", "single_thread_value": 1.0 / per_patch,
+    rec = {"value": done / dt, "unit": "patches/s", "cores": cores, "kind": "port", "single_thread_value": single,
            "sample": f"{done} of the {P} patches x {n} pts (same buffers), oracle/gpc_oracle.c -O3 -march=native, "
                      f"{cores} threads, {dt:.1f} s"}
-    return rec, rmse, float(np.max(np.abs(diff))), float(np.sqrt(np.mean(f_cpu * f_cpu)))
+    rm = {"rmse": float(np.sqrt(np.mean(diff * diff))), "max_abs": float(np.max(np.abs(diff))),
+          "f_rms": float(np.sqrt(np.mean(f_cpu * f_cpu))), "what": "GPU f* vs CPU oracle f* on the cpu_baseline sample"}
+    return rec, rm
+
+
+# ------------------------------------------------------------------------------------------------ dense (C2 headline, C3)
+
+def bench_dense(env, P, n, steps, warmup, seed=2):
+    """One GPU's (or, N > 1, the sharded job's) dense fit + predict.  Returns a dict of measurements; `P` is patches PER GPU."""
+    import torch
+    import torch.distributed as dist
+    from gp_compressor_amd import capi, dist as gdist, synth
+    ctx, dev, world, rank, use_dist = env["ctx"], env["dev"], env["world"], env["rank"], env["use_dist"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    prm = capi.default_params_dense()                         # gaussian_process defaults, reference double-noise (F5)
+    if not use_dist:
+        off, x0, x1, y = synth.make_patches(P, n, res=RES, seed=seed)
+        slots = None
+        S, Pg = P, P
+    else:
+        # the whole job's batch from rank-seeded shards, then the LPT partition of the C-ABI: this rank's slots
+        goff, gx0, gx1, gy = gdist.global_batch(world, P, n, res=RES, seed=seed)
+        Pg = len(goff) - 1
+        slots, off, x0, x1, y = gdist.shard_batch(goff, gx0, gx1, gy, world, rank)
+        S = slots.shape[1]
+        del gx0, gx1, gy
+    N = int(off[-1])
+    n_max = int(np.max(np.diff(off))) if S else 0
+    d_off, d_x0, d_x1, d_y = t(off), t(x0), t(x1), t(y)
+    nb = 2 if use_dist else 1
+    f_bufs = [torch.empty((S, 1, M), dtype=torch.float64, device=dev) for _ in range(nb)]
+    status = torch.empty((S,), dtype=torch.int32, device=dev)
+    gathers = [gdist.ShardedGather(slots, Pg, f_bufs[0], world) for _ in range(nb)] if use_dist else None
+    pending = [None]
+
+    def step(k, ev=None):
+        b = k & 1 if use_dist else 0
+        if ev is not None:
+            ev[0].record()
+        ctx.dense_fit_predict_grid_dev(prm, S, d_off, n_max, N, d_x0, d_x1, d_y, 1, RES, SZ, f_bufs[b], status=status)
+        if ev is not None:
+            ev[1].record()
+        if use_dist:
+            gathers[b].start(f_bufs[b], async_op=True)        # RCCL's stream; overlaps the un-permute below and the next kernel
+            if pending[0] is not None:
+                gathers[pending[0]].finish()                  # step k-1: wait for its gather, un-permute to patch order
+            pending[0] = b
+
+    def fence():
+        if use_dist and pending[0] is not None:
+            gathers[pending[0]].finish()
+            pending[0] = None
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(warmup):
+        step(k)
+    fence()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k, events[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    last = (steps - 1) & 1 if use_dist and steps > 0 else 0
+    st = status.cpu().numpy()
+    f_host = f_bufs[last].cpu().numpy()
+    ok = bool(np.all(st == 0)) and bool(np.all(np.isfinite(f_host)))
+    if use_dist:
+        ok = ok and gathers[last].own_rows_match(f_bufs[last], rank, slots)
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+    kernel = ctx.last_dense_kernel()
+    flops = algorithmic_flops(n, M) * P
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+    del d_off, d_x0, d_x1, d_y, f_bufs, gathers
+    return {"value": world * P * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kern_ms": kern_ms, "ok": ok,
+            "kernel": kernel, "achieved": achieved, "host": (off, x0, x1, y, f_host) if not use_dist else None}
+
+
+def dense_record(name, r, P, n, world, steps, warmup):
+    tkey = {"dense_mfma_nt16": "dense_mfma_nt16", "dense_mfma_big": f"dense_mfma_big@n{n}"}.get(r["kernel"], r["kernel"])
+    par = (f"{world * P} patches partitioned over {world} ranks by gpc_partition_patches (LPT), 1 all-gather of f_star + un-permute"
+           if world > 1 else "1 GPU")
+    return {"metric": "patches/sec (compress+predict)", "value": r["value"], "unit": "patches/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{name}: {P} patches x {n} pts per GPU, RBF + Gaussian noise, dense Cholesky fit + predictive mean "
+                                   f"on the {SZ}x{SZ} grid (m={M})",
+                       "patches_per_gpu": P, "points_per_patch": n, "grid_points": M, "parallelism": par, "kernel": r["kernel"],
+                       "results_ok": r["ok"]},
+            "roofline": {"bound": "mfma", "achieved": r["achieved"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": r["achieved"] / FP64_PEAK_TFLOPS, "traffic": _traffic(tkey), "kernel_ms": r["kern_ms"],
+                         "flops_per_patch": algorithmic_flops(n, M)}}
+
+
+# ------------------------------------------------------------------------------------------------ C4: sparse online GP
+
+def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s):
+    """BASELINE configs[3]: sparse_gp online updates, patches of n points streamed in `chunks` add calls, capacity `cap`,
+    then predict on the grid.  regime "fill": kernel parameters under which the basis reaches the capacity (l = res/8,
+    sigma_f^2 = 1, s20 = 1e-4); "defaults": the reference's own hyper-parameters (the basis stays at ~13)."""
+    import torch
+    from gp_compressor_amd import capi, synth
+    ctx, dev = env["ctx"], env["dev"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    off, x0, x1, y = synth.make_patches(P, n, res=RES, seed=4)
+    kw = dict(sigmaf_sq=1.0, l_sq=(RES / 8) ** 2, noise=1e-4, capacity=cap) if regime == "fill" else dict(capacity=cap)
+    prm = capi.default_params_sparse(1, **kw)
+    g = capi.Sparse(ctx, prm, P, 1)
+    xs0, xs1 = synth.grid(RES, SZ)
+    d_xs0, d_xs1 = t(xs0), t(xs1)
+    f = torch.empty((P, 1, M), dtype=torch.float64, device=dev)
+    cn = n // chunks
+    coff = t((np.arange(P + 1) * cn).astype(np.int32))
+    bufs = []
+    for c in range(chunks):
+        idx = (off[:-1, None].astype(np.int64) + np.arange(c * cn, (c + 1) * cn)[None, :]).reshape(-1)
+        bufs.append((t(x0[idx]), t(x1[idx]), t(y[:, idx])))
+    # untimed pass: warm-up + the basis sizes at the chunk boundaries (for the algorithmic byte count)
+    sizes = [np.zeros(P)]
+    for c in range(chunks):
+        g.add_dev(coff, cn, P * cn, *bufs[c])
+        torch.cuda.synchronize()
+        sizes.append(g.sizes().astype(np.float64))
+    g.predict_dev(M, d_xs0, d_xs1, f)
+    torch.cuda.synchronize()
+    # B_add = 32 b^2 bytes per point (C and Q read once, written once; SURVEY 8(d)), b interpolated linearly between the
+    # measured basis sizes at the chunk boundaries
+    bytes_total = 0.0
+    frac = (np.arange(cn) + 0.5) / cn
+    for c in range(chunks):
+        b = sizes[c][:, None] + (sizes[c + 1] - sizes[c])[:, None] * frac[None, :]
+        bytes_total += float(np.sum(32.0 * b * b))
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(chunks)] for _ in range(steps)]
+    t_tot = 0.0
+    for k in range(steps):
+        g.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in range(chunks):
+            ev[k][c][0].record()
+            g.add_dev(coff, cn, P * cn, *bufs[c])
+            ev[k][c][1].record()
+        g.predict_dev(M, d_xs0, d_xs1, f)
+        torch.cuda.synchronize()
+        t_tot += time.perf_counter() - t0
+    add_ms = float(np.mean([sum(a.elapsed_time(b) for a, b in ev[k]) for k in range(steps)]))
+    bv = g.sizes()
+    f_host = f.cpu().numpy()
+    ok = bool(np.all(np.isfinite(f_host)))
+    achieved = bytes_total / (add_ms * 1e-3) / 1e9
+    rec = {"metric": "patches/sec (compress+predict)", "value": P * steps / t_tot, "unit": "patches/s", "n_gpus": 1, "steps": steps,
+           "warmup": 1, "ms_per_step": 1e3 * t_tot / steps, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"C4 sparse_gp online ({regime}): {P} patches x {n} pts streamed in {chunks} add calls, capacity {cap}, "
+                                  f"then predictive mean on the {SZ}x{SZ} grid"
+                                  + (" -- basis-filling kernel l=res/8, sigma_f^2=1, s20=1e-4" if regime == "fill"
+                                     else " -- the reference's default hyper-parameters (sigma_f^2=100, l^2=1, s20=0.1)"),
+                      "patches_per_gpu": P, "points_per_patch": n, "capacity": cap, "bv_mean": float(bv.mean()), "bv_max": int(bv.max()),
+                      "kernel": "sparse_add_kernel<true> + sparse_add_kernel<false> + sparse_predict_kernel", "results_ok": ok},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                        "traffic": _traffic(f"sparse_add@C4_{regime}"), "kernel_ms": add_ms, "bytes_per_patch": bytes_total / P,
+                        "what": "the add calls of one pass (small-basis phase + regular kernel): sum over points of 32 b_t^2 bytes / "
+                                "their HIP-event time"
+                                + ("" if regime == "fill" else "; with ~13 basis vectors the pass is latency-bound, not stream-bound")}}
+    if budget_s > 0:
+        O = _oracle()
+        op = O.sparse_params(1, p0=prm.sigmaf_sq, p1=prm.l_sq, s20=prm.noise, eps_tol=prm.eps_tol, capacity=cap)
+
+        def run(lo, hi):
+            out = np.zeros((hi - lo, M))
+            for i in range(lo, hi):
+                sl = slice(int(off[i]), int(off[i + 1]))
+                h = O.Sparse(op, cap + 2, fast=True)
+                for c in range(chunks):
+                    cs = slice(sl.start + c * cn, sl.start + (c + 1) * cn)
+                    h.add_measurements(x0[cs], x1[cs], y[:, cs])
+                out[i - lo] = h.predict(xs0, xs1)[0][0]
+            return out
+        cores = host_cores()
+        outs, done, dt, single = _timed_threads(run, P, cores, budget_s, probe=2)
+        f_cpu = np.concatenate(outs, axis=0)
+        diff = f_host[:done, 0, :] - f_cpu
+        rec["cpu_baseline"] = {"value": done / dt, "unit": "patches/s", "cores": cores, "kind": "port", "single_thread_value": single,
+                               "sample": f"{done} of the {P} patches (same buffers, same chunking), oracle/gpc_oracle.c -O3 -march=native, "
+                                         f"{cores} threads, {dt:.1f} s"}
+        rec["rmse_vs_ref"] = {"rmse": float(np.sqrt(np.mean(diff * diff))), "max_abs": float(np.max(np.abs(diff))),
+                              "f_rms": float(np.sqrt(np.mean(f_cpu * f_cpu))), "what": "GPU f* vs CPU oracle f* on the cpu_baseline sample"}
+        rec["speedup_vs_cpu_baseline"] = rec["value"] / rec["cpu_baseline"]["value"]
+    g.close()
+    return rec
+
+
+# ------------------------------------------------------------------------------------------------ C5: probit IRLS
+
+def bench_irls_c5(env, P, n, steps, budget_s):
+    """BASELINE configs[4]: probit occupancy-GP variant, dense Newton / IRLS loop on the GPU (gpc_dense_irls_fit_predict_dev)."""
+    import torch
+    from gp_compressor_amd import capi, synth
+    ctx, dev = env["ctx"], env["dev"]
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    off, x0, x1, y = synth.make_patches(P, n, res=RES, seed=5)
+    lab = synth.occupancy_labels(off, y[0])
+    s20, l_sq, sf = 0.25, (RES / 3) ** 2, 1.0
+    prm = capi.default_params_dense(sigmaf_sq=sf, l_sq=l_sq, noise=s20, noise_model=2)
+    ir = capi.default_params_irls(max_iter=20, tol=1e-9)
+    d_off, d_x0, d_x1, d_y = t(off), t(x0), t(x1), t(lab)
+    d_f = torch.empty((P, M), dtype=torch.float64, device=dev)
+    d_it = torch.empty((P,), dtype=torch.int32, device=dev)
+    d_st = torch.empty((P,), dtype=torch.int32, device=dev)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        ctx.dense_irls_fit_predict_dev(prm, ir, P, d_off, n, P * n, d_x0, d_x1, d_y, M, None, None, RES, SZ, d_f, None, None, d_it, d_st)
+        if ev is not None:
+            ev[1].record()
+    step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(ev[k])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    it, st, f_host = d_it.cpu().numpy(), d_st.cpu().numpy(), d_f.cpu().numpy()
+    ok = bool(np.all(st == 0)) and bool(np.all(np.isfinite(f_host))) and int(it.max()) < ir.max_iter
+    flops = float(np.sum(irls_flops(n, M, it.astype(np.float64))))
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+    rec = {"metric": "patches/sec (compress+predict)", "value": P * steps / elapsed, "unit": "patches/s", "n_gpus": 1, "steps": steps,
+           "warmup": 1, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"C5 probit occupancy GP: {P} patches x {n} labelled pts (+-1), RBF kernel, probit likelihood (CDF variant), "
+                                  f"Newton/IRLS loop on the GPU (tol {ir.tol:g}, <= {ir.max_iter} steps) + latent mean on the {SZ}x{SZ} grid",
+                      "patches_per_gpu": P, "points_per_patch": n, "newton_steps_mean": float(it.mean()), "newton_steps_max": int(it.max()),
+                      "kernel": ctx.last_dense_kernel(), "results_ok": ok},
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                        "traffic": _traffic("dense_mfma_big_irls@n1024"), "kernel_ms": kern_ms, "flops_per_patch": flops / P,
+                        "what": "sum over patches of newton_steps x (3.5 n^2 + n^3/3 + 2 n^2) + 9 n m flops / HIP-event time of the launch"}}
+    if budget_s > 0:
+        O = _oracle()
+        op = O.dense_params(sigmaf_sq=sf, l_sq=l_sq, sigman_sq=s20)
+        xs0, xs1 = O.grid(RES, SZ)
+
+        def run(lo, hi):
+            sub = (off[lo:hi + 1] - off[lo]).astype(np.int32)
+            sl = slice(int(off[lo]), int(off[hi]))
+            return O.dense_irls_fit_predict_batch(op, 2, sub, x0[sl], x1[sl], lab[sl], xs0, xs1, max_iter=ir.max_iter, tol=ir.tol, fast=True)[0]
+        cores = host_cores()
+        outs, done, dt, single = _timed_threads(run, P, cores, budget_s, probe=1)
+        f_cpu = np.concatenate(outs, axis=0)
+        diff = f_host[:done] - f_cpu
+        rec["cpu_baseline"] = {"value": done / dt, "unit": "patches/s", "cores": cores, "kind": "port", "single_thread_value": single,
+                               "sample": f"{done} of the {P} patches x {n} pts (same buffers), orc_dense_irls_fit -O3 -march=native, "
+                                         f"{cores} threads, {dt:.1f} s"}
+        rec["rmse_vs_ref"] = {"rmse": float(np.sqrt(np.mean(diff * diff))), "max_abs": float(np.max(np.abs(diff))),
+                              "f_rms": float(np.sqrt(np.mean(f_cpu * f_cpu))), "what": "GPU latent mean vs CPU oracle on the cpu_baseline sample"}
+        rec["speedup_vs_cpu_baseline"] = rec["value"] / rec["cpu_baseline"]["value"]
+    return rec
 
 
 def main():
@@ -98,11 +398,13 @@ def main():
     ap.add_argument("--patches", type=int, default=8192, help="patches per GPU (C2: 8192)")
     ap.add_argument("--points", type=int, default=256, help="points per patch (C2: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling passes)")
+    ap.add_argument("--only", default="", help="profiling: run just one workload -- c3 | c4fill | c4defaults | c5 -- and print its record")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from gp_compressor_amd import capi, synth
+    from gp_compressor_amd import capi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -114,114 +416,77 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or os.environ.get("GPC_BENCH_FORCE_DIST") == "1":
+    use_dist = world > 1 or os.environ.get("GPC_BENCH_FORCE_DIST") == "1"      # the latter: 1-rank rehearsal of the N > 1 path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    P, n, res, sz = args.patches, args.points, 0.15, 20
-    m = sz * sz
-    # every rank owns its own 8192 patches of the scan (seeded per rank): weak scaling, no data-path exchange
-    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=2 + 1000 * rank)
-    N = int(off[-1])
-    t = lambda a: torch.from_numpy(a).to(dev)
-    d_off, d_x0, d_x1, d_y = t(off), t(x0), t(x1), t(y)
-    # two output buffers: with N > 1 the all-gather of step k runs on RCCL's stream while the kernel of step k+1 computes
-    use_dist = world > 1 or os.environ.get("GPC_BENCH_FORCE_DIST") == "1"      # the latter: 1-rank rehearsal of the N > 1 path
-    f_bufs = [torch.empty((P, 1, m), dtype=torch.float64, device=dev) for _ in range(2 if use_dist else 1)]
-    status = torch.empty((P,), dtype=torch.int32, device=dev)
-    g_bufs = [torch.empty((world * P, 1, m), dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
-    works = [None, None]
-
     ctx = capi.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # kernel and events share torch's current stream
-    prm = capi.default_params_dense()                         # gaussian_process defaults, reference double-noise (F5)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels and events share torch's current stream
+    env = {"ctx": ctx, "dev": dev, "world": world, "rank": rank, "use_dist": use_dist}
+    cpu = world == 1 and not use_dist and not args.no_cpu_baseline
+    sec_steps = max(1, min(args.steps, 5))
 
-    def step(k, ev=None):
-        b = k & 1 if use_dist else 0
-        if use_dist and works[b] is not None:
-            works[b].wait()                                   # the gather that still reads this buffer (stream-level wait)
-        if ev is not None:
-            ev[0].record()
-        ctx.dense_fit_predict_grid_dev(prm, P, d_off, n, N, d_x0, d_x1, d_y, 1, res, sz, f_bufs[b], status=status)
-        if ev is not None:
-            ev[1].record()
-        if use_dist:
-            works[b] = dist.all_gather_into_tensor(g_bufs[b], f_bufs[b], async_op=True)
+    if args.only:
+        if args.only == "c3":
+            r = bench_dense(env, 8192, 512, sec_steps, 1, seed=3)
+            out = dense_record("C3 outdoor scan (one GPU's share)", r, 8192, 512, world, sec_steps, 1)
+        elif args.only in ("c4fill", "c4defaults"):
+            out = bench_sparse_c4(env, args.only[2:], int(os.environ.get("GPC_C4_P", "32768")), 256, 4, 200, 1, 0.0)
+        elif args.only == "c5":
+            out = bench_irls_c5(env, 4096, 1024, 1, 0.0)
+        else:
+            raise SystemExit("--only: c3 | c4fill | c4defaults | c5")
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        ctx.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
-    def fence():
-        if use_dist:
-            for w in works:
-                if w is not None:
-                    w.wait()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
+    P, n = args.patches, args.points
+    r = bench_dense(env, P, n, args.steps, args.warmup)
+    name = "C2 room scan" if (P, n) == (8192, 256) else "room scan (non-default size)"
+    out = dense_record(name, r, P, n, world, args.steps, args.warmup)
+    if cpu:
+        off, x0, x1, y, f_host = r["host"]
+        # the host-pointer entry of the C-ABI (H2D of the patch buffers + kernel + D2H of f*), for the record: this
+        # PCIe-inclusive rate is NOT `value` (inputs are HBM-resident in the timed region above)
+        prm = capi.default_params_dense()
+        ctx.dense_fit_predict_grid(prm, off, x0, x1, y, RES, SZ)
+        th = time.perf_counter()
+        for _ in range(3):
+            ctx.dense_fit_predict_grid(prm, off, x0, x1, y, RES, SZ)
+        th = (time.perf_counter() - th) / 3
+        out["host_pointer_entry"] = {"value": P / th, "unit": "patches/s", "ms_per_call": 1e3 * th,
+                                     "what": "gpc_dense_fit_predict_grid with host buffers: H2D + kernel + D2H, synchronous"}
+        rec, rm = cpu_baseline_dense(off, x0, x1, y, f_host, 12.0)
+        out["cpu_baseline"] = rec
+        out["rmse_vs_ref"] = rm
+        out["speedup_vs_cpu_baseline"] = out["value"] / rec["value"]
+    r["host"] = None
 
-    for k in range(args.warmup):
-        step(k)
-    fence()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k, events[k])
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
-    last = (args.steps - 1) & 1 if use_dist and args.steps > 0 else 0
-    f_star = f_bufs[last]
-    gathered = g_bufs[last] if use_dist else None
-
-    st = status.cpu().numpy()
-    f_host = f_star.cpu().numpy()
-    ok = bool(np.all(st == 0)) and bool(np.all(np.isfinite(f_host)))
-    if gathered is not None:
-        mine = gathered[rank * P:(rank + 1) * P].cpu().numpy()
-        ok = ok and bool(np.array_equal(mine, f_host))
-
+    secondary = []
+    if not args.no_secondary:
+        # C3: BASELINE configs[2] -- 8192 patches x 512 points per GPU (65536 at N = 8), same (sharded, N > 1) path
+        r3 = bench_dense(env, 8192, 512, sec_steps, 1, seed=3)
+        rec3 = dense_record("C3 outdoor scan" + (" (one GPU's share)" if world == 1 else ""), r3, 8192, 512, world, sec_steps, 1)
+        if cpu:
+            off, x0, x1, y, f_host = r3["host"]
+            rec3["cpu_baseline"], rec3["rmse_vs_ref"] = cpu_baseline_dense(off, x0, x1, y, f_host, 4.0)
+            rec3["speedup_vs_cpu_baseline"] = rec3["value"] / rec3["cpu_baseline"]["value"]
+        r3["host"] = None
+        secondary.append(rec3)
+        if world == 1 and not use_dist:
+            torch.cuda.empty_cache()
+            for regime in ("fill", "defaults"):
+                secondary.append(bench_sparse_c4(env, regime, 32768, 256, 4, 200, 2, 4.0 if cpu else 0.0))
+                torch.cuda.empty_cache()
+            secondary.append(bench_irls_c5(env, 4096, 1024, 2, 3.0 if cpu else 0.0))
     if rank == 0:
-        flops = algorithmic_flops(n, m) * P
-        achieved = flops / (kern_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(ctx.last_dense_kernel(), {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "patches/sec (compress+predict)", "value": world * P * args.steps / elapsed, "unit": "patches/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{'C2 room scan' if (P, n) == (8192, 256) else 'room scan (non-default size)'}: {P} patches x {n} pts per GPU, RBF + Gaussian noise, dense Cholesky "
-                                   f"fit + predictive mean on the {sz}x{sz} grid (m={m})",
-                       "patches_per_gpu": P, "points_per_patch": n, "grid_points": m,
-                       "parallelism": f"patches sharded over {world} rank(s), 1 all-gather of f_star" if world > 1 else "1 GPU",
-                       "kernel": ctx.last_dense_kernel(), "results_ok": ok},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "flops_per_patch": algorithmic_flops(n, m)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            # the host-pointer entry of the C-ABI (H2D of the patch buffers + kernel + D2H of f*), for the record: this
-            # PCIe-inclusive rate is NOT `value` (inputs are HBM-resident in the timed region above)
-            ctx.dense_fit_predict_grid(prm, off, x0, x1, y, res, sz)
-            th = time.perf_counter()
-            for _ in range(3):
-                ctx.dense_fit_predict_grid(prm, off, x0, x1, y, res, sz)
-            th = (time.perf_counter() - th) / 3
-            out["host_pointer_entry"] = {"value": P / th, "unit": "patches/s", "ms_per_call": 1e3 * th,
-                                         "what": "gpc_dense_fit_predict_grid with host buffers: H2D + kernel + D2H, synchronous"}
-            rec, rmse, maxabs, frms = cpu_baseline(off, x0, x1, y, res, sz, f_host)
-            out["cpu_baseline"] = rec
-            out["rmse_vs_ref"] = {"rmse": rmse, "max_abs": maxabs, "f_rms": frms,
-                                  "what": "GPU f* vs CPU oracle f* on the cpu_baseline sample"}
-            out["speedup_vs_cpu_baseline"] = out["value"] / rec["value"]
+        if secondary:
+            out["secondary"] = secondary
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist.is_initialized():

@@ -4,10 +4,30 @@ Patches are independent in the reference (each gps[i] touches only its own X_i, 
 /root/reference/src/gp_compressor.cpp:146-163), so the only exchange of the multi-GPU path is one fixed-size
 all-gather of f_star over RCCL/xGMI (backend "nccl" on ROCm; "gloo" in the CPU tests).  The partition itself is the
 C-ABI's gpc_partition_patches (longest-processing-time on n^3 / n b^2, ranks padded to ceil(P/world) slots).
+
+bench.py (N > 1) and tests/test_dist_cpu.py drive the SAME code: global_batch -> shard_batch -> [the rank's fit +
+predict] -> ShardedGather (one all_gather_into_tensor, un-permute to patch order, self-check).
 """
 import numpy as np
 
-from . import capi
+from . import capi, synth
+
+
+def global_batch(world, patches_per_rank, n, res=0.15, seed=2, ragged=False, n_min=None):
+    """The job's whole patch batch as the concatenation of `world` rank-seeded shards (shard r: seed + 1000 r, the same
+    buffers a 1-rank run of shard r would see).  Deterministic, so every rank can build it without an exchange.
+    Returns off (P+1,), x0, x1 (N,), y (1, N) with P = world * patches_per_rank."""
+    offs, xs0, xs1, ys = [], [], [], []
+    base = 0
+    for r in range(world):
+        off, x0, x1, y = synth.make_patches(patches_per_rank, n, res=res, seed=seed + 1000 * r, ragged=ragged, n_min=n_min)
+        offs.append(off[:-1].astype(np.int64) + base)
+        base += int(off[-1])
+        xs0.append(x0)
+        xs1.append(x1)
+        ys.append(y)
+    off = np.concatenate(offs + [np.array([base], dtype=np.int64)]).astype(np.int32)
+    return off, np.concatenate(xs0), np.concatenate(xs1), np.ascontiguousarray(np.concatenate(ys, axis=1))
 
 
 def shard_batch(off, x0, x1, y, world, rank, sparse_capacity=0):
@@ -16,27 +36,78 @@ def shard_batch(off, x0, x1, y, world, rank, sparse_capacity=0):
     off = np.ascontiguousarray(off, dtype=np.int32)
     slots = capi.partition_patches(off, world, sparse_capacity)
     mine = slots[rank]
-    counts = np.array([off[p + 1] - off[p] if p >= 0 else 0 for p in mine], dtype=np.int64)
+    off64 = off.astype(np.int64)
+    counts = np.where(mine >= 0, off64[np.maximum(mine, 0) + 1] - off64[np.maximum(mine, 0)], 0)
     loc_off = np.zeros(len(mine) + 1, dtype=np.int32)
     loc_off[1:] = np.cumsum(counts)
-    idx = np.concatenate([np.arange(off[p], off[p + 1]) for p in mine if p >= 0] or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+    # rows of the rank's patches, slot by slot (vectorised: start of each slot repeated over its rows + a running index)
+    starts = np.repeat(off64[np.maximum(mine, 0)], counts)
+    within = np.arange(int(loc_off[-1]), dtype=np.int64) - np.repeat(loc_off[:-1].astype(np.int64), counts)
+    idx = starts + within
     y = np.atleast_2d(y)
     return slots, loc_off, np.ascontiguousarray(x0[idx]), np.ascontiguousarray(x1[idx]), np.ascontiguousarray(y[:, idx])
+
+
+def slot_index(slots, P):
+    """slot_of_patch (P,): row of the gathered (world * S) buffer that holds patch p"""
+    sp = np.asarray(slots).reshape(-1)
+    slot_of_patch = np.full(P, -1, dtype=np.int64)
+    slot_of_patch[sp[sp >= 0]] = np.nonzero(sp >= 0)[0]
+    assert np.all(slot_of_patch >= 0), "a patch has no slot"
+    return slot_of_patch
+
+
+class ShardedGather:
+    """The exchange step of the multi-GPU path: ONE all_gather_into_tensor of the ranks' (S, ny, m) slot buffers into a
+    (world * S, ny, m) buffer, then the un-permutation to patch order (a device gather).  start() may run asynchronously
+    (RCCL's own stream) so that the next step's kernel overlaps it; finish() waits and un-permutes."""
+
+    def __init__(self, slots, P, like, world):
+        import torch
+        self.torch = torch
+        self.world, self.S = slots.shape
+        assert self.world == world
+        self.P = P
+        self.index = torch.from_numpy(slot_index(slots, P)).to(like.device)
+        shape = tuple(like.shape[1:])
+        self.flat = torch.empty((world * self.S,) + shape, dtype=like.dtype, device=like.device)
+        self.out = torch.empty((P,) + shape, dtype=like.dtype, device=like.device)
+        self.work = None
+
+    def start(self, local_f, async_op=True):
+        import torch.distributed as dist
+        assert local_f.shape[0] == self.S and local_f.is_contiguous()
+        if dist.is_initialized():
+            w = dist.all_gather_into_tensor(self.flat, local_f, async_op=async_op)   # rank r lands in rows [r*S, (r+1)*S)
+            self.work = w if async_op else None
+        else:
+            self.flat.copy_(local_f)
+            self.work = None
+
+    def finish(self):
+        """returns f_star in patch order, (P, ny, m), on the device"""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        self.torch.index_select(self.flat, 0, self.index, out=self.out)
+        return self.out
+
+    def own_rows_match(self, local_f, rank, slots):
+        """self-check: the gathered rows of this rank's own slots are the buffer it contributed, bit for bit, and the
+        un-permuted result holds them at its patches' positions"""
+        torch = self.torch
+        mine = np.asarray(slots[rank])
+        ok = bool(torch.equal(self.flat[rank * self.S:(rank + 1) * self.S], local_f))
+        live = np.nonzero(mine >= 0)[0]
+        if len(live):
+            pid = torch.from_numpy(mine[live].astype(np.int64)).to(local_f.device)
+            ok = ok and bool(torch.equal(self.out[pid], local_f[torch.from_numpy(live).to(local_f.device)]))
+        return ok
 
 
 def gather_fstar(local_f, slots, P):
     """local_f: torch tensor (S, ny, m) of this rank's slots.  One all_gather_into_tensor, then un-permute to patch
     order: returns (P, ny, m) on the same device."""
-    import torch
-    import torch.distributed as dist
-    world, S = slots.shape
-    assert local_f.shape[0] == S
-    flat = torch.empty((world * S,) + tuple(local_f.shape[1:]), dtype=local_f.dtype, device=local_f.device)
-    if world > 1:
-        dist.all_gather_into_tensor(flat, local_f.contiguous())   # rank r lands in rows [r*S, (r+1)*S)
-    else:
-        flat.copy_(local_f)
-    slot_of_patch = np.empty(P, dtype=np.int64)
-    sp = slots.reshape(-1)
-    slot_of_patch[sp[sp >= 0]] = np.nonzero(sp >= 0)[0]
-    return flat[torch.from_numpy(slot_of_patch).to(flat.device)]
+    g = ShardedGather(np.asarray(slots), P, local_f, slots.shape[0])
+    g.start(local_f.contiguous(), async_op=False)
+    return g.finish().clone()

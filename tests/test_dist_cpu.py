@@ -30,15 +30,27 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        P = 21
-        off, x0, x1, y = synth.make_patches(P, 48, seed=4, ragged=True)
+        # the code path of bench.py at N > 1: rank-seeded shards -> global batch -> LPT slots -> fit + predict -> ONE
+        # all-gather -> un-permute -> self-check.  Ragged patches, and a patch count that does not divide by the world
+        # size, so that the last rank carries a padding slot (an empty patch whose f* row is zero).
+        goff, gx0, gx1, gy = gdist.global_batch(world, 11, 48, seed=4, ragged=True)
+        P = len(goff) - 2                                    # drop the last patch: world * 11 - 1 patches
+        off = goff[:P + 1]
+        x0, x1, y = gx0[:off[-1]], gx1[:off[-1]], gy[:, :off[-1]]
         xs0, xs1 = synth.grid(0.15, 6)
         slots, loff, lx0, lx1, ly = gdist.shard_batch(off, x0, x1, y, world, rank)
+        assert slots.shape == (world, 11) and int((slots < 0).sum()) == 1
         f, _, st = O.dense_fit_predict_batch(O.dense_params(), loff, lx0, lx1, ly, xs0, xs1)
-        full = gdist.gather_fstar(torch.from_numpy(f), slots, P).numpy()
+        local = torch.from_numpy(f)
+        g = gdist.ShardedGather(slots, P, local, world)
+        g.start(local, async_op=True)
+        full = g.finish()
+        ok = g.own_rows_match(local, rank, slots)
+        full2 = gdist.gather_fstar(local, slots, P)
+        ok = ok and bool(torch.equal(full, full2))
         if rank == 0:
             ref, _, _ = O.dense_fit_predict_batch(O.dense_params(), off, x0, x1, y, xs0, xs1)
-            q.put((bool(np.array_equal(full, ref)), slots.tolist()))
+            q.put((ok and bool(np.array_equal(full.numpy(), ref)), slots.tolist(), P))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -54,10 +66,10 @@ def test_shard_allgather_roundtrip_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    ok, slots = q.get(timeout=120)
+    ok, slots, P = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
     flat = [s for row in slots for s in row if s >= 0]
-    assert sorted(flat) == list(range(21))
+    assert sorted(flat) == list(range(P)) and P == world * 11 - 1
