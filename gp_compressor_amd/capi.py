@@ -75,6 +75,7 @@ PROTOTYPES = {
     "gpc_sparse_create": (C.c_int, [_vp, C.POINTER(Params), _i, _i, C.POINTER(_vp)]),
     "gpc_sparse_destroy": (None, [_vp]),
     "gpc_sparse_reset": (C.c_int, [_vp]),
+    "gpc_sparse_set_trace": (C.c_int, [_vp, _vp]),
     "gpc_sparse_add": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_add_dev": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_predict": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -381,7 +382,8 @@ class Sparse:
     def reset(self):
         self.ctx._check(self.lib.gpc_sparse_reset(self.h))
 
-    def add(self, off, x0, x1, y, perm=None):
+    def add(self, off, x0, x1, y, perm=None, trace=False):
+        """trace=True: also returns the decision bytes of the call (gpc_sparse_set_trace), (N,) uint8 in insertion order"""
         off = np.ascontiguousarray(off, dtype=np.int32)
         y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.float64)
         assert y.shape[0] == self.ny and off.shape[0] == self.P + 1
@@ -389,8 +391,21 @@ class Sparse:
         x1 = np.ascontiguousarray(x1, dtype=np.float64)
         pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
         st = np.full(self.P, -1, dtype=np.int32)
-        self.ctx._check(self.lib.gpc_sparse_add(self.h, _ptr(off), _ptr(x0), _ptr(x1), _ptr(y), _ptr(pm), _ptr(st)))
-        return st
+        tr, d_tr = None, _vp()
+        if trace:
+            tr = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+            self.ctx._check(self.lib.gpc_dev_malloc(self.ctx.h, tr.nbytes, C.byref(d_tr)))
+            self.ctx._check(self.lib.gpc_dev_memcpy(self.ctx.h, d_tr, _ptr(tr), tr.nbytes, 1))
+            self.ctx._check(self.lib.gpc_sparse_set_trace(self.h, d_tr))
+        try:
+            self.ctx._check(self.lib.gpc_sparse_add(self.h, _ptr(off), _ptr(x0), _ptr(x1), _ptr(y), _ptr(pm), _ptr(st)))
+            if trace:
+                self.ctx._check(self.lib.gpc_dev_memcpy(self.ctx.h, _ptr(tr), d_tr, tr.nbytes, 2))
+        finally:
+            if trace:
+                self.lib.gpc_sparse_set_trace(self.h, None)
+                self.lib.gpc_dev_free(self.ctx.h, d_tr)
+        return (st, tr[:int(off[-1])]) if trace else st
 
     def add_dev(self, off, n_max, n_total, x0, x1, y, perm=None, status=None):
         self.ctx._check(self.lib.gpc_sparse_add_dev(self.h, _ptr(off), n_max, n_total, _ptr(x0), _ptr(x1), _ptr(y),

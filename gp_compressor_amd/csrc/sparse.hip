@@ -28,6 +28,7 @@ struct gpc_sparse {
     double *alpha, *C, *Q, *BV;
     int32_t *b, *count, *stat;
     int32_t* done_it;   // P: hand-over between the small-basis phase and the regular add kernel (allocated with the object)
+    uint8_t* trace;     // diagnostic (gpc_sparse_set_trace): device buffer for the decision bytes of the next add calls, or nullptr
 };
 
 struct SpState {
@@ -336,6 +337,7 @@ struct SpAddParams {
     int fuse_next;   // 1: full-update passes also form the next point's mat-vecs (0 only through GPC_SPARSE_NO_FUSE, for the tests)
     const int32_t* start_it;   // per patch: points of this call already consumed by the small-basis kernel (nullptr: 0)
     int32_t* done_it;          // small-basis kernel only: how many points of this call it consumed
+    uint8_t* trace;            // diagnostic: one decision byte per point of the call, in insertion order (or nullptr)
 };
 
 // Small-basis phase.  With the reference's default hyper-parameters the basis stays at a dozen vectors whatever the capacity,
@@ -454,9 +456,11 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     S.BV[1] = px1;
                 }
                 b = 1;
+                if (A.trace && tid == 0) A.trace[o + it] = 0x81;
                 __syncthreads();
                 continue;
             }
+            int dec = 0;     // decision byte (include/gpc.h, gpc_sparse_set_trace): bit 0 full update, bits 1-3 / 4-6 deletions
 
             // k = construct_covariance(X, BV)  (:119, :523-530)
             if (from_prev) {
@@ -563,8 +567,10 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                 b = sp_full_update_delete<RB>(S, b, rr, gamma, qv, px0, px1, A.prm.ref_field_delete_bug, ck, eh, sv, Cstar, Qstar, Crep,
                                           Qrep, part + 4 * ld, sval, sidx, more ? nx : nullptr, kvn, pnext, sf, A.c_exp, T);
                 have_next = more;
+                dec = 1 | 2;
             } else {
                 // full update (:164-203)
+                dec = 1;
                 for (int i = tid; i <= b; i += SP_NTH) {
                     const double si = (i < b) ? ck[i] : (double)1.0f;
                     sv[i] = si;
@@ -616,6 +622,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                 if (loc < 0 || loc >= b) loc = 0;          // all-NaN scores: the reference keeps minloc = 0
                 b = sp_delete_bv<RB>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
                 have_next = false;
+                if (((dec >> 1) & 7) < 7) dec += 2;
             }
             // Delete for geometric reasons (:226-242)
             {
@@ -635,6 +642,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     if (minscore < (double)1e-9f) {
                         b = sp_delete_bv<RB>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
                         have_next = false;              // the matrices and the basis changed after the pass
+                        if (((dec >> 4) & 7) < 7) dec += 16;
                     }
                     else if (!(minscore >= (double)1e-9f)) break;   // NaN: `minscore < 1e-9f` is false in the reference too
                 }
@@ -644,6 +652,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                 const double c00 = S.C[0];
                 if (c00 != c00 && st == GPC_STATUS_OK) st = GPC_STATUS_NAN;
             }
+            if (A.trace && tid == 0) A.trace[o + it] = (uint8_t)dec;
         }
         __syncthreads();
         for (int i = tid; i < b; i += SP_NTH) {
@@ -1080,6 +1089,7 @@ int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc
     g->alpha = g->C = g->Q = g->BV = nullptr;
     g->b = g->count = g->stat = nullptr;
     g->done_it = nullptr;
+    g->trace = nullptr;
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t ld = (size_t)g->ld, Pn = (size_t)(P > 0 ? P : 1);
     hipError_t e = hipSetDevice(ctx->device);
@@ -1125,6 +1135,15 @@ void gpc_sparse_destroy(gpc_sparse* g)
 
 int gpc_sparse_ld(const gpc_sparse* g) { return g ? g->ld : GPC_EINVAL; }
 
+int gpc_sparse_set_trace(gpc_sparse* g, uint8_t* trace_dev)
+{
+    if (!g) return GPC_EINVAL;
+    if (g->ctx->dead.load()) return GPC_EINVAL;
+    std::lock_guard<std::mutex> lk(g->ctx->mu);
+    g->trace = trace_dev;
+    return GPC_OK;
+}
+
 int gpc_sparse_reset(gpc_sparse* g)
 {
     if (!g) return GPC_EINVAL;
@@ -1160,6 +1179,7 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     A.alpha = g->alpha; A.C = g->C; A.Q = g->Q; A.BV = g->BV;
     A.b = g->b; A.count = g->count; A.stat = g->stat; A.status_out = status;
     A.fuse_next = getenv("GPC_SPARSE_NO_FUSE") ? 0 : 1;
+    A.trace = g->trace;
     const size_t lds = sp_add_lds(g->ld);
     // capacity <= 64: one wave per patch (every row of the basis fits a lane; no cross-wave barriers, four times the patches
     // in flight); capacity <= 100 (the reference's default): two waves, twice the patches in flight; otherwise four waves per

@@ -188,6 +188,13 @@ int gpc_sparse_add(gpc_sparse* g, const int32_t* off, const double* x0, const do
                    const int32_t* perm, int32_t* status);
 int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total, const double* x0, const double* x1,
                        const double* y, const int32_t* perm, int32_t* status);
+/* Diagnostic: record the branch decisions of the following add calls.  trace_dev is a DEVICE buffer of n_total bytes (the
+ * n_total of those calls), NULL switches it off.  Byte off[i] + t belongs to the t-th point patch i inserted in the call:
+ * bit 0: 1 = full update (basis grew, src/sparse_gp.hpp:164-203), 0 = sparse update (:155-163); bits 1-3: capacity
+ * deletions that followed (:206-223); bits 4-6: geometric deletions (:226-242); 0x81: first point of an empty GP (:100-114).
+ * The CPU oracle and its binary128 arbiter emit the same bytes (oracle/gpc_oracle_hp.c), which is how the tests count the
+ * decisions an fp64 implementation takes differently from the exact recursion. */
+int gpc_sparse_set_trace(gpc_sparse* g, uint8_t* trace_dev);
 /* predict_measurements(f_star, X_star, sigconf, conf) for every patch on one shared X_star (src/sparse_gp.hpp:299-351).
  * sigma may be NULL (the caller in src/gp_compressor.cpp:333-334 discards it); conf selects the 0-100 confidence form. */
 int gpc_sparse_predict(gpc_sparse* g, int m, const double* xs0, const double* xs1, double* f_star, double* sigma,

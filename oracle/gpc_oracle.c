@@ -389,6 +389,7 @@ struct orc_sparse {
     double* s;
     double* t;
     int32_t n_full, n_sparse, n_deleted;
+    uint8_t last_dec;  /* decision byte of the last add (layout: gpc_oracle_hp.c) */
 };
 
 void orc_sparse_default_params(orc_sparse_params* p, int ny)
@@ -531,6 +532,7 @@ void orc_sparse_add(orc_sparse* g, double x0, double x1, const double* y)
         g->BV[0] = x0;
         g->BV[1] = x1;
         g->n_full++;
+        g->last_dec = 0x81;
         return;   /* the reference only checks isnan(C(0,0)) after this (:245) */
     }
 
@@ -598,8 +600,10 @@ void orc_sparse_add(orc_sparse* g, double x0, double x1, const double* y)
         for (int j = 0; j < b; ++j)
             for (int i = 0; i < b; ++i) Cm(i, j) += (re * s[i]) * s[j];
         g->n_sparse++;
+        g->last_dec = 0;
     } else {
         /* full update (:164-203) */
+        g->last_dec = 1;
         s[b] = (double)1.0f;
         for (int c = 0; c < ny; ++c) {
             Al(c, b) = 0;
@@ -630,6 +634,7 @@ void orc_sparse_add(orc_sparse* g, double x0, double x1, const double* y)
             if (i == 0 || score < minscore) { minscore = score; minloc = i; }
         }
         orc_sparse_delete_bv(g, minloc);
+        if (((g->last_dec >> 1) & 7) < 7) g->last_dec += 2;
     }
     /* Delete for geometric reasons (:226-242) */
     {
@@ -640,7 +645,10 @@ void orc_sparse_add(orc_sparse* g, double x0, double x1, const double* y)
                 score = (double)1.0f / Qm(i, i);
                 if (i == 0 || score < minscore) { minscore = score; minloc = i; }
             }
-            if (minscore < (double)1e-9f) orc_sparse_delete_bv(g, minloc);
+            if (minscore < (double)1e-9f) {
+                orc_sparse_delete_bv(g, minloc);
+                if (((g->last_dec >> 4) & 7) < 7) g->last_dec += 16;
+            }
         }
     }
 }
@@ -654,6 +662,19 @@ void orc_sparse_add_measurements(orc_sparse* g, int n, const double* x0, const d
         int r = perm ? perm[i] : i;
         for (int c = 0; c < g->p.ny; ++c) yy[c] = y[(size_t)c * n + r];
         orc_sparse_add(g, x0[r], x1[r], yy);
+    }
+}
+
+/* the same with the decision trace (one byte per point in insertion order; layout in gpc_oracle_hp.c) */
+void orc_sparse_add_measurements_trace(orc_sparse* g, int n, const double* x0, const double* x1,
+                                       const double* y, const int32_t* perm, uint8_t* trace)
+{
+    double yy[8];
+    for (int i = 0; i < n; ++i) {
+        int r = perm ? perm[i] : i;
+        for (int c = 0; c < g->p.ny; ++c) yy[c] = y[(size_t)c * n + r];
+        orc_sparse_add(g, x0[r], x1[r], yy);
+        if (trace) trace[i] = g->last_dec;
     }
 }
 

@@ -110,6 +110,8 @@ void orc_sparse_add(orc_sparse* g, double x0, double x1, const double* y);
  * y is ny planes of n (plane c at y + c*n).  sparse_gp.hpp:59-86 */
 void orc_sparse_add_measurements(orc_sparse* g, int n, const double* x0, const double* x1,
                                  const double* y, const int32_t* perm);
+void orc_sparse_add_measurements_trace(orc_sparse* g, int n, const double* x0, const double* x1,
+                                       const double* y, const int32_t* perm, uint8_t* trace);
 void orc_sparse_delete_bv(orc_sparse* g, int loc);          /* sparse_gp.hpp:252-295 */
 /* predict_measurements: sparse_gp.hpp:299-351; f_star is ny planes of m; sigconf (m) may be NULL */
 void orc_sparse_predict(const orc_sparse* g, int m, const double* xs0, const double* xs1,
@@ -125,6 +127,16 @@ void orc_sparse_train_sigmaf(const orc_sparse* g, int n, const double* x0, const
 void orc_sparse_get_state(const orc_sparse* g, double* alpha, double* C, double* Q, double* BV);
 /* statistics: how many full / sparse updates and deletions happened (for BV-count agreement reports) */
 void orc_sparse_get_counters(const orc_sparse* g, int32_t* n_full, int32_t* n_sparse, int32_t* n_deleted);
+
+/* ---- binary128 arbiter of the same recursion (gpc_oracle_hp.c, liboracle_hp.so; Gaussian noise only) */
+typedef struct hp_sparse hp_sparse;
+hp_sparse* hp_sparse_create(const orc_sparse_params* p, int max_bv);
+void hp_sparse_destroy(hp_sparse* g);
+int hp_sparse_size(const hp_sparse* g);
+void hp_sparse_add_measurements(hp_sparse* g, int n, const double* x0, const double* x1, const double* y, const int32_t* perm,
+                                uint8_t* trace);
+void hp_sparse_predict(const hp_sparse* g, int m, const double* xs0, const double* xs1, double* f_star, double* sigma_out);
+void hp_sparse_get_state(const hp_sparse* g, double* alpha, double* C, double* Q, double* BV);
 
 /* sparse_gp::shuffle (sparse_gp.hpp:43-56) with libc rand(), exactly as written (rand() % i) */
 void orc_shuffle_libc(int n, int32_t* ind);

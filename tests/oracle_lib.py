@@ -123,6 +123,7 @@ def _bind(L):
     L.orc_sparse_total_count.argtypes = [C.c_void_p]
     L.orc_sparse_add.argtypes = [C.c_void_p, d, d, c_dp]
     L.orc_sparse_add_measurements.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_ip]
+    L.orc_sparse_add_measurements_trace.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_ip, C.c_void_p]
     L.orc_sparse_delete_bv.argtypes = [C.c_void_p, C.c_int]
     L.orc_sparse_predict.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_dp, C.c_int]
     L.orc_sparse_likelihood.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]
@@ -256,13 +257,16 @@ class Sparse:
         yy = np.ascontiguousarray(np.atleast_1d(y), dtype=np.float64)
         self.L.orc_sparse_add(self.h, float(x0), float(x1), _dp(yy))
 
-    def add_measurements(self, x0, x1, y, perm=None):
+    def add_measurements(self, x0, x1, y, perm=None, trace=False):
+        """trace=True: returns the decision bytes (one per point, insertion order; layout in oracle/gpc_oracle_hp.c)"""
         y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.float64)
         assert y.shape[0] == self.ny
         n = y.shape[1]
         pp = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
-        self.L.orc_sparse_add_measurements(self.h, n, _dp(np.ascontiguousarray(x0)), _dp(np.ascontiguousarray(x1)),
-                                           _dp(y), _ip(pp))
+        tr = np.zeros(n, dtype=np.uint8) if trace else None
+        self.L.orc_sparse_add_measurements_trace(self.h, n, _dp(np.ascontiguousarray(x0)), _dp(np.ascontiguousarray(x1)),
+                                                 _dp(y), _ip(pp), None if tr is None else tr.ctypes.data)
+        return tr
 
     def delete_bv(self, loc):
         self.L.orc_sparse_delete_bv(self.h, loc)
@@ -310,6 +314,70 @@ class Sparse:
         a = np.zeros(3, dtype=np.int32)
         self.L.orc_sparse_get_counters(self.h, _ip(a[0:1]), _ip(a[1:2]), _ip(a[2:3]))
         return tuple(int(v) for v in a)
+
+
+_hp = None
+
+
+def hp_lib():
+    global _hp
+    if _hp is None:
+        L = _load("liboracle_hp.so")
+        L.hp_sparse_create.restype = C.c_void_p
+        L.hp_sparse_create.argtypes = [C.POINTER(SparseParams), C.c_int]
+        L.hp_sparse_destroy.argtypes = [C.c_void_p]
+        L.hp_sparse_size.restype = C.c_int
+        L.hp_sparse_size.argtypes = [C.c_void_p]
+        L.hp_sparse_add_measurements.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_ip, C.c_void_p]
+        L.hp_sparse_predict.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_dp]
+        L.hp_sparse_get_state.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp]
+        _hp = L
+    return _hp
+
+
+class SparseHP:
+    """The binary128 arbiter of the sparse recursion (oracle/gpc_oracle_hp.c): same interface as Sparse, Gaussian noise."""
+
+    def __init__(self, params, max_bv):
+        assert params.noise_model == 0
+        self.L = hp_lib()
+        self.ny = params.ny
+        self.h = self.L.hp_sparse_create(C.byref(params), max_bv)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.hp_sparse_destroy(self.h)
+            self.h = None
+
+    def size(self):
+        return self.L.hp_sparse_size(self.h)
+
+    def add_measurements(self, x0, x1, y, perm=None, trace=False):
+        y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.float64)
+        assert y.shape[0] == self.ny
+        n = y.shape[1]
+        pp = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+        tr = np.zeros(n, dtype=np.uint8) if trace else None
+        self.L.hp_sparse_add_measurements(self.h, n, _dp(np.ascontiguousarray(x0)), _dp(np.ascontiguousarray(x1)), _dp(y), _ip(pp),
+                                          None if tr is None else tr.ctypes.data)
+        return tr
+
+    def predict(self, xs0, xs1):
+        m = xs0.shape[0]
+        f = np.zeros((self.ny, m))
+        s = np.zeros(m)
+        self.L.hp_sparse_predict(self.h, m, _dp(np.ascontiguousarray(xs0)), _dp(np.ascontiguousarray(xs1)), _dp(f), _dp(s))
+        return f, s
+
+    def state(self):
+        b = self.size()
+        alpha = np.zeros((self.ny, b))
+        Ccm = np.zeros((b, b))
+        Qcm = np.zeros((b, b))
+        BV = np.zeros((b, 2))
+        self.L.hp_sparse_get_state(self.h, _dp(alpha), _dp(Ccm), _dp(Qcm), _dp(BV))
+        return alpha, Ccm.T.copy(), Qcm.T.copy(), BV
 
 
 def shuffle_stream(n, rs):

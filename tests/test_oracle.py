@@ -527,3 +527,74 @@ def test_irls_oracle_edge_cases(oracle):
         fd2 = (log_ndtr(yy * (x + h) / sig) - 2 * log_ndtr(yy * x / sig) + log_ndtr(yy * (x - h) / sig)) / (h * h)
         assert abs(L.orc_probit_std_dx_ln(s20, yy, x, sx) - fd) <= 1e-6 * max(abs(fd), 1e-3)
         assert abs(L.orc_probit_std_dx2_ln(s20, yy, x, sx) - fd2) <= 1e-4 * max(abs(fd2), 1e-2)
+
+
+# ------------------------------------------------------------------ the binary128 arbiter of the sparse recursion
+
+def _arb_case(oracle, kw, n, seed, ny=1):
+    res = 0.15
+    off, x0, x1, y = synth.make_patches(1, n, res=res, seed=seed, ny=ny)
+    perm = synth.sattolo_perms(off, seed=seed + 1)
+    p = oracle.sparse_params(ny, **kw)
+    cap = p.capacity
+    g = oracle.Sparse(p, cap + 2)
+    tr = g.add_measurements(x0, x1, y, perm, trace=True)
+    h = oracle.SparseHP(p, cap + 2)
+    th = h.add_measurements(x0, x1, y, perm, trace=True)
+    xs0, xs1 = oracle.grid(res, 20)
+    return g, h, tr, th, g.predict(xs0, xs1), h.predict(xs0, xs1), (x0, x1, y, perm, p)
+
+
+def test_arbiter_agrees_with_fp64_where_well_conditioned(oracle):
+    """liboracle_hp.so runs the recursion of oracle/gpc_oracle.c in IEEE binary128.  Where the kernel matrix of the basis is
+    well conditioned the fp64 oracle takes every branch the exact recursion takes (identical decision bytes, identical
+    basis) and its f* is the exact one to 2e-5 of max|f*| (measured: up to 4e-6; Q = K_BV^-1 reaches 1e6 at eps_tol = 1e-6f,
+    which is what fp64 loses) -- depth plane, capacity deletions, and the 3-channel field.  2e-5 is therefore also the
+    tolerance of the GPU-vs-oracle comparisons in tests/test_sparse_gpu.py: the GPU may be as far from the fp64 oracle as the
+    fp64 oracle is from the exact recursion."""
+    res = 0.15
+    for kw, n, ny in ((dict(p0=1.0, p1=(res / 4) ** 2, s20=1e-3, capacity=30), 128, 1),
+                      (dict(p0=1.0, p1=(res / 3) ** 2, s20=1e-2, capacity=12), 96, 1),
+                      (dict(p0=400.0, p1=(res / 4) ** 2, s20=1e-1, capacity=20, eps_tol=R.F(1e-4), field_delete_bug=0), 96, 3)):
+        for seed in (0, 1, 2):
+            g, h, tr, th, (f, s), (fh, sh), _ = _arb_case(oracle, kw, n, seed, ny)
+            assert np.array_equal(tr, th) and g.size() == h.size()
+            assert np.array_equal(g.state()[3], h.state()[3])                      # same basis vectors, same order
+            assert np.max(np.abs(f - fh)) <= 2e-5 * np.max(np.abs(fh))
+            assert np.max(np.abs(s - sh)) <= 2e-5 * np.max(sh)
+    # first-point closed form and the decision byte of an empty GP
+    assert tr[0] == 0x81 and th[0] == 0x81
+
+
+def test_arbiter_default_hyperparameters_regime(oracle):
+    """The reference's own hyper-parameters (sigma_f^2 = 100, l^2 = 1 on a 0.15 m patch): every K_ij is in [97.8, 100],
+    gamma sits at eps_tol and |Q| ~ 1e6, so `gamma < eps_tol` (src/sparse_gp.hpp:155) is decided by fp64 rounding noise.
+    Measured against the exact (binary128) recursion on 12 patches of 256 points:
+      * the exact recursion settles on ~10 basis vectors; the fp64 C oracle takes a different branch at 2-4 % of the points
+        (first one after ~10 points) and ends with 8-19 vectors; the NumPy restatement (BLAS summation order) differs from
+        both -- three correct fp64 implementations, three answers;
+      * f* of either fp64 implementation is typically 1e-3 .. 1e-2 of max|f*| away from the exact recursion, with a tail
+        (4e-2 on these 12 patches; whole-patch blow-ups appear among the 32768 patches of the bench's C4 "defaults" record).
+    This is the evidence behind `ftol 1e-2 .. 2e-2 RMS, basis counts not compared` in tests/test_sparse_gpu.py: in this regime
+    an fp64 implementation -- the reference's own Eigen build included -- is one sample of a distribution, and parity can
+    only be stated as "the GPU is as close to the exact recursion as the CPU oracle is" (test_sparse_gpu_vs_arbiter)."""
+    wrong_c, wrong_np, err_c, err_np, sizes = [], [], [], [], []
+    for seed in range(12):
+        g, h, tr, th, (f, s), (fh, sh), (x0, x1, y, perm, p) = _arb_case(oracle, {}, 256, 40 + seed)
+        gp = R.SparseGP(ny=1)
+        X = np.stack([x0, x1], 1)
+        for i in perm:
+            gp.add(X[i], y[:, i])
+        xs0, xs1 = oracle.grid(0.15, 20)
+        fn = gp.alpha[:, 0] @ R.rbf(gp.p0, gp.p1, gp.BV, np.stack([xs0, xs1], 1))
+        scale = np.max(np.abs(fh))
+        wrong_c.append(np.mean(tr != th))
+        err_c.append(np.max(np.abs(f - fh)) / scale)
+        err_np.append(np.max(np.abs(fn - fh[0])) / scale)
+        sizes.append((h.size(), g.size(), gp.b))
+    print("defaults regime: basis sizes (exact, C fp64, NumPy fp64):", sizes)
+    print("fraction of decisions the C oracle takes differently from the exact recursion:", np.round(wrong_c, 3))
+    print("max|f - f_exact| / max|f_exact|: C oracle", np.round(err_c, 5), " NumPy", np.round(err_np, 5))
+    assert 0.0 < np.mean(wrong_c) < 0.10
+    assert np.median(err_c) <= 1e-2 and np.median(err_np) <= 1e-2 and max(err_c) <= 0.1 and max(err_np) <= 0.1
+    assert len({b for b, _, _ in sizes}) <= 3 and len({c for _, c, _ in sizes}) >= 3     # exact: stable; fp64: scattered
