@@ -11,7 +11,7 @@
 //
 // State layout in HBM (persistent across calls, /root/reference/src/gp_mapping.cpp:338-339 keeps adding to
 // trained GPs):  alpha [P][ny][ld], C [P][ld][ld], Q [P][ld][ld] column-major like Eigen, BV [P][ld][2] (AoS,
-// = Eigen 2 x b column-major), b [P], total_count [P];  ld = capacity + 1 (a full update may hold capacity+1
+// = Eigen 2 x b column-major), b [P], total_count [P];  ld = capacity + 1 rounded up to 16 (a full update may hold capacity+1
 // basis vectors until the deletion that follows it), or GPC_MAX_BV when capacity == -1.
 #include <cstdlib>
 #include <vector>
@@ -1085,7 +1085,11 @@ int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc
     gpc_sparse* g = new (std::nothrow) gpc_sparse();
     if (!g) return GPC_ENOMEM;
     g->ctx = ctx; g->prm = *params; g->P = P; g->ny = ny;
-    g->ld = params->capacity == -1 ? GPC_MAX_BV : params->capacity + 1;
+    // capacity + 1 rows (a full update holds capacity + 1 basis vectors until the deletion that follows it), rounded up to 16
+    // doubles = 128 B: every column of C and Q then starts on a cache line, and a wave's 64-row segment is exactly 4 lines.
+    // With ld = 201 the segments straddled lines -- 5 fetched per 4 used, re-fetched from HBM by the next row trip -- and
+    // the add path, which is bound by exactly this stream, read 27 % more than it consumed (profiles/r02_summary.json).
+    g->ld = params->capacity == -1 ? GPC_MAX_BV : ((params->capacity + 1 + 15) & ~15);
     g->alpha = g->C = g->Q = g->BV = nullptr;
     g->b = g->count = g->stat = nullptr;
     g->done_it = nullptr;
