@@ -48,7 +48,7 @@ def build(force=False, verbose=False, extra_flags=(), lib=None):
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target + ".tmp", *objs]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target + ".tmp", *objs, "-ldl"]
     subprocess.check_call(cmd)
     os.replace(target + ".tmp", target)
     if tag:

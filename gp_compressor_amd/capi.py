@@ -96,6 +96,19 @@ PROTOTYPES = {
     "gpc_patches_fetch": (C.c_int, [_vp] * 11),
     "gpc_patches_destroy": (None, [_vp]),
     "gpc_partition_patches": (C.c_int, [_i, _vp, _i, _i, _vp]),
+    "gpc_comm_unique_id": (C.c_int, [_vp]),
+    "gpc_comm_create": (C.c_int, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "gpc_comm_create_all": (C.c_int, [_i, C.POINTER(_vp), C.POINTER(_vp)]),
+    "gpc_comm_adopt": (C.c_int, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "gpc_comm_destroy": (None, [_vp]),
+    "gpc_comm_world": (C.c_int, [_vp]),
+    "gpc_comm_rank": (C.c_int, [_vp]),
+    "gpc_comm_library": (C.c_char_p, []),
+    "gpc_comm_set_partition": (C.c_int, [_vp, _i, _vp]),
+    "gpc_group_start": (C.c_int, []),
+    "gpc_group_end": (C.c_int, []),
+    "gpc_allgather_fstar_dev": (C.c_int, [_vp, _i, _vp, _vp, _vp]),
+    "gpc_unpermute_fstar_dev": (C.c_int, [_vp, _i, _vp, _vp]),
     "gpc_test_exp_host": (None, [_vp, _vp, _i]),
     "gpc_test_exp_small_host": (None, [_vp, _vp, _i]),
 }
@@ -493,6 +506,57 @@ def _sparse_set_state(self, bv_count, alpha, BV, C_=None, Q=None):
 
 
 Sparse.set_state = _sparse_set_state
+
+
+class Comm:
+    """gpc_comm: the communicator of the single all-gather (one per context).  Comm(ctx, world, rank, unique_id) creates one
+    through RCCL (unique_id: the 128 bytes of Comm.unique_id() on rank 0); Comm.all(ctxs) is the one-process form."""
+
+    def __init__(self, ctx, world=1, rank=0, unique_id=None, handle=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        if handle is None:
+            uid = unique_id if unique_id is not None else Comm.unique_id()
+            buf = (C.c_char * 128).from_buffer_copy(uid)
+            handle = _vp()
+            ctx._check(self.lib.gpc_comm_create(ctx.h, world, rank, C.addressof(buf), C.byref(handle)))
+        self.h = handle
+        ctx._children.add(self)
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        rc = load().gpc_comm_unique_id(C.addressof(buf))
+        if rc != GPC_OK:
+            raise GpcError(rc, "gpc_comm_unique_id (RCCL not found?)")
+        return bytes(buf)
+
+    @staticmethod
+    def all(ctxs):
+        lib = load()
+        n = len(ctxs)
+        hs = (_vp * n)(*[c.h for c in ctxs])
+        outs = (_vp * n)()
+        rc = lib.gpc_comm_create_all(n, hs, outs)
+        if rc != GPC_OK:
+            raise GpcError(rc, lib.gpc_last_error(ctxs[0].h).decode())
+        return [Comm(ctxs[i], handle=_vp(outs[i])) for i in range(n)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gpc_comm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_partition(self, P, slots):
+        sl = np.ascontiguousarray(slots, dtype=np.int32).reshape(-1)
+        self.ctx._check(self.lib.gpc_comm_set_partition(self.h, int(P), _ptr(sl)))
+
+    def allgather_fstar_dev(self, row_doubles, local_f, gathered, f_star=None):
+        self.ctx._check(self.lib.gpc_allgather_fstar_dev(self.h, int(row_doubles), _ptr(local_f), _ptr(gathered), _ptr(f_star)))
+
+    def unpermute_fstar_dev(self, row_doubles, gathered, f_star):
+        self.ctx._check(self.lib.gpc_unpermute_fstar_dev(self.h, int(row_doubles), _ptr(gathered), _ptr(f_star)))
 
 
 def partition_patches(off, world, sparse_capacity=0):

@@ -659,7 +659,8 @@ size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
     int waves, npad, per_cu;
     big_shape(a, &waves, &npad, &per_cu);
     const int ntw = (a.n_max + MF_TS - 1) / MF_TS;
-    const int cap = ctx->num_cus * per_cu;
+    int cap = ctx->num_cus * per_cu;
+    if (const char* e = getenv("GPC_BIG_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;   // diagnostic: resident-workgroup experiments
     const int grid = a.P < cap ? a.P : cap;
     if (grid_out) *grid_out = grid;
     return sizeof(double) * big_slot_doubles(ntw) * (size_t)grid;

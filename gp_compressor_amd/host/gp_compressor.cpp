@@ -118,8 +118,132 @@ void gp_compressor::release_device()
     d_dense_f_ = d_dense_c_ = nullptr;
 }
 
+void gp_compressor::set_devices(const std::vector<int>& devices)
+{
+    for (gpc_comm* c : shard_comm_) gpc_comm_destroy(c);
+    for (gpc_ctx* c : shard_ctx_) gpc_ctx_destroy(c);
+    shard_comm_.clear();
+    shard_ctx_.clear();
+    devices_ = devices;
+}
+
+// The dense model over several GPUs: the batched form of "patches shard embarrassingly, one all-gather reassembles the
+// decompressed cloud" (BASELINE north_star; patches are independent, src/gp_compressor.cpp:146-163).
+void gp_compressor::train_dense_sharded()
+{
+    const int P = batch_.patches(), m = sz_ * sz_, world = (int)devices_.size();
+    if (shard_ctx_.empty()) {
+        shard_ctx_.assign(world, nullptr);
+        for (int r = 0; r < world; ++r) check(gpc_ctx_create(&shard_ctx_[r], devices_[r]), nullptr, "gpc_ctx_create (shard)");
+        shard_comm_.assign(world, nullptr);
+        check(gpc_comm_create_all(world, shard_ctx_.data(), shard_comm_.data()), shard_ctx_[0], "gpc_comm_create_all");
+    }
+    const int S = (P + world - 1) / world;
+    std::vector<int32_t> slots((size_t)S * world);
+    check(gpc_partition_patches(P, batch_.off.data(), world, 0, slots.data()), nullptr, "gpc_partition_patches");
+    const size_t N = batch_.x0.size();
+    struct Shard {
+        std::vector<int32_t> off;
+        std::vector<double> x0, x1, y, rgb;
+        int n_max = 0;
+        void *d_off = nullptr, *d_x0 = nullptr, *d_x1 = nullptr, *d_y = nullptr, *d_rgb = nullptr, *d_st = nullptr;
+        void *d_lf = nullptr, *d_lc = nullptr, *d_gf = nullptr, *d_gc = nullptr, *d_f = nullptr, *d_c = nullptr;
+    };
+    std::vector<Shard> sh(world);
+    auto free_all = [&]() {
+        for (int r = 0; r < world; ++r)
+            for (void* q : {sh[r].d_off, sh[r].d_x0, sh[r].d_x1, sh[r].d_y, sh[r].d_rgb, sh[r].d_st, sh[r].d_lf, sh[r].d_lc, sh[r].d_gf,
+                            sh[r].d_gc, sh[r].d_f, sh[r].d_c})
+                if (q) (void)gpc_dev_free(shard_ctx_[r], q);
+    };
+    try {
+        for (int r = 0; r < world; ++r) {
+            Shard& s = sh[r];
+            gpc_ctx* c = shard_ctx_[r];
+            // this device's slots as a CSR batch (padding slots are empty patches)
+            s.off.assign(S + 1, 0);
+            for (int q = 0; q < S; ++q) {
+                const int p = slots[(size_t)r * S + q];
+                const int n = p >= 0 ? batch_.off[p + 1] - batch_.off[p] : 0;
+                s.off[q + 1] = s.off[q] + n;
+                s.n_max = std::max(s.n_max, n);
+            }
+            const size_t Nl = (size_t)s.off[S];
+            s.x0.resize(Nl); s.x1.resize(Nl); s.y.resize(Nl); s.rgb.resize(3 * Nl);
+            for (int q = 0; q < S; ++q) {
+                const int p = slots[(size_t)r * S + q];
+                if (p < 0) continue;
+                const size_t o = (size_t)batch_.off[p], n = (size_t)(batch_.off[p + 1] - batch_.off[p]), lo = (size_t)s.off[q];
+                std::copy_n(&batch_.x0[o], n, &s.x0[lo]);
+                std::copy_n(&batch_.x1[o], n, &s.x1[lo]);
+                std::copy_n(&batch_.y[o], n, &s.y[lo]);
+                for (int a = 0; a < 3; ++a) std::copy_n(&batch_.rgb[a * N + o], n, &s.rgb[a * Nl + lo]);
+            }
+            auto up = [&](void** d, const void* h, size_t bytes) {
+                check(gpc_dev_malloc(c, bytes, d), c, "gpc_dev_malloc (shard)");
+                if (bytes) check(gpc_dev_memcpy(c, *d, h, bytes, GPC_COPY_H2D), c, "gpc_dev_memcpy (shard)");
+            };
+            up(&s.d_off, s.off.data(), sizeof(int32_t) * (size_t)(S + 1));
+            up(&s.d_x0, s.x0.data(), 8 * Nl);
+            up(&s.d_x1, s.x1.data(), 8 * Nl);
+            up(&s.d_y, s.y.data(), 8 * Nl);
+            up(&s.d_rgb, s.rgb.data(), 24 * Nl);
+            check(gpc_dev_malloc(c, sizeof(int32_t) * (size_t)S, &s.d_st), c, "gpc_dev_malloc");
+            check(gpc_dev_malloc(c, 8 * (size_t)S * m, &s.d_lf), c, "gpc_dev_malloc");
+            check(gpc_dev_malloc(c, 8 * (size_t)S * 3 * m, &s.d_lc), c, "gpc_dev_malloc");
+            check(gpc_dev_malloc(c, 8 * (size_t)S * world * m, &s.d_gf), c, "gpc_dev_malloc");
+            check(gpc_dev_malloc(c, 8 * (size_t)S * world * 3 * m, &s.d_gc), c, "gpc_dev_malloc");
+            if (r == 0) {
+                check(gpc_dev_malloc(c, 8 * (size_t)P * m, &s.d_f), c, "gpc_dev_malloc");
+                check(gpc_dev_malloc(c, 8 * (size_t)P * 3 * m, &s.d_c), c, "gpc_dev_malloc");
+            }
+            check(gpc_comm_set_partition(shard_comm_[r], P, slots.data()), c, "gpc_comm_set_partition");
+        }
+        // every device fits + predicts its slots: the launches only enqueue, so the devices run concurrently
+        for (int r = 0; r < world; ++r) {
+            Shard& s = sh[r];
+            gpc_ctx* c = shard_ctx_[r];
+            check(gpc_dense_fit_predict_grid_dev(c, &dense_params, S, (const int32_t*)s.d_off, s.n_max, s.off[S], (const double*)s.d_x0,
+                                                 (const double*)s.d_x1, (const double*)s.d_y, 1, res_, sz_, (double*)s.d_lf, nullptr,
+                                                 (int32_t*)s.d_st), c, "gpc_dense_fit_predict_grid_dev (shard, depth)");
+            check(gpc_dense_fit_predict_grid_dev(c, &dense_params, S, (const int32_t*)s.d_off, s.n_max, s.off[S], (const double*)s.d_x0,
+                                                 (const double*)s.d_x1, (const double*)s.d_rgb, 3, res_, sz_, (double*)s.d_lc, nullptr,
+                                                 nullptr), c, "gpc_dense_fit_predict_grid_dev (shard, rgb)");
+        }
+        // the one exchange: all-gather of the depth grids and of the colour grids (inside one bracket: one fused exchange)
+        check(gpc_group_start(), shard_ctx_[0], "gpc_group_start");
+        for (int r = 0; r < world; ++r) {
+            check(gpc_allgather_fstar_dev(shard_comm_[r], m, (const double*)sh[r].d_lf, (double*)sh[r].d_gf, nullptr), shard_ctx_[r], "all-gather f*");
+            check(gpc_allgather_fstar_dev(shard_comm_[r], 3 * m, (const double*)sh[r].d_lc, (double*)sh[r].d_gc, nullptr), shard_ctx_[r], "all-gather c*");
+        }
+        check(gpc_group_end(), shard_ctx_[0], "gpc_group_end");
+        // device 0 un-permutes to patch order and hands the grids to the host flow (load_compressed reprojects them)
+        check(gpc_unpermute_fstar_dev(shard_comm_[0], m, (const double*)sh[0].d_gf, (double*)sh[0].d_f), shard_ctx_[0], "un-permute f*");
+        check(gpc_unpermute_fstar_dev(shard_comm_[0], 3 * m, (const double*)sh[0].d_gc, (double*)sh[0].d_c), shard_ctx_[0], "un-permute c*");
+        dense_f_.assign((size_t)P * m, 0.0);
+        dense_c_.assign((size_t)P * 3 * m, 0.0);
+        check(gpc_dev_memcpy(shard_ctx_[0], dense_f_.data(), sh[0].d_f, 8 * (size_t)P * m, GPC_COPY_D2H), shard_ctx_[0], "download f*");
+        check(gpc_dev_memcpy(shard_ctx_[0], dense_c_.data(), sh[0].d_c, 8 * (size_t)P * 3 * m, GPC_COPY_D2H), shard_ctx_[0], "download c*");
+        std::vector<int32_t> st(S);
+        for (int r = 0; r < world; ++r) {
+            check(gpc_dev_memcpy(shard_ctx_[r], st.data(), sh[r].d_st, sizeof(int32_t) * (size_t)S, GPC_COPY_D2H), shard_ctx_[r], "download status");
+            for (int q = 0; q < S; ++q) {
+                const int p = slots[(size_t)r * S + q];
+                if (p >= 0) status_[p] = st[q];
+            }
+        }
+        for (int r = 0; r < world; ++r) check(gpc_ctx_synchronize(shard_ctx_[r]), shard_ctx_[r], "gpc_ctx_synchronize");
+    } catch (...) {
+        free_all();
+        throw;
+    }
+    free_all();
+}
+
 gp_compressor::~gp_compressor()
 {
+    for (gpc_comm* c : shard_comm_) gpc_comm_destroy(c);
+    for (gpc_ctx* c : shard_ctx_) gpc_ctx_destroy(c);
     release_device();
     if (gps_) gpc_sparse_destroy(gps_);
     if (rgb_gps_) gpc_sparse_destroy(rgb_gps_);
@@ -129,7 +253,7 @@ gp_compressor::~gp_compressor()
 // src/gp_compressor.cpp:21-27
 void gp_compressor::save_compressed(const std::string& /*name: ignored by the reference too*/)
 {
-    if (gpu_producer) project_cloud_device(); else project_cloud();
+    if (gpu_producer && devices_.empty()) project_cloud_device(); else project_cloud();
     train_processes();
 }
 
@@ -358,14 +482,18 @@ void gp_compressor::train_processes()
         return;
     }
     if (model_ == gp_model::dense) {
-        dense_f_.assign((size_t)P * m, 0.0);
-        dense_c_.assign((size_t)P * 3 * m, 0.0);
-        check(gpc_dense_fit_predict_grid(ctx_, &dense_params, P, batch_.off.data(), batch_.x0.data(), batch_.x1.data(),
-                                         batch_.y.data(), 1, res_, sz_, dense_f_.data(), nullptr, status_.data()),
-              ctx_, "gpc_dense_fit_predict_grid(depth)");
-        check(gpc_dense_fit_predict_grid(ctx_, &dense_params, P, batch_.off.data(), batch_.x0.data(), batch_.x1.data(),
-                                         batch_.rgb.data(), 3, res_, sz_, dense_c_.data(), nullptr, status_.data()),
-              ctx_, "gpc_dense_fit_predict_grid(rgb)");
+        if (!devices_.empty()) {
+            train_dense_sharded();
+        } else {
+            dense_f_.assign((size_t)P * m, 0.0);
+            dense_c_.assign((size_t)P * 3 * m, 0.0);
+            check(gpc_dense_fit_predict_grid(ctx_, &dense_params, P, batch_.off.data(), batch_.x0.data(), batch_.x1.data(),
+                                             batch_.y.data(), 1, res_, sz_, dense_f_.data(), nullptr, status_.data()),
+                  ctx_, "gpc_dense_fit_predict_grid(depth)");
+            check(gpc_dense_fit_predict_grid(ctx_, &dense_params, P, batch_.off.data(), batch_.x0.data(), batch_.x1.data(),
+                                             batch_.rgb.data(), 3, res_, sz_, dense_c_.data(), nullptr, status_.data()),
+                  ctx_, "gpc_dense_fit_predict_grid(rgb)");
+        }
         mean_added_ = 0;
         max_added_ = 0;
         for (int i = 0; i < P; ++i) {
@@ -679,6 +807,10 @@ int gpc_host_project_device(void* h, char* err, int errlen)
 {
     try { static_cast<gpc::gp_compressor*>(h)->project_cloud_device(); return 0; }
     catch (const std::exception& e) { if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", e.what()); return -1; }
+}
+void gpc_host_set_devices(void* h, const int* devices, int n)
+{
+    static_cast<gpc::gp_compressor*>(h)->set_devices(std::vector<int>(devices, devices + (n > 0 ? n : 0)));
 }
 void gpc_host_set_gpu_producer(void* h, int on) { static_cast<gpc::gp_compressor*>(h)->gpu_producer = on != 0; }
 int gpc_host_patch_count(void* h) { return static_cast<gpc::gp_compressor*>(h)->patches().patches(); }

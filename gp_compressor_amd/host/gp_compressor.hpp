@@ -90,6 +90,11 @@ public:
     // statistics the reference prints ("Mean added" / "Max added", :173-174)
     double mean_added() const { return mean_added_; }
     int max_added() const { return max_added_; }
+    // Multi-GPU: the reference is one process, so one process drives the GPUs of the node -- one gpc_ctx per
+    // device, gpc_partition_patches (longest-processing-time) deals the patches, every device fits + predicts its slots and ONE
+    // RCCL all-gather (gpc_comm_create_all + gpc_group bracket) reassembles the grids.  Dense model, host-cut patches
+    // (save_compressed() then runs project_cloud() on the host); an empty list returns to the single-device flow.
+    void set_devices(const std::vector<int>& devices);
     // insertion-order source; default std::rand like sparse_gp::shuffle (src/sparse_gp.hpp:43-56)
     std::function<int()> rng;
     // hyper-parameters (defaults = the reference's compile-time constants)
@@ -118,6 +123,10 @@ protected:
     gpc_patches* dev_patches_ = nullptr;
     double *d_dense_f_ = nullptr, *d_dense_c_ = nullptr;
     void release_device();
+    void train_dense_sharded();
+    std::vector<int> devices_;                // set_devices(): non-empty = the sharded dense flow
+    std::vector<gpc_ctx*> shard_ctx_;         // one per device (shard_ctx_[0] is its own context, not ctx_)
+    std::vector<gpc_comm*> shard_comm_;
     std::vector<int32_t> status_;
     double mean_added_ = 0.0;
     int max_added_ = 0;

@@ -36,6 +36,7 @@ def load():
         L.gpc_host_project.argtypes = [vp]
         L.gpc_host_project_device.argtypes = [vp, vp, i]
         L.gpc_host_set_gpu_producer.argtypes = [vp, i]
+        L.gpc_host_set_devices.argtypes = [vp, vp, i]
         L.gpc_host_patch_count.argtypes = [vp]
         L.gpc_host_point_count.argtypes = [vp]
         L.gpc_host_get_batch.argtypes = [vp] * 9
@@ -69,6 +70,11 @@ class GpCompressor:
     def set_gpu_producer(self, on):
         """save_compressed(): cut the patches on the GPU and keep the whole round trip on the device (default), or on the host"""
         self.L.gpc_host_set_gpu_producer(self.h, int(bool(on)))
+
+    def set_devices(self, devices):
+        """multi-GPU mode of the dense model: one process drives these devices (gp_compressor::set_devices); [] switches it off"""
+        d = np.ascontiguousarray(devices, dtype=np.int32)
+        self.L.gpc_host_set_devices(self.h, d.ctypes.data if len(d) else None, len(d))
 
     def set_sparse_kernel(self, sigmaf_sq, l_sq, s20_depth, s20_rgb, capacity):
         self.L.gpc_host_set_sparse_kernel(self.h, sigmaf_sq, l_sq, s20_depth, s20_rgb, capacity)

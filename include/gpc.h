@@ -295,6 +295,38 @@ void gpc_patches_destroy(gpc_patches* p);
  * slot_patch has world*ceil(P/world) entries (patch id or -1 for padding), rank r owns slots [r*S, (r+1)*S). */
 int gpc_partition_patches(int P, const int32_t* off, int world, int sparse_capacity, int32_t* slot_patch);
 
+/* ---- multi-GPU: the one exchange step ------------------------------------------------------- */
+/* Every rank fits + predicts the S = ceil(P / world) slots gpc_partition_patches gave it; ONE ncclAllGather of the slot buffers
+ * over RCCL / xGMI, then a device gather to patch order, reassembles f_star [P][row] on every rank.  RCCL is bound at run time
+ * (no link-time dependency; a copy already loaded in the process, e.g. PyTorch's, is shared).
+ *   one process per GPU:      rank 0 calls gpc_comm_unique_id and hands the 128 bytes to the other ranks by whatever channel
+ *                             the host has (file, socket, MPI); every rank: gpc_comm_create(ctx, world, rank, id, &c).
+ *                             A communicator the host created itself goes through gpc_comm_adopt (ncclComm_t as void*; not owned).
+ *   one process, N GPUs (how the single-process reference would use a node): one gpc_ctx per device, gpc_comm_create_all, and
+ *                             the per-device calls bracketed by gpc_group_start / gpc_group_end.  Inside a bracket the
+ *                             collectives are only enqueued at gpc_group_end, so pass f_star = NULL to gpc_allgather_fstar_dev
+ *                             there and run gpc_unpermute_fstar_dev per device after the bracket.
+ * gpc_comm_set_partition(c, P, slot_patch) takes the table gpc_partition_patches filled (host pointer, world * S entries) and
+ * keeps its inverse on the device.  gpc_allgather_fstar_dev: local_f [S][row_doubles] (this rank's slots, padding slots
+ * included), gathered [world * S][row_doubles] scratch, f_star [P][row_doubles] or NULL; all DEVICE pointers, enqueued on the
+ * context's stream, no synchronisation.  A gpc_comm holds a reference on its context like the other children. */
+typedef struct gpc_comm gpc_comm;
+#define GPC_UNIQUE_ID_BYTES 128
+int gpc_comm_unique_id(void* id128);
+int gpc_comm_create(gpc_ctx* ctx, int world, int rank, const void* id128, gpc_comm** out);
+int gpc_comm_create_all(int ndev, gpc_ctx* const* ctxs, gpc_comm** out /* ndev */);
+int gpc_comm_adopt(gpc_ctx* ctx, void* nccl_comm, int world, int rank, gpc_comm** out);
+void gpc_comm_destroy(gpc_comm* c);
+int gpc_comm_world(const gpc_comm* c);
+int gpc_comm_rank(const gpc_comm* c);
+/* path of the RCCL library in use ("" before the first communicator) */
+const char* gpc_comm_library(void);
+int gpc_comm_set_partition(gpc_comm* c, int P, const int32_t* slot_patch);
+int gpc_group_start(void);
+int gpc_group_end(void);
+int gpc_allgather_fstar_dev(gpc_comm* c, int row_doubles, const double* local_f, double* gathered, double* f_star);
+int gpc_unpermute_fstar_dev(gpc_comm* c, int row_doubles, const double* gathered, double* f_star);
+
 /* ---- diagnostics ------------------------------------------------------------------------------------------------ */
 /* Host-side evaluation of the table-driven exp() the kernels use for the RBF kernel (same source, csrc/gpc_device.h),
  * so that its error against libm -- which the reference calls, src/rbf_kernel.cpp:17 -- can be bounded without a GPU. */

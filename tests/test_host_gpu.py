@@ -148,3 +148,22 @@ def test_device_resident_round_trip_equals_host_buffers(H, model):
         assert np.array_equal(a_xyz, b_xyz) and np.array_equal(a_rgb, b_rgb)
     else:
         assert np.max(np.abs(a_xyz - b_xyz)) <= 1e-6 and np.max(np.abs(a_rgb.astype(int) - b_rgb.astype(int))) <= 1
+
+
+def test_multi_gpu_mode_of_the_host_class(H):
+    """gp_compressor::set_devices: the C++ surface -- not only the Python bench -- shards the dense flow: one gpc_ctx per device,
+    gpc_partition_patches, per-device fit + predict, ONE RCCL all-gather (gpc_comm_create_all + gpc_group bracket), un-permute.
+    The box has one GPU, so the device list is [0] (world 1: the exchange degenerates, every other step is the N-device
+    code); the cloud must equal the single-device flow's (dense partial sums meet in LDS atomics: equal to a float ulp)."""
+    res, sz = 0.15, 20
+    xyz, rgb = H.synthetic_plane_cloud(10000, seed=5)
+    clouds = []
+    for devices in (None, [0]):
+        g = H.GpCompressor(xyz, rgb, res=res, sz=sz, model="dense", seed=3)
+        g.set_gpu_producer(False)
+        if devices is not None:
+            g.set_devices(devices)
+        clouds.append(g.roundtrip())
+    (a_xyz, a_rgb, a_mean, a_max), (b_xyz, b_rgb, b_mean, b_max) = clouds
+    assert a_xyz.shape == b_xyz.shape and len(a_xyz) == 64 * sz * sz and (a_mean, a_max) == (b_mean, b_max)
+    assert np.max(np.abs(a_xyz - b_xyz)) <= 1e-6 and np.max(np.abs(a_rgb.astype(int) - b_rgb.astype(int))) <= 1
