@@ -57,6 +57,8 @@ PROTOTYPES = {
     "gpc_dev_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "gpc_dev_free": (C.c_int, [_vp, _vp]),
     "gpc_dev_memcpy": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _i]),
+    "gpc_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "gpc_host_free": (C.c_int, [_vp, _vp]),
     "gpc_ctx_destroy": (None, [_vp]),
     "gpc_last_error": (C.c_char_p, [_vp]),
     "gpc_last_dense_kernel": (C.c_char_p, [_vp]),
@@ -212,6 +214,23 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.gpc_ctx_synchronize(self.h))
+
+    def host_array(self, shape, dtype=np.float64):
+        """a numpy array in page-locked memory (gpc_host_alloc): host-pointer entries transfer such buffers in place.
+        The memory lives until the process ends or free_host_array(a) is called."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = _vp()
+        self._check(self.lib.gpc_host_alloc(self.h, max(n, 8), C.byref(p)))
+        buf = (C.c_char * max(n, 8)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def free_host_array(self, a):
+        p = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        if p is not None:
+            self._check(self.lib.gpc_host_free(self.h, p))
 
     def last_dense_kernel(self):
         return self.lib.gpc_last_dense_kernel(self.h).decode()

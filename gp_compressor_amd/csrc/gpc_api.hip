@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <numeric>
+#include <condition_variable>
+#include <thread>
 #include <vector>
 
 #include "gpc_device.h"
@@ -137,6 +139,24 @@ int gpc_dev_free(gpc_ctx* ctx, void* p)
     return GPC_OK;
 }
 
+int gpc_host_alloc(gpc_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx || ctx->dead.load()) return GPC_EINVAL;
+    if (!out) return gpc_fail(ctx, GPC_EINVAL, "out is NULL");
+    *out = nullptr;
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    GPC_HIP(ctx, hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault));
+    return GPC_OK;
+}
+
+int gpc_host_free(gpc_ctx* ctx, void* p)
+{
+    if (!ctx) return GPC_EINVAL;
+    if (!p) return GPC_OK;
+    GPC_HIP(ctx, hipHostFree(p));
+    return GPC_OK;
+}
+
 int gpc_dev_memcpy(gpc_ctx* ctx, void* dst, const void* src, size_t bytes, int kind)
 {
     if (!ctx || ctx->dead.load()) return GPC_EINVAL;
@@ -163,6 +183,20 @@ void gpc_ctx_destroy(gpc_ctx* ctx)
         if (ctx->ws) (void)hipFree(ctx->ws);
         ctx->ws = nullptr;
         ctx->ws_bytes = 0;
+        if (ctx->s_in) {
+            (void)hipStreamSynchronize(ctx->s_in);
+            (void)hipStreamSynchronize(ctx->s_out);
+            (void)hipStreamDestroy(ctx->s_in);
+            (void)hipStreamDestroy(ctx->s_out);
+            for (auto& row : ctx->ev)
+                for (auto& e : row) if (e) (void)hipEventDestroy(e);
+            ctx->s_in = ctx->s_out = nullptr;
+        }
+        if (ctx->io) (void)hipFree(ctx->io);
+        if (ctx->pin_in) (void)hipHostFree(ctx->pin_in);
+        if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
+        ctx->io = ctx->pin_in = ctx->pin_out = nullptr;
+        ctx->io_bytes = ctx->pin_in_bytes = ctx->pin_out_bytes = 0;
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
         ctx->own_stream = nullptr;
         ctx->stream = nullptr;
@@ -312,6 +346,110 @@ int gpc_dense_fit_predict_grid_dev(gpc_ctx* ctx, const gpc_params* params, int P
 // ---- host-pointer wrappers: H2D, launch, D2H, synchronous -------------------------------------------------
 
 
+// Copy with several threads: staging pageable caller memory through pinned buffers is a CPU memcpy, and one core moves
+// ~10 GB/s where PCIe 5 moves 50.  A small pool owned by the process (created at the first host-pointer call on pageable
+// memory, joined at exit) splits every copy into one slice per thread.
+namespace {
+class CopyPool {
+public:
+    static CopyPool& get()
+    {
+        static CopyPool p;
+        return p;
+    }
+    void copy(void* dst, const void* src, size_t bytes)
+    {
+        if (bytes < (1u << 20) || th_.empty()) { std::memcpy(dst, src, bytes); return; }
+        std::unique_lock<std::mutex> lk(m_);
+        dst_ = (char*)dst; src_ = (const char*)src; bytes_ = bytes;
+        remaining_ = (int)th_.size();
+        ++gen_;
+        lk.unlock();
+        cv_.notify_all();
+        slice(0);                                   // the caller takes slice 0
+        lk.lock();
+        done_.wait(lk, [&] { return remaining_ == 0; });
+    }
+private:
+    CopyPool()
+    {
+        unsigned hc = std::thread::hardware_concurrency();
+        int n = (int)std::min(4u, hc > 2 ? hc / 2 : 1u);      // measured on the 16-CPU share of a 1-GPU box: 4 threads 4.35 ms per C2 call, 8: 6.6, 12: 4.4
+        if (const char* e = getenv("GPC_COPY_THREADS")) n = std::max(1, atoi(e));
+        parts_ = n;
+        for (int t = 1; t < n; ++t) th_.emplace_back([this, t] { run(t); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void slice(int t)
+    {
+        const size_t per = ((bytes_ / parts_) + 63) & ~(size_t)63;
+        const size_t lo = std::min(bytes_, per * t), hi = (t == parts_ - 1) ? bytes_ : std::min(bytes_, per * (t + 1));
+        if (lo < hi) std::memcpy(dst_ + lo, src_ + lo, hi - lo);
+    }
+    void run(int t)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (stop_) return;
+            lk.unlock();
+            slice(t);
+            lk.lock();
+            if (--remaining_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    char* dst_ = nullptr;
+    const char* src_ = nullptr;
+    size_t bytes_ = 0;
+    int parts_ = 1, remaining_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+};
+}  // namespace
+static void par_memcpy(void* dst, const void* src, size_t bytes) { CopyPool::get().copy(dst, src, bytes); }
+
+static bool is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+static int grow(gpc_ctx* ctx, void** p, size_t* have, size_t need, bool pinned)
+{
+    if (need <= *have) return GPC_OK;
+    if (*p) {
+        GPC_HIP(ctx, hipDeviceSynchronize());
+        if (pinned) GPC_HIP(ctx, hipHostFree(*p)); else GPC_HIP(ctx, hipFree(*p));
+        *p = nullptr;
+        *have = 0;
+    }
+    need = (need + (need >> 2) + 4095) & ~(size_t)4095;           // 25 % head-room: ragged batches of one cloud vary a little
+    if (pinned) GPC_HIP(ctx, hipHostMalloc(p, need, hipHostMallocDefault)); else GPC_HIP(ctx, hipMalloc(p, need));
+    *have = need;
+    return GPC_OK;
+}
+
+// Host-pointer entry of the dense path: H2D, kernel, D2H, synchronous for the caller -- but pipelined inside.  The batch is cut
+// into up to four chunks of whole patches; chunk c+1 goes up (copy stream, SDMA engine) and chunk c-1 comes down (second copy
+// stream) while the kernel runs on chunk c.  Pinned caller memory (gpc_host_alloc) is transferred in place; pageable memory is
+// staged through the context's pinned buffers by a threaded memcpy, which overlaps the GPU work of the previous chunk as well.
+// (Copies issued from pageable memory run as blit kernels that queue behind a compute kernel filling every CU: with those,
+// chunking overlaps nothing -- measured in round 1.)
 static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32_t* off,
                       const double* x0, const double* x1, const double* y, int ny,
                       int m, const double* xs0, const double* xs1, double res, int sz, bool grid,
@@ -327,46 +465,125 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
     if (rc != GPC_OK) return rc;
     if (!grid && m > 0 && (!xs0 || !xs1)) return gpc_fail(ctx, GPC_EINVAL, "xs0/xs1 is NULL");
     if (P == 0) return GPC_OK;
+    std::lock_guard<std::mutex> hlk(ctx->host_mu);
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     const bool want_v = !grid && params->want_variance && v_star;
-    DevBuf d_off, d_x0, d_x1, d_y, d_xs0, d_xs1, d_f, d_v, d_al, d_st;
     const size_t N = (size_t)n_total;
-    if ((rc = d_off.alloc(ctx, sizeof(int32_t) * (P + 1))) || (rc = d_x0.alloc(ctx, 8 * N)) || (rc = d_x1.alloc(ctx, 8 * N)) ||
-        (rc = d_y.alloc(ctx, 8 * N * ny)) || (rc = d_f.alloc(ctx, 8 * (size_t)P * ny * m)) ||
-        (rc = d_st.alloc(ctx, sizeof(int32_t) * P)))
-        return rc;
-    if (!grid && ((rc = d_xs0.alloc(ctx, 8 * (size_t)m)) || (rc = d_xs1.alloc(ctx, 8 * (size_t)m)))) return rc;
-    if (want_v && (rc = d_v.alloc(ctx, 8 * (size_t)P * m))) return rc;
-    if (alpha_out && (rc = d_al.alloc(ctx, 8 * N * ny))) return rc;
-    hipStream_t s = ctx->stream;
-    GPC_HIP(ctx, hipMemcpyAsync(d_off.p, off, sizeof(int32_t) * (P + 1), hipMemcpyHostToDevice, s));
-    if (N) {
-        GPC_HIP(ctx, hipMemcpyAsync(d_x0.p, x0, 8 * N, hipMemcpyHostToDevice, s));
-        GPC_HIP(ctx, hipMemcpyAsync(d_x1.p, x1, 8 * N, hipMemcpyHostToDevice, s));
-        GPC_HIP(ctx, hipMemcpyAsync(d_y.p, y, 8 * N * ny, hipMemcpyHostToDevice, s));
+    const int C = (P >= 2048 && !getenv("GPC_HOST_NO_PIPELINE")) ? 4 : 1;
+    if (!ctx->s_in) {
+        GPC_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
+        GPC_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
+        for (auto& row : ctx->ev)
+            for (auto& e : row) GPC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    // device arena: [off chunks | x0 | x1 | y planes per chunk | xs0 xs1 | f | v | alpha | status]
+    auto al256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t b_off = al256(sizeof(int32_t) * (size_t)(P + C)), b_x = al256(8 * N), b_y = al256(8 * N * ny), b_xs = al256(8 * (size_t)m),
+                 b_f = al256(8 * (size_t)P * ny * m), b_v = want_v ? al256(8 * (size_t)P * m) : 0, b_al = alpha_out ? al256(8 * N * ny) : 0,
+                 b_st = al256(sizeof(int32_t) * (size_t)P);
+    if ((rc = grow(ctx, &ctx->io, &ctx->io_bytes, b_off + 2 * b_x + b_y + 2 * b_xs + b_f + b_v + b_al + b_st, false))) return rc;
+    char* d = static_cast<char*>(ctx->io);
+    int32_t* d_off = (int32_t*)d; d += b_off;
+    double* d_x0 = (double*)d; d += b_x;
+    double* d_x1 = (double*)d; d += b_x;
+    double* d_y = (double*)d; d += b_y;
+    double* d_xs0 = (double*)d; d += b_xs;
+    double* d_xs1 = (double*)d; d += b_xs;
+    double* d_f = (double*)d; d += b_f;
+    double* d_v = (double*)d; d += b_v;
+    double* d_al = (double*)d; d += b_al;
+    int32_t* d_st = (int32_t*)d;
+    // pinned staging: inputs [off chunks | x0 | x1 | y] and outputs [f | v | alpha | status] -- only what is pageable on the caller's side
+    const bool pin_x = is_pinned(x0) && is_pinned(x1) && is_pinned(y), pin_f = (m == 0 || is_pinned(f_star)) && (!want_v || is_pinned(v_star));
+    if ((rc = grow(ctx, &ctx->pin_in, &ctx->pin_in_bytes, b_off + (pin_x ? 0 : 2 * b_x + b_y), true))) return rc;
+    if ((rc = grow(ctx, &ctx->pin_out, &ctx->pin_out_bytes, b_st + (pin_f ? 0 : b_f + b_v), true))) return rc;
+    char* hp = static_cast<char*>(ctx->pin_in);
+    int32_t* h_off = (int32_t*)hp; hp += b_off;
+    double* h_x0 = (double*)hp; hp += pin_x ? 0 : b_x;
+    double* h_x1 = (double*)hp; hp += pin_x ? 0 : b_x;
+    double* h_y = (double*)hp;
+    char* ho = static_cast<char*>(ctx->pin_out);
+    int32_t* h_st = (int32_t*)ho; ho += b_st;
+    double* h_f = (double*)ho; ho += pin_f ? 0 : b_f;
+    double* h_v = (double*)ho;
+    hipStream_t sc = ctx->stream, si = ctx->s_in, so = ctx->s_out;
+    // the arena may still be read by work a previous call left on the compute stream
+    GPC_HIP(ctx, hipEventRecord(ctx->ev[0][7], sc));
+    GPC_HIP(ctx, hipStreamWaitEvent(si, ctx->ev[0][7], 0));
     if (!grid && m) {
-        GPC_HIP(ctx, hipMemcpyAsync(d_xs0.p, xs0, 8 * (size_t)m, hipMemcpyHostToDevice, s));
-        GPC_HIP(ctx, hipMemcpyAsync(d_xs1.p, xs1, 8 * (size_t)m, hipMemcpyHostToDevice, s));
+        GPC_HIP(ctx, hipMemcpyAsync(d_xs0, xs0, 8 * (size_t)m, hipMemcpyHostToDevice, si));
+        GPC_HIP(ctx, hipMemcpyAsync(d_xs1, xs1, 8 * (size_t)m, hipMemcpyHostToDevice, si));
     }
-    if (grid)
-        rc = gpc_dense_fit_predict_grid_dev(ctx, params, P, d_off.as<int32_t>(), n_max, n_total, d_x0.as<double>(),
-                                            d_x1.as<double>(), d_y.as<double>(), ny, res, sz, d_f.as<double>(),
-                                            alpha_out ? d_al.as<double>() : nullptr, d_st.as<int32_t>());
-    else
-        rc = gpc_dense_fit_predict_dev(ctx, params, P, d_off.as<int32_t>(), n_max, n_total, d_x0.as<double>(),
-                                       d_x1.as<double>(), d_y.as<double>(), ny, m, d_xs0.as<double>(), d_xs1.as<double>(),
-                                       d_f.as<double>(), want_v ? d_v.as<double>() : nullptr,
-                                       alpha_out ? d_al.as<double>() : nullptr, d_st.as<int32_t>());
-    if (rc != GPC_OK) {
-        (void)hipStreamSynchronize(s);
-        return rc;
+    int p_lo[5];
+    for (int c = 0; c <= C; ++c) p_lo[c] = (int)((long long)P * c / C);
+    int fail = GPC_OK;
+    for (int c = 0; c < C && fail == GPC_OK; ++c) {
+        const int p0 = p_lo[c], Pc = p_lo[c + 1] - p0;
+        const size_t r0 = (size_t)off[p0], Nc = (size_t)off[p0 + Pc] - r0;
+        int32_t* ho_c = h_off + p0 + c;                                   // chunk c owns Pc + 1 entries
+        int nmax_c = 0;
+        for (int i = 0; i <= Pc; ++i) ho_c[i] = off[p0 + i] - off[p0];
+        for (int i = 0; i < Pc; ++i) nmax_c = std::max(nmax_c, ho_c[i + 1] - ho_c[i]);
+        int32_t* d_off_c = d_off + p0 + c;
+        GPC_HIP(ctx, hipMemcpyAsync(d_off_c, ho_c, sizeof(int32_t) * (size_t)(Pc + 1), hipMemcpyHostToDevice, si));
+        // chunk-local layout on the device: x0 | x1 | ny planes of Nc (the kernel's plane stride is the chunk's n_total)
+        double* dx0 = d_x0 + r0; double* dx1 = d_x1 + r0; double* dy = d_y + r0 * ny;
+        if (Nc) {
+            const double *sx0 = x0 + r0, *sx1 = x1 + r0;
+            if (!pin_x) {
+                par_memcpy(h_x0 + r0, sx0, 8 * Nc);
+                par_memcpy(h_x1 + r0, sx1, 8 * Nc);
+                sx0 = h_x0 + r0; sx1 = h_x1 + r0;
+            }
+            GPC_HIP(ctx, hipMemcpyAsync(dx0, sx0, 8 * Nc, hipMemcpyHostToDevice, si));
+            GPC_HIP(ctx, hipMemcpyAsync(dx1, sx1, 8 * Nc, hipMemcpyHostToDevice, si));
+            for (int q = 0; q < ny; ++q) {
+                const double* sy = y + (size_t)q * N + r0;
+                if (!pin_x) { par_memcpy(h_y + r0 * ny + q * Nc, sy, 8 * Nc); sy = h_y + r0 * ny + q * Nc; }
+                GPC_HIP(ctx, hipMemcpyAsync(dy + q * Nc, sy, 8 * Nc, hipMemcpyHostToDevice, si));
+            }
+        }
+        GPC_HIP(ctx, hipEventRecord(ctx->ev[0][c], si));
+        GPC_HIP(ctx, hipStreamWaitEvent(sc, ctx->ev[0][c], 0));
+        double* df = d_f + (size_t)p0 * ny * m;
+        if (grid)
+            rc = gpc_dense_fit_predict_grid_dev(ctx, params, Pc, d_off_c, nmax_c, (int)Nc, dx0, dx1, dy, ny, res, sz, df,
+                                                alpha_out ? d_al + r0 * ny : nullptr, d_st + p0);
+        else
+            rc = gpc_dense_fit_predict_dev(ctx, params, Pc, d_off_c, nmax_c, (int)Nc, dx0, dx1, dy, ny, m, d_xs0, d_xs1, df,
+                                           want_v ? d_v + (size_t)p0 * m : nullptr, alpha_out ? d_al + r0 * ny : nullptr, d_st + p0);
+        if (rc != GPC_OK) { fail = rc; break; }
+        GPC_HIP(ctx, hipEventRecord(ctx->ev[1][c], sc));
+        GPC_HIP(ctx, hipStreamWaitEvent(so, ctx->ev[1][c], 0));
+        if (m) GPC_HIP(ctx, hipMemcpyAsync(pin_f ? (void*)(f_star + (size_t)p0 * ny * m) : (void*)(h_f + (size_t)p0 * ny * m), df,
+                                           8 * (size_t)Pc * ny * m, hipMemcpyDeviceToHost, so));
+        if (want_v && m) GPC_HIP(ctx, hipMemcpyAsync(pin_f ? (void*)(v_star + (size_t)p0 * m) : (void*)(h_v + (size_t)p0 * m), d_v + (size_t)p0 * m,
+                                                     8 * (size_t)Pc * m, hipMemcpyDeviceToHost, so));
+        GPC_HIP(ctx, hipMemcpyAsync(h_st + p0, d_st + p0, sizeof(int32_t) * (size_t)Pc, hipMemcpyDeviceToHost, so));
+        GPC_HIP(ctx, hipEventRecord(ctx->ev[2][c], so));
     }
-    if (m) GPC_HIP(ctx, hipMemcpyAsync(f_star, d_f.p, 8 * (size_t)P * ny * m, hipMemcpyDeviceToHost, s));
-    if (want_v && m) GPC_HIP(ctx, hipMemcpyAsync(v_star, d_v.p, 8 * (size_t)P * m, hipMemcpyDeviceToHost, s));
-    if (alpha_out && N) GPC_HIP(ctx, hipMemcpyAsync(alpha_out, d_al.p, 8 * N * ny, hipMemcpyDeviceToHost, s));
-    if (status) GPC_HIP(ctx, hipMemcpyAsync(status, d_st.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, s));
-    GPC_HIP(ctx, hipStreamSynchronize(s));
+    if (fail != GPC_OK) {
+        (void)hipStreamSynchronize(si); (void)hipStreamSynchronize(sc); (void)hipStreamSynchronize(so);
+        return fail;
+    }
+    // alpha has chunk-local planes on the device ([ny][Nc] per chunk): gathered plane by plane at the end (rarely requested)
+    for (int c = 0; c < C; ++c) {
+        const int p0 = p_lo[c], Pc = p_lo[c + 1] - p0;
+        GPC_HIP(ctx, hipEventSynchronize(ctx->ev[2][c]));
+        if (!pin_f && m) par_memcpy(f_star + (size_t)p0 * ny * m, h_f + (size_t)p0 * ny * m, 8 * (size_t)Pc * ny * m);
+        if (!pin_f && want_v && m) par_memcpy(v_star + (size_t)p0 * m, h_v + (size_t)p0 * m, 8 * (size_t)Pc * m);
+        if (status) std::memcpy(status + p0, h_st + p0, sizeof(int32_t) * (size_t)Pc);
+    }
+    if (alpha_out && N) {
+        for (int c = 0; c < C; ++c) {
+            const int p0 = p_lo[c], Pc = p_lo[c + 1] - p0;
+            const size_t r0 = (size_t)off[p0], Nc = (size_t)off[p0 + Pc] - r0;
+            for (int q = 0; q < ny && Nc; ++q)
+                GPC_HIP(ctx, hipMemcpyAsync(alpha_out + (size_t)q * N + r0, d_al + r0 * ny + q * Nc, 8 * Nc, hipMemcpyDeviceToHost, so));
+        }
+        GPC_HIP(ctx, hipStreamSynchronize(so));
+    }
+    GPC_HIP(ctx, hipStreamSynchronize(sc));
     return GPC_OK;
 }
 

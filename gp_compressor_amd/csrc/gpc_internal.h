@@ -28,6 +28,18 @@ struct gpc_ctx {
     // grow-only device workspace (K / L factors of the generic dense kernel, variance scratch, grid tables)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // host-pointer entries (gpc_api.hip, dense_host): a grow-only device arena for the batch, pinned staging buffers for
+    // pageable caller memory, and two copy streams so that the upload of chunk c+1 and the download of chunk c-1 run on the
+    // SDMA engines while the kernel works on chunk c
+    void* io = nullptr;
+    size_t io_bytes = 0;
+    void* pin_in = nullptr;
+    size_t pin_in_bytes = 0;
+    void* pin_out = nullptr;
+    size_t pin_out_bytes = 0;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev[3][8] = {};
+    std::mutex host_mu;                // one host-pointer call at a time per context (they share the arena)
     std::mutex mu;
     char err[512] = {0};
     const char* last_dense_kernel = "";

@@ -104,6 +104,13 @@ int gpc_ctx_synchronize(gpc_ctx* ctx);
 int gpc_dev_malloc(gpc_ctx* ctx, size_t bytes, void** out);
 int gpc_dev_free(gpc_ctx* ctx, void* p);
 int gpc_dev_memcpy(gpc_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
+/* Page-locked host memory for the buffers handed to the host-pointer entries (gpc_dense_fit_predict[_grid] ...).  Those entries
+ * cut the batch into chunks and overlap upload, kernel and download on separate streams; from pinned memory the copies run in
+ * place on the SDMA engines, from ordinary (pageable) memory they are first staged through pinned buffers of the context by a
+ * threaded memcpy.  A reference-side binding assembles its X, y, C batch anyway (src/gp_compressor.cpp:146-155 copies the
+ * lists into matrices): assembling it in gpc_host_alloc memory saves the staging copy. */
+int gpc_host_alloc(gpc_ctx* ctx, size_t bytes, void** out);
+int gpc_host_free(gpc_ctx* ctx, void* p);
 void gpc_ctx_destroy(gpc_ctx* ctx);
 /* text of the last failure on this context ("" if none); valid until the next call on the context */
 const char* gpc_last_error(const gpc_ctx* ctx);

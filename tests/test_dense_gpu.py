@@ -358,3 +358,50 @@ def test_dense_does_not_read_stale_lds(gp, oracle, monkeypatch):
         idx = np.concatenate([np.arange(off[i], off[i + 1]) for i in sel])
         fo, _, so = oracle.dense_fit_predict_batch(oracle.dense_params(1.0, (res / 4) ** 2, 1e-3), soff, x0[idx], x1[idx], y[:, idx], xs0, xs1)
         assert np.max(np.abs(f[sel] - fo)) <= 1e-8 * np.max(np.abs(fo))
+
+
+def test_host_pointer_entry_pipeline_and_pinned_buffers(gp, oracle, monkeypatch):
+    """The host-pointer entries cut a batch of >= 2048 patches into four chunks and overlap upload, kernel and download
+    (csrc/gpc_api.hip, dense_host): a ragged 3-channel batch through the pipeline, through the single-chunk form
+    (GPC_HOST_NO_PIPELINE) and from page-locked caller buffers (gpc_host_alloc) gives the same grids, alpha and status; the
+    oracle on a sample.  Point-wise X* with the variance goes through the same chunking."""
+    capi, ctx = gp
+    P, res, sz = 2100, 0.15, 10
+    off, x0, x1, y = synth.make_patches(P, 48, res=res, seed=91, ragged=True, ny=3)
+    prm = capi.default_params_dense()
+    f, st, al = ctx.dense_fit_predict_grid(prm, off, x0, x1, y, res, sz, want_alpha=True)
+    monkeypatch.setenv("GPC_HOST_NO_PIPELINE", "1")
+    f1, st1, al1 = ctx.dense_fit_predict_grid(prm, off, x0, x1, y, res, sz, want_alpha=True)
+    monkeypatch.delenv("GPC_HOST_NO_PIPELINE")
+    tol = 1e-12 * np.max(np.abs(f1))                    # the dense kernel's LDS atomics meet in arrival order: equal to an ulp or two
+    assert np.all(st == 0) and np.array_equal(st, st1)
+    assert np.max(np.abs(f - f1)) <= tol and np.max(np.abs(al - al1)) <= 1e-12 * np.max(np.abs(al1))
+    # page-locked caller buffers: transferred in place
+    pin = {k: ctx.host_array(a.shape, a.dtype) for k, a in (("off", off), ("x0", x0), ("x1", x1), ("y", y))}
+    for k, a in (("off", off), ("x0", x0), ("x1", x1), ("y", y)):
+        pin[k][...] = a
+    pf = ctx.host_array((P, 3, sz * sz))
+    pst = ctx.host_array((P,), np.int32)
+    import ctypes as C
+    rc = ctx.lib.gpc_dense_fit_predict_grid(ctx.h, C.byref(prm), P, pin["off"].ctypes.data, pin["x0"].ctypes.data, pin["x1"].ctypes.data,
+                                            pin["y"].ctypes.data, 3, res, sz, pf.ctypes.data, None, pst.ctypes.data)
+    assert rc == 0 and np.all(pst == 0) and np.max(np.abs(pf - f1)) <= tol
+    for a in list(pin.values()) + [pf, pst]:
+        ctx.free_host_array(a)
+    # oracle on a sample of patches from every chunk
+    xs0, xs1 = synth.grid(res, sz)
+    for i in (0, 524, 525, 1049, 1575, 2099):
+        sl = slice(off[i], off[i + 1])
+        fo, _, _ = oracle.dense_fit_predict_batch(oracle.dense_params(), np.array([0, off[i + 1] - off[i]], dtype=np.int32), x0[sl], x1[sl],
+                                                  y[:, sl], xs0, xs1)
+        _close(f[i], fo[0], FTOL)
+    # point-wise X* + variance (the generic kernel) through the chunked entry
+    pv = capi.default_params_dense(want_variance=1)
+    fv, vv, stv = ctx.dense_fit_predict(pv, off, x0, x1, y[:1], xs0, xs1)
+    assert np.all(stv == 0)
+    _close(fv[:, 0, :], f1[:, 0, :], 1e-9)
+    i = 1600
+    sl = slice(off[i], off[i + 1])
+    _, vo, _ = oracle.dense_fit_predict_batch(oracle.dense_params(), np.array([0, off[i + 1] - off[i]], dtype=np.int32), x0[sl], x1[sl],
+                                              y[:1, sl], xs0, xs1, variance=True)
+    assert np.max(np.abs(vv[i] - vo[0])) <= VTOL
