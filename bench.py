@@ -225,6 +225,68 @@ def dense_record(name, r, P, n, world, steps, warmup):
                          "flops_per_patch": algorithmic_flops(n, M)}}
 
 
+def bench_dense_variance(env, P, n, steps, budget_s):
+    """C2 with the predictive variance the reference always computes (gaussian_process::predict_measurements,
+    src/gaussian_process.cpp:35-43): point-wise X* = the grid, f* and V* through gpc_dense_fit_predict_dev."""
+    import torch
+    from gp_compressor_amd import capi, synth
+    ctx, dev = env["ctx"], env["dev"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    off, x0, x1, y = synth.make_patches(P, n, res=RES, seed=2)
+    xs0, xs1 = synth.grid(RES, SZ)
+    prm = capi.default_params_dense(want_variance=1)
+    d_off, d_x0, d_x1, d_y, d_xs0, d_xs1 = t(off), t(x0), t(x1), t(y), t(xs0), t(xs1)
+    d_f = torch.empty((P, 1, M), dtype=torch.float64, device=dev)
+    d_v = torch.empty((P, M), dtype=torch.float64, device=dev)
+    d_st = torch.empty((P,), dtype=torch.int32, device=dev)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        ctx.dense_fit_predict_dev(prm, P, d_off, n, P * n, d_x0, d_x1, d_y, 1, M, d_xs0, d_xs1, d_f, v_star=d_v, status=d_st)
+        if ev is not None:
+            ev[1].record()
+    step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(ev[k])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    v_host, st = d_v.cpu().numpy(), d_st.cpu().numpy()
+    ok = bool(np.all(st == 0)) and bool(np.all(np.isfinite(v_host))) and bool(np.all(v_host > -1e-12))
+    fl = algorithmic_flops(n, M) + float(n) * n * M + 2.0 * n * M
+    achieved = fl * P / (kern_ms * 1e-3) / 1e12
+    rec = {"metric": "patches/sec (compress+predict)", "value": P * steps / elapsed, "unit": "patches/s", "n_gpus": 1, "steps": steps,
+           "warmup": 1, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"C2 + predictive variance: {P} patches x {n} pts, dense fit + mean AND variance on the {SZ}x{SZ} grid "
+                                  f"(V* = k** - |L^-1 k*|^2, what gaussian_process::predict_measurements computes)",
+                      "patches_per_gpu": P, "points_per_patch": n, "grid_points": M, "kernel": ctx.last_dense_kernel(), "results_ok": ok},
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                        "traffic": _traffic("dense_variance@C2"), "kernel_ms": kern_ms, "flops_per_patch": fl,
+                        "what": "F(n, m) + n^2 m + 2 n m flops per patch / HIP-event time of fit + variance kernels"}}
+    if budget_s > 0:
+        O = _oracle()
+        p_ = O.dense_params()
+
+        def run(lo, hi):
+            sub = (off[lo:hi + 1] - off[lo]).astype(np.int32)
+            sl = slice(int(off[lo]), int(off[hi]))
+            return O.dense_fit_predict_batch(p_, sub, x0[sl], x1[sl], np.ascontiguousarray(y[:, sl]), xs0, xs1, variance=True, fast=True)[1]
+        cores = host_cores()
+        outs, done, dt, single = _timed_threads(run, P, cores, budget_s, probe=4)
+        v_cpu = np.concatenate(outs, axis=0)
+        diff = v_host[:done] - v_cpu
+        rec["cpu_baseline"] = {"value": done / dt, "unit": "patches/s", "cores": cores, "kind": "port", "single_thread_value": single,
+                               "sample": f"{done} of the {P} patches (same buffers), oracle/gpc_oracle.c -O3 -march=native, {cores} threads, {dt:.1f} s"}
+        rec["rmse_vs_ref"] = {"rmse": float(np.sqrt(np.mean(diff * diff))), "max_abs": float(np.max(np.abs(diff))),
+                              "f_rms": float(np.sqrt(np.mean(v_cpu * v_cpu))), "what": "GPU V* vs CPU oracle V* on the cpu_baseline sample"}
+        rec["speedup_vs_cpu_baseline"] = rec["value"] / rec["cpu_baseline"]["value"]
+    return rec
+
+
 # ------------------------------------------------------------------------------------------------ C4: sparse online GP
 
 def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s):
@@ -436,8 +498,10 @@ def main():
             out = bench_sparse_c4(env, args.only[2:], int(os.environ.get("GPC_C4_P", "32768")), 256, 4, 200, 1, 0.0)
         elif args.only == "c5":
             out = bench_irls_c5(env, 4096, 1024, 1, 0.0)
+        elif args.only == "c2var":
+            out = bench_dense_variance(env, 8192, 256, 3, 0.0)
         else:
-            raise SystemExit("--only: c3 | c4fill | c4defaults | c5")
+            raise SystemExit("--only: c3 | c4fill | c4defaults | c5 | c2var")
         if rank == 0:
             print(json.dumps(out), flush=True)
         ctx.close()
@@ -503,6 +567,7 @@ def main():
         r3["host"] = None
         secondary.append(rec3)
         if world == 1 and not use_dist:
+            secondary.append(bench_dense_variance(env, 8192, 256, 3, 3.0 if cpu else 0.0))
             torch.cuda.empty_cache()
             for regime in ("fill", "defaults"):
                 secondary.append(bench_sparse_c4(env, regime, 32768, 256, 4, 200, 2, 4.0 if cpu else 0.0))

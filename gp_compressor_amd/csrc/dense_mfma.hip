@@ -45,6 +45,8 @@ struct MfmaParams {
     double c_exp;
     double pivot_tol;               // a pivot <= pivot_tol is reported as GPC_STATUS_NOT_SPD
     unsigned long long* stamps;     // diagnostic build (-DMF_STAMPS) only: [block][wave][MF_NPH] cycle sums
+    double* export_L;               // EXPORT instantiation (predictive variance, dense_variance.hip): per patch NT (NT + 1) / 2 operand
+                                    // images, row-major over the lower triangle: slot i (i + 1) / 2 + k holds L_ik (k < i) or L_ii^-1 (k == i)
 };
 
 // Diagnostic phase timing (cdna_hip_programming.md section 7, "In-kernel stamps"): compiled in only with -DMF_STAMPS
@@ -130,7 +132,7 @@ __device__ static __forceinline__ unsigned mf_range_mask(int t_lo, int t_hi)
 }
 __device__ static __forceinline__ int mf_cs(int j, int nt_full) { return j * nt_full - (j * (j - 1)) / 2; }
 
-template <int NT>
+template <int NT, bool EXPORT = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 {
     constexpr int NTILES = NT * (NT + 1) / 2;
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         const int o = __builtin_amdgcn_readfirstlane(A.off[patch]);
         const int n = __builtin_amdgcn_readfirstlane(A.off[patch + 1]) - o;
         double* fs = A.f_star + (size_t)patch * ny * m;
+        [[maybe_unused]] double* gexp = EXPORT ? g.export_L + (size_t)patch * (NT * (NT + 1) / 2) * MF_IMG : nullptr;
         if (n <= 0 || n > NT * MF_TS) {
             for (int p = tid; p < m * ny; p += MF_THREADS) fs[p] = (n == 0) ? 0.0 : __builtin_nan("");
             if (tid == 0 && A.status) A.status[patch] = (n == 0) ? GPC_STATUS_OK : GPC_STATUS_NAN;
@@ -382,6 +385,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], acc[t][3], z4, 0, 0, 0);                       \
             acc[t] = (D0 + D1) + (D2 + D3); /* = L_ik[l & 15][(l>>4) + 4 r] */                                       \
             mf_img_store(panN + ti_(t) * MF_IMG, mf_opaque(lane), acc[t]);                                          \
+            if constexpr (EXPORT)                                                                                    \
+                mf_img_store(gexp + (size_t)((ti_(t) * (ti_(t) + 1)) / 2 + tj_(t)) * MF_IMG, mf_opaque(lane), acc[t]); \
         }                                                                                                            \
     }
 #define MF_UPD_CASE(t)                                                                                               \
@@ -549,6 +554,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
                 d4 D0 = z4, D1 = z4, D2 = z4, D3 = z4;
                 const d4 lv = mf_img_load(Linv + j * MF_IMG, ln);
+                if constexpr (EXPORT) mf_img_store(gexp + (size_t)((j * (j + 1)) / 2 + j) * MF_IMG, ln, lv);
                 // right-hand sides of block j as MFMA B operand: column n < ny carries channel n
                 d4 yb = z4;
                 {
@@ -577,6 +583,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 if (ok && j + 1 < nt) {
                     Ln = (D0 + D1) + (D2 + D3);                       // operand image of L_(j+1)j
                     mf_img_store(panP + (j + 1) * MF_IMG, ln, Ln);
+                    if constexpr (EXPORT) mf_img_store(gexp + (size_t)(((j + 1) * (j + 2)) / 2 + j) * MF_IMG, ln, Ln);
                     timed_out |= !mf_wait_ge(tile_ready_addr, j + 1);
                     MF_TRACE_AT(8 * j + 4);
                     W = *reinterpret_cast<const d4*>(DS + ln * 4);
@@ -836,26 +843,44 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 
 bool dense_mfma_supported(const DenseArgs& a)
 {
-    return a.n_max <= MF_NPAD && a.v_star == nullptr && (a.ny == 1 || a.ny == 3);
+    return a.n_max <= MF_NPAD && (a.ny == 1 || a.ny == 3);
 }
 
-template <int NT>
+template <int NT, bool EXPORT = false>
 static int launch_nt(gpc_ctx* ctx, const MfmaParams& g, int grid, const char* name)
 {
     const size_t lds = sizeof(double) * (size_t)L_TOTAL;
     // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
-    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_mfma_kernel<NT>),
+    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_mfma_kernel<NT, EXPORT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(dense_mfma_kernel<NT>, dim3(grid), dim3(MF_THREADS), lds, ctx->stream, g);
+    hipLaunchKernelGGL((dense_mfma_kernel<NT, EXPORT>), dim3(grid), dim3(MF_THREADS), lds, ctx->stream, g);
     GPC_HIP(ctx, hipGetLastError());
     ctx->last_dense_kernel = name;
     return GPC_OK;
 }
 
-int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a)
+// Predictive variance (gaussian_process::predict_measurements, /root/reference/src/gaussian_process.cpp:35-43): the fit runs as
+// usual and additionally writes its factor (operand images of every L_ik and of the L_ii^-1) into the context's workspace,
+// 272 KB per patch at NT = 16; dense_variance.hip then evaluates V* = k** - ||L^-1 k*||^2 from there.
+int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a_in)
 {
+    DenseArgs a = a_in;
+    double* v_star = a.v_star;
+    a.v_star = nullptr;
+    const int nt_max = a.n_max <= 64 ? 4 : a.n_max <= 128 ? 8 : a.n_max <= 192 ? 12 : 16;
+    size_t fbytes = 0;
+    if (v_star) {
+        if (a.sel) return gpc_fail(ctx, GPC_EINVAL, "variance + size-class dispatch is not supported");
+        fbytes = sizeof(double) * (size_t)a.P * (nt_max * (nt_max + 1) / 2) * MF_IMG;
+        const int rc = gpc_ws_reserve(ctx, fbytes + sizeof(double) * (size_t)a.n_total * a.ny);
+        if (rc != GPC_OK) return rc;
+        // the variance kernel evaluates K* anyway: it forms the mean from the same tiles, so the fit predicts nothing
+        a.m = 0;
+        if (!a.alpha_out) a.alpha_out = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + fbytes);
+    }
     MfmaParams g;
     g.a = a;
+    g.export_L = v_star ? static_cast<double*>(ctx->ws) : nullptr;
     g.c_exp = (double)(-0.5f) / a.prm.l_sq;
     g.pivot_tol = GPC_PIVOT_RTOL * (a.prm.sigmaf_sq + a.prm.noise);
     g.stamps = nullptr;
@@ -941,6 +966,17 @@ int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a)
         }
     } tdump{ctx, g.stamps, grid};
 #endif
+    if (v_star) {
+        int rc;
+        if (nt_max == 4) rc = launch_nt<4, true>(ctx, g, grid, "dense_mfma_nt4 + dense_variance");
+        else if (nt_max == 8) rc = launch_nt<8, true>(ctx, g, grid, "dense_mfma_nt8 + dense_variance");
+        else if (nt_max == 12) rc = launch_nt<12, true>(ctx, g, grid, "dense_mfma_nt12 + dense_variance");
+        else rc = launch_nt<16, true>(ctx, g, grid, "dense_mfma_nt16 + dense_variance");
+        if (rc != GPC_OK) return rc;
+        DenseArgs av = a;
+        av.m = a_in.m;
+        return dense_variance_launch(ctx, av, nt_max, g.export_L, a.alpha_out, v_star);
+    }
     if (a.n_max <= 64) return launch_nt<4>(ctx, g, grid, "dense_mfma_nt4");
     if (a.n_max <= 128) return launch_nt<8>(ctx, g, grid, "dense_mfma_nt8");
     if (a.n_max <= 192) return launch_nt<12>(ctx, g, grid, "dense_mfma_nt12");

@@ -1,0 +1,188 @@
+// dense_variance.hip -- predictive variance of the dense GP on the MFMA pipe, n <= 256.
+//
+// gaussian_process::predict_measurements (/root/reference/src/gaussian_process.cpp:35-43):
+//     v = chol.matrixL().solve(K_star);   V_star(j) = squared_exp_distance(x*_j, x*_j) - v.col(j).squaredNorm()
+// -- an n x m triangular solve per patch (n^2 m flops: four times the whole fit at n = 256, m = 400), which the reference
+// always pays although gp_compressor never reads the result (src/gp_compressor.cpp:333-334).  Round 1 sent every variance
+// request to the generic kernel (3 TFLOP/s).  Here the register-tile kernel fits as usual and additionally exports its factor
+// as MFMA operand images (dense_mfma.hip, EXPORT instantiation: L_ik for k < i, L_ii^-1 on the diagonal, row-major over the
+// lower triangle, 2 KB each), and this kernel solves from there:
+//
+//   * one 512-thread workgroup per patch; each WAVE owns one block of 16 prediction points at a time (m = 400: 25 blocks, four
+//     rounds of eight) and runs the forward substitution of that block entirely in registers: V_i = L_ii^-1 (B_i - sum_{k<i}
+//     L_ik V_k), where B_i is evaluated on the fly (K* never exists in memory) and every V_k stays in the C/D register layout
+//     of the MFMA that produced it -- which is exactly the B-operand layout of the MFMA that consumes it.  4 MFMAs per tile
+//     product, accumulator-chained; the dependency chain of a block is hidden by the SIMD's second wave and by the eight
+//     blocks in flight.
+//   * the factor is the A operand of every product, the same for all eight waves: it streams through LDS in chunks of eight
+//     images (16 KB, double-buffered), loaded once per workgroup and round -- each thread fetches 32 bytes of the next chunk
+//     while the waves consume the current one; one barrier per chunk.
+//   * squared column norms accumulate in registers; two shuffles combine the four row groups of a lane column at the end.
+//   * the mean comes out of the same B_i tiles (f* = K*^T alpha, :32: four FMAs per tile and channel), so the fit kernel
+//     skips its own prediction phase when the variance is requested.
+// Measured on C2 (8192 x 256, m = 400): fit + mean + variance 8.6 ms = 955 k patches/s, 31.8 TFLOP/s = 0.40 of the FP64 peak
+// counting F(n, m) + n^2 m + 2 n m flops per patch (the generic kernel: 91 ms).
+#include "gpc_device.h"
+#include "gpc_internal.h"
+#include "mfma_tile.h"
+
+#define DV_THREADS 512
+#define DV_WAVES 8
+#define DV_CH 8   // operand images per LDS chunk
+
+struct VarParams {
+    DenseArgs a;
+    double c_exp;
+    const double* factor;   // [P][NT (NT + 1) / 2][256]
+    const double* alpha;    // [ny][n_total]: the fit's weights (the mean f* = K*^T alpha comes out of the same B_i tiles for free)
+    double* v_star;         // [P][m]
+};
+
+template <int NT>
+__global__ __launch_bounds__(DV_THREADS, 2) void dense_variance_kernel(VarParams g)
+{
+    constexpr int NTILES = NT * (NT + 1) / 2;
+    constexpr int NCHUNK = (NTILES + DV_CH - 1) / DV_CH;
+    __shared__ __attribute__((aligned(16))) double T[GPC_EXP_TABLE_SIZE];
+    __shared__ __attribute__((aligned(16))) double px0[NT * MF_TS], px1[NT * MF_TS], al[3][NT * MF_TS];
+    __shared__ __attribute__((aligned(16))) double Lbuf[2][DV_CH * MF_IMG];
+
+    const DenseArgs& A = g.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int m = A.m;
+    const double sf = A.prm.sigmaf_sq, cexp = g.c_exp;
+    gpc_exp_table_init(T);
+
+    const int patch = blockIdx.x;
+    const int o = __builtin_amdgcn_readfirstlane(A.off[patch]);
+    const int n = __builtin_amdgcn_readfirstlane(A.off[patch + 1]) - o;
+    const int ny = __builtin_amdgcn_readfirstlane(A.ny);
+    double* vs = g.v_star + (size_t)patch * m;
+    double* fs = A.f_star + (size_t)patch * ny * m;
+    const int st = A.status ? __builtin_amdgcn_readfirstlane(A.status[patch]) : GPC_STATUS_OK;
+    if (n <= 0 || n > NT * MF_TS || st != GPC_STATUS_OK) {
+        // no training points: f* = 0, v = sigma_f^2 (the prior); a failed fit: NaN
+        for (int p = tid; p < m; p += DV_THREADS) vs[p] = (n == 0) ? sf : __builtin_nan("");
+        for (int p = tid; p < m * ny; p += DV_THREADS) fs[p] = (n == 0) ? 0.0 : __builtin_nan("");
+        return;
+    }
+    const int nt = __builtin_amdgcn_readfirstlane((n + MF_TS - 1) / MF_TS);
+    for (int i = tid; i < NT * MF_TS; i += DV_THREADS) {
+        px0[i] = (i < n) ? A.x0[o + i] : 0.0;
+        px1[i] = (i < n) ? A.x1[o + i] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) al[c][i] = (c < ny && i < n) ? g.alpha[(size_t)c * A.n_total + o + i] : 0.0;
+    }
+    const double* F = g.factor + (size_t)patch * NTILES * MF_IMG;
+    // this thread's 32 bytes of a chunk: chunk c = images [c DV_CH, (c + 1) DV_CH) = 2048 doubles, 4 per thread
+    const int my4 = tid * 4;
+    const int nblk = (m + MF_TS - 1) / MF_TS;
+    const int rounds = (nblk + DV_WAVES - 1) / DV_WAVES;
+    // last chunk that rows < nt touch (the stream is consumed in order; everything behind it is never read)
+    const int last_pos = (nt * (nt + 1)) / 2 - 1;
+    const int last_chunk = __builtin_amdgcn_readfirstlane(last_pos / DV_CH);
+
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int blk = rd * DV_WAVES + wave;
+        const bool active = blk < nblk;
+        const int q = MF_TS * blk + lr;                 // this lane's prediction point (column of the block)
+        const bool qv = active && q < m;
+        const double gx0 = qv ? A.xs0[q] : 0.0, gx1 = qv ? A.xs1[q] : 0.0;
+        d4 V[NT];
+        double nrm = 0.0, fm[3] = {0.0, 0.0, 0.0};
+        d4 pre = d4{0.0, 0.0, 0.0, 0.0};
+        __syncthreads();                                // previous round (or the px load) is complete; Lbuf may be rewritten
+        // chunk 0 -> buffer 0, chunk 1 in flight
+        {
+            const d4 c0 = *reinterpret_cast<const d4*>(F + my4);
+            *reinterpret_cast<d4*>(&Lbuf[0][my4]) = c0;
+            const int c1 = min(1, NCHUNK - 1);
+            pre = *reinterpret_cast<const d4*>(F + (size_t)c1 * DV_CH * MF_IMG + my4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (i < nt) {
+                // B_i: K*(rows 16 i + lg + 4 r, column q), straight into the accumulator; rows beyond n are padding -> 0
+                d4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int p = MF_TS * i + lg + 4 * r;
+                    acc[r] = (qv && p < n) ? gpc_rbf_neg(sf, cexp, px0[p], px1[p], gx0, gx1, T) : 0.0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (c < ny) fm[c] = __builtin_fma(acc[r], al[c][p], fm[c]);      // f* = K*^T alpha (:32), same tile
+                }
+#pragma unroll
+                for (int k = 0; k <= i; ++k) {
+                    const int pos = (i * (i + 1)) / 2 + k;          // compile-time after unrolling
+                    const int c = pos / DV_CH, slot = pos % DV_CH;
+                    if (slot == 0 && c > 0) {
+                        // entering chunk c: publish it (prefetched during chunk c-1) and start fetching chunk c+1
+                        *reinterpret_cast<d4*>(&Lbuf[c & 1][my4]) = pre;
+                        const int cn = min(c + 1, last_chunk);
+                        pre = *reinterpret_cast<const d4*>(F + (size_t)cn * DV_CH * MF_IMG + my4);
+                        __syncthreads();
+                    }
+                    const d4 img = mf_img_load(&Lbuf[c & 1][slot * MF_IMG], lane);
+                    if (k < i) {
+                        // acc -= L_ik V_k   (blgp = 1: NEG(A))
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(img[s], V[k][s], acc, 0, 0, 1);
+                    } else {
+                        // V_i = L_ii^-1 acc: four independent products, tree sum
+                        const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
+                        const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[0], acc[0], z4, 0, 0, 0);
+                        const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[1], acc[1], z4, 0, 0, 0);
+                        const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[2], acc[2], z4, 0, 0, 0);
+                        const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[3], acc[3], z4, 0, 0, 0);
+                        V[i] = (D0 + D1) + (D2 + D3);
+                        nrm += (V[i][0] * V[i][0] + V[i][1] * V[i][1]) + (V[i][2] * V[i][2] + V[i][3] * V[i][3]);
+                    }
+                }
+            }
+        }
+        // the four row groups (lg) of a column
+        nrm += __shfl_xor(nrm, 16, 64);
+        nrm += __shfl_xor(nrm, 32, 64);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            fm[c] += __shfl_xor(fm[c], 16, 64);
+            fm[c] += __shfl_xor(fm[c], 32, 64);
+        }
+        if (qv && lg == 0) {
+            vs[q] = sf - nrm;                           // squared_exp_distance(x*, x*) = sigma_f^2 (no noise term, :40)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (c < ny) fs[(size_t)c * m + q] = fm[c];
+        }
+    }
+}
+
+template <int NT>
+static int var_launch_t(gpc_ctx* ctx, const VarParams& g, int grid)
+{
+    hipLaunchKernelGGL(dense_variance_kernel<NT>, dim3(grid), dim3(DV_THREADS), 0, ctx->stream, g);
+    GPC_HIP(ctx, hipGetLastError());
+    return GPC_OK;
+}
+
+int dense_variance_launch(gpc_ctx* ctx, const DenseArgs& a, int nt_max, const double* factor, const double* alpha, double* v_star)
+{
+    if (a.P == 0 || a.m == 0) return GPC_OK;
+    if (!a.xs0 || !a.xs1) return gpc_fail(ctx, GPC_EINVAL, "the predictive variance needs point-wise X*");
+    VarParams g;
+    g.a = a;
+    g.c_exp = (double)(-0.5f) / a.prm.l_sq;
+    g.factor = factor;
+    g.alpha = alpha;
+    g.v_star = v_star;
+    switch (nt_max) {
+        case 4: return var_launch_t<4>(ctx, g, a.P);
+        case 8: return var_launch_t<8>(ctx, g, a.P);
+        case 12: return var_launch_t<12>(ctx, g, a.P);
+        default: return var_launch_t<16>(ctx, g, a.P);
+    }
+}

@@ -126,6 +126,9 @@ int dense_generic_launch(gpc_ctx* ctx, const DenseArgs& a, int grid);
 bool dense_mfma_supported(const DenseArgs& a);
 int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a);
 
+// predictive variance from the exported factor of the register-tile kernel (dense_variance.hip): V* [P][m]
+int dense_variance_launch(gpc_ctx* ctx, const DenseArgs& a, int nt_max, const double* factor, const double* alpha, double* v_star);
+
 // tiled left-looking MFMA kernel: 256 < n <= 1024, factor in a global-memory workspace slot per workgroup (see dense_mfma_big.hip)
 bool dense_big_supported(const DenseArgs& a);
 size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out);
