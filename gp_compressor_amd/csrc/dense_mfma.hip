@@ -92,21 +92,24 @@ struct MfmaParams {
 #endif
 
 // ---- LDS carve (doubles) ----------------------------------------------------------------------------------
-#define L_EXP 0                          // 64    exp table
-#define L_PX0 64                         // 256   x0
-#define L_PX1 (L_PX0 + MF_NPAD)          // 256   x1
-#define L_YC (L_PX1 + MF_NPAD)           // 3*256 running right-hand sides (forward solve)
-#define L_ZV (L_YC + 3 * MF_NPAD)        // 3*256 z = L^-1 y
-#define L_WV (L_ZV + 3 * MF_NPAD)        // 3*256 backward-solve accumulators w_k[c][16 k + .] (ds_add_f64 targets)
-#define L_AV (L_WV + 3 * MF_NPAD)        // 3*256 alpha
-#define L_DS (L_AV + 3 * MF_NPAD)        // 256 + 16 (+ pad to 288) diagonal-tile hand-over (register layout) + rsqrt row
-#define L_FLAG (L_DS + 288)              // 12    ints: [0] not-SPD/timeout, [1] ready, [2] tile_ready, [3] alpha_ready, [4] sub_ready,
-                                         //       [5] pan_cnt, [6] t00_ready, [7] z_ready, [8..23] pre_cnt[k] (backward solve)
-#define L_LINV (L_FLAG + 12)              // 16*256 L_kk^-1, operand layout
-#define L_LINVT (L_LINV + 16 * 256)      // 16*256 L_kk^-T, operand layout (backward solve)
-#define L_PANP (L_LINVT + 16 * 256)      // 2 x 16*256 panel L_ik, operand layout, double-buffered by k & 1 (also the
-                                         // predict reduction buffer: 8*4*256)
-#define L_TOTAL (L_PANP + 32 * 256)      // doubles  (158.8 KB)
+// NT <= 16 (n <= 256): 256 padded points, three vector planes (depth or RGB), 16 images per array -- 158.8 KB.
+// NT == 17 (n <= 272, the patches just above 256 points that an octree leaf of the C2 cloud produces): 272 padded points,
+// ONE vector plane (ny == 1 only: the two colour planes are what pays for the 17th image of each array) -- 155.3 KB.
+//   exp table 64 | x0, x1 NPAD each | y (running rhs), z, w (ds_add_f64 targets), alpha: NPL planes of NPAD each |
+//   diagonal-tile hand-over 256 + rsqrt row (288) | flags: ints [0] not-SPD/timeout, [1] ready, [2] tile_ready, [3] alpha_ready,
+//   [4] sub_ready, [5] pan_cnt, [6] t00_ready, [7] z_ready, [8 ..] pre_cnt[k] | NI images L_kk^-1 | NI images L_kk^-T |
+//   2 x NI images: panel L_ik, double-buffered by k & 1 (also the predict reduction buffer: 8*4*256)
+__host__ __device__ constexpr int mf_npad(int nt) { return nt > 16 ? nt * MF_TS : MF_NPAD; }
+__host__ __device__ constexpr int mf_npl(int nt) { return nt > 16 ? 1 : 3; }
+__host__ __device__ constexpr int mf_ni(int nt) { return nt > 16 ? nt : 16; }
+__host__ __device__ constexpr int mf_flagd(int nt) { return ((4 + (mf_ni(nt) + 1) / 2) + 1) & ~1; }
+__host__ __device__ constexpr int mf_l_vec(int nt) { return 64 + 2 * mf_npad(nt); }
+__host__ __device__ constexpr int mf_l_ds(int nt) { return mf_l_vec(nt) + 4 * mf_npl(nt) * mf_npad(nt); }
+__host__ __device__ constexpr int mf_l_flag(int nt) { return mf_l_ds(nt) + 288; }
+__host__ __device__ constexpr int mf_l_linv(int nt) { return mf_l_flag(nt) + mf_flagd(nt); }
+__host__ __device__ constexpr int mf_l_total(int nt) { return mf_l_linv(nt) + 4 * mf_ni(nt) * 256; }
+static_assert(mf_l_total(16) == 64 + 14 * 256 + 288 + 12 + 64 * 256, "the n <= 256 carve is the one of round 1");
+static_assert(mf_l_total(17) * 8 <= 160 * 1024 && (mf_l_linv(17) & 1) == 0, "NT = 17 fits the LDS, images 16-byte aligned");
 
 // ---- slot dispatch ----------------------------------------------------------------------------------------
 // Tiles are enumerated column-major over the lower triangle (idx = cs(j) + i - j, cs(j) = j NT - j (j-1)/2) and
@@ -120,11 +123,13 @@ struct MfmaParams {
 #define MF_G1(X) X(5) X(6) X(7) X(8) X(9)
 #define MF_G2(X) X(10) X(11) X(12) X(13) X(14)
 #define MF_G3(X) X(15) X(16) X(17) X(18) X(19)
+#define MF_G4(X) X(20) X(21) X(22) X(23) X(24)
 #define MF_SLOTS(X)                           \
     if (smask & 0x0001Fu) { MF_G0(X) }        \
     if (smask & 0x003E0u) { MF_G1(X) }        \
     if (smask & 0x07C00u) { MF_G2(X) }        \
-    if (smask & 0xF8000u) { MF_G3(X) }
+    if (smask & 0xF8000u) { MF_G3(X) }        \
+    if (smask & 0x1F00000u) { MF_G4(X) }
 // bits t_lo .. t_hi (empty when t_hi < t_lo); 0 <= t_lo, t_hi < 31
 __device__ static __forceinline__ unsigned mf_range_mask(int t_lo, int t_hi)
 {
@@ -137,7 +142,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 {
     constexpr int NTILES = NT * (NT + 1) / 2;
     constexpr int TPW = (NTILES + MF_WORKERS - 1) / MF_WORKERS;
-    static_assert(TPW <= 20, "MF_G0..MF_G3 cover 20 slots");
+    static_assert(TPW <= 25, "MF_G0..MF_G4 cover 25 slots");
+    constexpr int NPAD = mf_npad(NT), NI = mf_ni(NT);
+    constexpr int L_PX0 = 64, L_PX1 = L_PX0 + NPAD, L_YC = mf_l_vec(NT), L_ZV = L_YC + mf_npl(NT) * NPAD, L_WV = L_ZV + mf_npl(NT) * NPAD,
+                  L_AV = L_WV + mf_npl(NT) * NPAD, L_DS = mf_l_ds(NT), L_FLAG = mf_l_flag(NT), L_LINV = mf_l_linv(NT),
+                  L_LINVT = L_LINV + NI * 256, L_PANP = L_LINVT + NI * 256;
+    constexpr int L_EXP = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     double* T = lds + L_EXP;
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     double* panBase = lds + L_PANP;
     // Image slot 0 of either panel buffer is never part of a panel (tile row 0 has no sub-diagonal tiles):
     double* SubX = panBase;               // hand-over of the sub-diagonal tile (j, j-1) to the factor wave (register layout)
-    double* Gzero = panBase + 16 * 256;   // hand-over of tile (0, 0), afterwards G_0 (backward solve)
+    double* Gzero = panBase + NI * 256;   // hand-over of tile (0, 0), afterwards G_0 (backward solve)
 
     const DenseArgs& A = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -178,11 +188,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
     const int ny = __builtin_amdgcn_readfirstlane(A.ny), m = A.m;
     const double sf = A.prm.sigmaf_sq, cexp = g.c_exp, noise = A.prm.noise;
 
-    // tile coordinates of this worker's slots (wave-uniform): 4 tiles per SGPR, one byte each (ti | tj << 4)
-    constexpr int TQ = (TPW + 3) / 4;
+    // tile coordinates of this worker's slots (wave-uniform): 4 tiles per SGPR, one byte each (ti | tj << 4); NT = 17 has tile
+    // index 16, so its fields are 8 bits wide: 2 tiles per SGPR
+    constexpr int TB = NT > 16 ? 16 : 8, TPS = 32 / TB, TSH = TB / 2;
+    constexpr unsigned TM = (1u << TSH) - 1u;
+    constexpr int TQ = (TPW + TPS - 1) / TPS;
     unsigned tq[TQ];
-#define ti_(t) ((int)((tq[(t) >> 2] >> (8 * ((t) & 3))) & 15u))
-#define tj_(t) ((int)((tq[(t) >> 2] >> (8 * ((t) & 3) + 4)) & 15u))
+#define ti_(t) ((int)((tq[(t) / TPS] >> (TB * ((t) % TPS))) & TM))
+#define tj_(t) ((int)((tq[(t) / TPS] >> (TB * ((t) % TPS) + TSH)) & TM))
     unsigned valid_mask = 0;   // slots that hold a tile at all
 #pragma unroll
     for (int q = 0; q < TQ; ++q) tq[q] = 0;
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             if (idx >= j * NT - (j * (j - 1)) / 2) jj = j;
         const int ii = jj + idx - (jj * NT - (jj * (jj - 1)) / 2);
         const bool ok = idx < NTILES && !is_factor;
-        tq[t >> 2] |= ok ? ((unsigned)(ii | (jj << 4)) << (8 * (t & 3))) : 0u;
+        tq[t / TPS] |= ok ? ((unsigned)(ii | (jj << TSH)) << (TB * (t % TPS))) : 0u;
         valid_mask |= ok ? (1u << t) : 0u;
     }
 #pragma unroll
@@ -207,6 +220,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 
     // one workgroup per patch, straight-line (a persistent patch loop makes hipcc hoist hundreds of lane-dependent
     // LDS addresses out of it and spill; the block hand-over costs ~1-2 us against ~100 us of work)
+    // (The size-class dispatch launches P workgroups per class although only the class's share holds a patch: the count lives
+    // on the device.  The empty ones each wait for a CU with 158 KB of LDS free, ~0.1 ms per launch on the C2-size cloud; walking
+    // the class list with one workgroup per CU instead turns this body into a loop and costs 1.6 KB of scratch per lane --
+    // measured at compile time for every instantiation, even with the loop compiled out by a template flag -- so it stays.)
     do {
         int patch = blockIdx.x;
         if (A.sel) {                                  // size-class dispatch: this launch owns the patches sel[0 .. count)
@@ -237,8 +254,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 if (c < ny) {
-                    yc[c * MF_NPAD + i] = live ? A.y[(size_t)c * A.n_total + o + i] : 0.0;
-                    wsum[c * MF_NPAD + i] = 0.0;
+                    yc[c * NPAD + i] = live ? A.y[(size_t)c * A.n_total + o + i] : 0.0;
+                    wsum[c * NPAD + i] = 0.0;
                 }
             }
         }
@@ -252,7 +269,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             flag[6] = 0;
             flag[7] = -1;
         }
-        if (tid < 16) flag[8 + tid] = 0;
+        if (tid < NI) flag[8 + tid] = 0;
         dev = __builtin_fmax(dev, mf_dpp<0x121>(dev));     // max over the 16 lanes of a DPP row
         dev = __builtin_fmax(dev, mf_dpp<0x122>(dev));
         dev = __builtin_fmax(dev, mf_dpp<0x124>(dev));
@@ -437,8 +454,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 if (lane == 0) __hip_atomic_fetch_add(pan_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             for (int k = 0; k + 1 < nt && !dead; ++k) {
-                double* panP = panBase + (k & 1) * (16 * 256);
-                double* panN = panBase + ((k + 1) & 1) * (16 * 256);
+                double* panP = panBase + (k & 1) * (NI * 256);
+                double* panN = panBase + ((k + 1) & 1) * (NI * 256);
                 // panel k complete?  (also: every wave has finished step k-1, so panel buffer (k+1)&1 may be rewritten)
                 timed_out |= !mf_wait_ge(pan_cnt_addr, MF_WAVES * (k + 1));
                 MF_STAMP_FINE(1);
@@ -475,8 +492,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         timed_out |= !mf_wait_ge(z_ready_addr, k);
                         if (lane < 16)
                             for (int c = 0; c < ny; ++c)
-                                yc[c * MF_NPAD + MF_TS * (k + 2) + lane] -=
-                                    mf_row_dot(panP + (k + 2) * MF_IMG, lane, zv + c * MF_NPAD + MF_TS * k);
+                                yc[c * NPAD + MF_TS * (k + 2) + lane] -=
+                                    mf_row_dot(panP + (k + 2) * MF_IMG, lane, zv + c * NPAD + MF_TS * k);
                         mf_publish(sub_ready, k + 2);
                     }
                     const int idxd = __builtin_amdgcn_readfirstlane(mf_cs(k + 2, NT));
@@ -497,7 +514,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     timed_out |= !mf_wait_ge(z_ready_addr, k);
                     const int i = k + 3 + (tid >> 4), mr = tid & 15;
                     for (int c = 0; c < ny; ++c)
-                        yc[c * MF_NPAD + MF_TS * i + mr] -= mf_row_dot(panP + i * 256, mr, zv + c * MF_NPAD + MF_TS * k);
+                        yc[c * NPAD + MF_TS * i + mr] -= mf_row_dot(panP + i * 256, mr, zv + c * NPAD + MF_TS * k);
                 }
                 MF_STAMP_FINE(5);
                 MF_TRACE_AT(8 * k + 2);
@@ -550,7 +567,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 mf_publish(ready, j);            // L_jj^-1 is all the workers need to start their TRSMs; z_j follows
                 MF_TRACE_AT(8 * j + 2);
                 const int ln = mf_opaque(lane);
-                double* panP = panBase + (j & 1) * (16 * 256);
+                double* panP = panBase + (j & 1) * (NI * 256);
                 const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
                 d4 D0 = z4, D1 = z4, D2 = z4, D3 = z4;
                 const d4 lv = mf_img_load(Linv + j * MF_IMG, ln);
@@ -561,7 +578,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     const int lr = ln & 15, lg = ln >> 4;
                     if (lr < ny) {
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) yb[q4] = yc[lr * MF_NPAD + MF_TS * j + lg + 4 * q4];
+                        for (int q4 = 0; q4 < 4; ++q4) yb[q4] = yc[lr * NPAD + MF_TS * j + lg + 4 * q4];
                     }
                 }
                 if (ok && j + 1 < nt) {
@@ -599,7 +616,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     const int lr = ln & 15, lg = ln >> 4;
                     if (lr < ny) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) zv[lr * MF_NPAD + MF_TS * j + lg + 4 * r] = zj[r];
+                        for (int r = 0; r < 4; ++r) zv[lr * NPAD + MF_TS * j + lg + 4 * r] = zj[r];
                     }
                 }
                 mf_publish(z_ready, j);
@@ -611,8 +628,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     {
                         const int lr = ln & 15, lg = ln >> 4;
                         for (int c = 0; c < ny; ++c) {
-                            const double* zq = zv + c * MF_NPAD + MF_TS * j + lg;
-                            atomicAdd(yc + c * MF_NPAD + MF_TS * (j + 1) + lr,
+                            const double* zq = zv + c * NPAD + MF_TS * j + lg;
+                            atomicAdd(yc + c * NPAD + MF_TS * (j + 1) + lr,
                                       -((Ln[0] * zq[0] + Ln[1] * zq[4]) + (Ln[2] * zq[8] + Ln[3] * zq[12])));
                         }
                     }
@@ -667,7 +684,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 d4 ub = d4{0.0, 0.0, 0.0, 0.0};
                 if (lr < ny) {
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[lr * MF_NPAD + MF_TS * k + lg + 4 * q4];
+                    for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[lr * NPAD + MF_TS * k + lg + 4 * q4];
                 }
                 const int expect = nt - k - 2;
                 if (expect > 0) {
@@ -675,7 +692,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     MF_STAMP_FINE(10);
                     if (lr < ny) {
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) ub[q4] -= wsum[lr * MF_NPAD + MF_TS * k + lg + 4 * q4];
+                        for (int q4 = 0; q4 < 4; ++q4) ub[q4] -= wsum[lr * NPAD + MF_TS * k + lg + 4 * q4];
                     }
                 }
                 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[0], ub[0], D0, 0, 0, 0);       // + L_kk^-T (z_k - w_k)
@@ -685,7 +702,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                 al = (D0 + D1) + (D2 + D3);   // lanes lr = n < ny: alpha_n[16 k + (l>>4) + 4 r]; zero elsewhere
                 if (lr < ny) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) av[lr * MF_NPAD + MF_TS * k + lg + 4 * r] = al[r];
+                    for (int r = 0; r < 4; ++r) av[lr * NPAD + MF_TS * k + lg + 4 * r] = al[r];
                 }
                 mf_publish(alpha_ready, nt - k);
                 MF_STAMP_FINE(11);
@@ -699,7 +716,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         _Pragma("unroll") for (int c = 0; c < 3; ++c) {   /* static index: pa[] must stay in registers */            \
             if (c < ny) {                                                                                            \
                 const double tot = mf_row_reduce4(pa[c], lrf);   /* lanes lr = 0, 4, 8, 12 hold components 0..3 */   \
-                if ((lrf & 3) == 0) atomicAdd(wsum + c * MF_NPAD + MF_TS * cur_col + lgf + 4 * (lrf >> 2), tot);     \
+                if ((lrf & 3) == 0) atomicAdd(wsum + c * NPAD + MF_TS * cur_col + lgf + 4 * (lrf >> 2), tot);     \
             }                                                                                                        \
         }                                                                                                            \
         if (lane == 0) __hip_atomic_fetch_add(pre_cnt + cur_col, cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
@@ -720,10 +737,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             }                                                                                                        \
             const double* avq = av + MF_TS * ti_(t) + (mf_opaque(lane) & 15);                                        \
             _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                            \
-                if (c < ny) pa[c] += acc[t] * avq[c * MF_NPAD];                                                      \
+                if (c < ny) pa[c] += acc[t] * avq[c * NPAD];                                                      \
             ++cnt;                                                                                                   \
         }                                                                                                            \
     }
+            MF_BWD_CASE(24) MF_BWD_CASE(23) MF_BWD_CASE(22) MF_BWD_CASE(21) MF_BWD_CASE(20)
             MF_BWD_CASE(19) MF_BWD_CASE(18) MF_BWD_CASE(17) MF_BWD_CASE(16) MF_BWD_CASE(15)
             MF_BWD_CASE(14) MF_BWD_CASE(13) MF_BWD_CASE(12) MF_BWD_CASE(11) MF_BWD_CASE(10)
             MF_BWD_CASE(9) MF_BWD_CASE(8) MF_BWD_CASE(7) MF_BWD_CASE(6) MF_BWD_CASE(5)
@@ -736,7 +754,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             for (int i = tid; i < n; i += MF_THREADS)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    if (c < ny) A.alpha_out[(size_t)c * A.n_total + o + i] = av[c * MF_NPAD + i];
+                    if (c < ny) A.alpha_out[(size_t)c * A.n_total + o + i] = av[c * NPAD + i];
         MF_STAMP(8);
 
         // ---- predictive mean ----
@@ -747,18 +765,17 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             const double res = A.grid_res;
             double* red = panBase;   // 8 waves x 4 tiles x 256 doubles = 64 KB: aliases the (dead) panel buffers
             double ea[2][8], eb[2][8];
-            const int ibase = 32 * wave;
-            const bool wave_live = ibase < n;
-            if (wave_live) {
+            // grid factors of the 32 training points [ib, ib + 32): Ey[py][i], Ex[px][i]
+            auto grid_factors = [&](int ib) __attribute__((always_inline)) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int pq = 16 * h + lr;
                     const double gq = res * (((double)pq + 0.5) / (double)sz - 0.5);
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
-                        const int i = ibase + 4 * s + lg;
+                        const int i = ib + 4 * s + lg;
                         const bool on = (pq < sz) && (i < n);
-                        const double dy = gq - px1[i], dx = gq - px0[i];
+                        const double dy = gq - px1[on ? i : 0], dx = gq - px0[on ? i : 0];
                         if (small_grid) {
                             ea[h][s] = on ? gpc_exp_small(cexp * (dy * dy)) : 0.0;    // Ey[py = pq][i]
                             eb[h][s] = on ? gpc_exp_small(cexp * (dx * dx)) : 0.0;    // Ex[px = pq][i]
@@ -768,20 +785,25 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                         }
                     }
                 }
-            }
+            };
+            const int ibase = 32 * wave;
+            const bool wave_live = ibase < n;
+            if (wave_live) grid_factors(ibase);
             for (int c = 0; c < ny; ++c) {
                 d4 P[2][2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nl = 0; nl < 2; ++nl) P[mt][nl] = d4{0.0, 0.0, 0.0, 0.0};
-                if (wave_live) {
+                // one 32-point chunk per wave covers 256 points; NT = 17 (ny == 1) takes a second trip for the points 256 .. 271
+                for (int ib = ibase; ib < n; ib += 32 * MF_WAVES) {
+                    if (NT > 16 && ib != ibase) grid_factors(ib);
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
-                        const int i = ibase + 4 * s + lg;
+                        const int i = ib + 4 * s + lg;
                         // rows between 16 nt and the end of this 32-row group are never written by the solve: whatever the
                         // previous kernel left in LDS there (possibly NaN) must not reach the sum -- select, do not multiply
-                        const double al = (i < n) ? sf * av[c * MF_NPAD + i] : 0.0;
+                        const double al = (i < n) ? sf * av[c * NPAD + i] : 0.0;
 #pragma unroll
                         for (int nl = 0; nl < 2; ++nl) {
                             const double bop = eb[nl][s] * al;
@@ -826,7 +848,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     const double kk = gpc_rbf_neg(sf, cexp, px0[i], px1[i], q0, q1, T);
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        if (c < ny) s_[c] += kk * av[c * MF_NPAD + i];
+                        if (c < ny) s_[c] += kk * av[c * NPAD + i];
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
@@ -843,13 +865,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
 
 bool dense_mfma_supported(const DenseArgs& a)
 {
-    return a.n_max <= MF_NPAD && (a.ny == 1 || a.ny == 3);
+    // n <= 256 for depth and colour; n <= 272 for the depth plane alone (NT = 17, see the LDS carve); the variance path exports
+    // the factor of the n <= 256 shapes only
+    return (a.n_max <= MF_NPAD || (a.n_max <= 17 * MF_TS && a.ny == 1 && a.v_star == nullptr)) && (a.ny == 1 || a.ny == 3);
 }
 
 template <int NT, bool EXPORT = false>
 static int launch_nt(gpc_ctx* ctx, const MfmaParams& g, int grid, const char* name)
 {
-    const size_t lds = sizeof(double) * (size_t)L_TOTAL;
+    const size_t lds = sizeof(double) * (size_t)mf_l_total(NT);
     // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
     GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_mfma_kernel<NT, EXPORT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -980,5 +1004,6 @@ int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a_in)
     if (a.n_max <= 64) return launch_nt<4>(ctx, g, grid, "dense_mfma_nt4");
     if (a.n_max <= 128) return launch_nt<8>(ctx, g, grid, "dense_mfma_nt8");
     if (a.n_max <= 192) return launch_nt<12>(ctx, g, grid, "dense_mfma_nt12");
-    return launch_nt<16>(ctx, g, grid, "dense_mfma_nt16");
+    if (a.n_max <= 256) return launch_nt<16>(ctx, g, grid, "dense_mfma_nt16");
+    return launch_nt<17>(ctx, g, grid, "dense_mfma_nt17");
 }

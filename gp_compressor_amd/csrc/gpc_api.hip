@@ -254,16 +254,31 @@ static int dense_check(gpc_ctx* ctx, const gpc_params* prm, int P, const void* o
     return GPC_OK;
 }
 
-// Ragged batches whose largest patch exceeds the register-resident kernel's 256 points: patches are sorted into the two size
-// classes on the device (no host round trip: `off` lives there), the small ones go to the register-resident kernel and only
-// the large ones to the tiled kernel.  Patches are independent, so the order inside a class does not matter.
-__global__ void dense_classify_kernel(int P, const int32_t* off, int bound, int32_t* sel_small, int32_t* sel_big, int32_t* counts)
+// Ragged batches whose largest patch exceeds the register-resident kernel's 256 points: patches are sorted into size classes on
+// the device (no host round trip: `off` lives there) -- n <= 256 -> the register-resident kernel, 256 < n <= 272 -> its NT = 17
+// shape (depth plane only: the octree leaves of a cloud cut for 256-point patches scatter around that size, median 258, and
+// would otherwise pay the tiled kernel's 4x cost per patch), the rest -> the tiled kernel.  Patches are independent, so the
+// order inside a class does not matter.
+__global__ void dense_classify_kernel(int P, const int32_t* off, int bound0, int bound1, int32_t* sel0, int32_t* sel1, int32_t* sel2,
+                                      int32_t* counts)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const int n = off[i + 1] - off[i];
-    if (n <= bound) sel_small[atomicAdd(&counts[0], 1)] = i;
-    else sel_big[atomicAdd(&counts[1], 1)] = i;
+    if (n <= bound0) sel0[atomicAdd(&counts[0], 1)] = i;
+    else if (n <= bound1) sel1[atomicAdd(&counts[1], 1)] = i;
+    else sel2[atomicAdd(&counts[2], 1)] = i;
+}
+
+// the context's two auxiliary streams and its events (also used by the host-pointer pipeline), created on first use
+static int gpc_aux_streams(gpc_ctx* ctx)
+{
+    if (ctx->s_in) return GPC_OK;
+    GPC_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
+    GPC_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
+    for (auto& row : ctx->ev)
+        for (auto& e : row) GPC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return GPC_OK;
 }
 
 static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
@@ -277,30 +292,77 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
         const int rcp = gpc_debug_poison_lds(ctx);
         if (rcp != GPC_OK) return rcp;
     }
-    if (dense_mfma_supported(a) && !getenv("GPC_FORCE_GENERIC") && !getenv("GPC_FORCE_BIG")) return dense_mfma_launch(ctx, a);
-    if ((dense_big_supported(a) || (getenv("GPC_FORCE_BIG") && a.n_max <= 1024 && !a.v_star)) && !getenv("GPC_FORCE_GENERIC")) {   // GPC_FORCE_BIG: diagnostic
+    const bool force_generic = getenv("GPC_FORCE_GENERIC") != nullptr, force_big = getenv("GPC_FORCE_BIG") != nullptr;
+    const bool ny_ok = a.ny == 1 || a.ny == 3;
+    if (!force_generic && !force_big && ny_ok) {
+        const bool no_split = a.P == 1 || getenv("GPC_NO_SPLIT");
+        if (a.n_max <= 256 || (no_split && dense_mfma_supported(a) && !getenv("GPC_NO_NT17")))
+            return dense_mfma_launch(ctx, a);                                                               // one shape for the whole batch
+        if (!a.v_star && a.n_max <= GPC_MAX_POINTS && !no_split) {
+            const bool nt17 = a.ny == 1 && !getenv("GPC_NO_NT17");
+            const bool need_big = !(nt17 && a.n_max <= 17 * 16);
+            int grid_b = 0;
+            const size_t big_bytes = need_big ? (dense_big_ws_bytes(ctx, a, &grid_b) + 255) & ~(size_t)255 : 0;
+            int rc = gpc_ws_reserve(ctx, big_bytes + sizeof(int32_t) * (3 * (size_t)a.P + 64));
+            if (rc != GPC_OK) return rc;
+            int32_t* counts = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->ws) + big_bytes);
+            int32_t* sel0 = counts + 64;
+            int32_t* sel1 = sel0 + a.P;
+            int32_t* sel2 = sel1 + a.P;
+            GPC_HIP(ctx, hipMemsetAsync(counts, 0, 3 * sizeof(int32_t), ctx->stream));
+            hipLaunchKernelGGL(dense_classify_kernel, dim3((a.P + 255) / 256), dim3(256), 0, ctx->stream, a.P, a.off, 256, nt17 ? 17 * 16 : 256,
+                               sel0, sel1, sel2, counts);
+            GPC_HIP(ctx, hipGetLastError());
+            // The classes are independent: they run on three streams (forked from and joined to the context's), so that
+            // the tail of one kernel -- its last workgroups running on a mostly idle chip -- fills with the next one's work.
+            const bool fork = !getenv("GPC_NO_FORK");
+            hipStream_t main_s = ctx->stream;
+            if (fork) {
+                rc = gpc_aux_streams(ctx);
+                if (rc != GPC_OK) return rc;
+                GPC_HIP(ctx, hipEventRecord(ctx->ev[0][5], main_s));
+                GPC_HIP(ctx, hipStreamWaitEvent(ctx->s_in, ctx->ev[0][5], 0));
+                GPC_HIP(ctx, hipStreamWaitEvent(ctx->s_out, ctx->ev[0][5], 0));
+            }
+            // largest patches first: the tiled kernel's workgroups are the long ones
+            if (need_big) {
+                DenseArgs b = a;
+                b.sel = sel2; b.sel_count = counts + 2;
+                if (fork) ctx->stream = ctx->s_out;
+                rc = dense_big_launch(ctx, b, grid_b);
+                ctx->stream = main_s;
+                if (rc != GPC_OK) return rc;
+            }
+            DenseArgs s = a;
+            if (nt17) {
+                s.n_max = 17 * 16;
+                s.sel = sel1; s.sel_count = counts + 1;
+                if (fork) ctx->stream = ctx->s_in;
+                rc = dense_mfma_launch(ctx, s);
+                ctx->stream = main_s;
+                if (rc != GPC_OK) return rc;
+            }
+            s.n_max = 256;
+            s.sel = sel0; s.sel_count = counts;
+            rc = dense_mfma_launch(ctx, s);            // workgroups beyond the class count leave at once
+            if (rc != GPC_OK) return rc;
+            if (fork) {
+                GPC_HIP(ctx, hipEventRecord(ctx->ev[1][5], ctx->s_in));
+                GPC_HIP(ctx, hipEventRecord(ctx->ev[2][5], ctx->s_out));
+                GPC_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev[1][5], 0));
+                GPC_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev[2][5], 0));
+            }
+            ctx->last_dense_kernel = !need_big ? "dense_mfma_nt16 + dense_mfma_nt17" : nt17 ? "dense_mfma_nt16 + dense_mfma_nt17 + dense_mfma_big"
+                                                                                             : "dense_mfma_nt16 + dense_mfma_big";
+            return rc;
+        }
+    }
+    if ((dense_big_supported(a) || (force_big && a.n_max <= 1024 && !a.v_star)) && !force_generic) {   // GPC_FORCE_BIG: diagnostic
         int grid_b = 0;
         const size_t big_bytes = (dense_big_ws_bytes(ctx, a, &grid_b) + 255) & ~(size_t)255;
-        const bool split = a.n_max > 256 && a.P > 1 && !getenv("GPC_FORCE_BIG") && !getenv("GPC_NO_SPLIT");
-        int rcb = gpc_ws_reserve(ctx, big_bytes + (split ? sizeof(int32_t) * (2 * (size_t)a.P + 64) : 0));
+        int rcb = gpc_ws_reserve(ctx, big_bytes);
         if (rcb != GPC_OK) return rcb;
-        if (!split) return dense_big_launch(ctx, a, grid_b);
-        int32_t* counts = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->ws) + big_bytes);
-        int32_t* sel_small = counts + 64;
-        int32_t* sel_big = sel_small + a.P;
-        GPC_HIP(ctx, hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), ctx->stream));
-        hipLaunchKernelGGL(dense_classify_kernel, dim3((a.P + 255) / 256), dim3(256), 0, ctx->stream, a.P, a.off, 256, sel_small, sel_big, counts);
-        GPC_HIP(ctx, hipGetLastError());
-        DenseArgs s = a;
-        s.n_max = 256;
-        s.sel = sel_small; s.sel_count = counts;
-        int rc = dense_mfma_launch(ctx, s);            // workgroups beyond the class count leave at once
-        if (rc != GPC_OK) return rc;
-        DenseArgs b = a;
-        b.sel = sel_big; b.sel_count = counts + 1;
-        rc = dense_big_launch(ctx, b, grid_b);
-        ctx->last_dense_kernel = "dense_mfma_nt16 + dense_mfma_big";
-        return rc;
+        return dense_big_launch(ctx, a, grid_b);
     }
     int grid = 0;
     size_t bytes = dense_generic_ws_bytes(ctx, a, &grid);
@@ -470,11 +532,9 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
     const bool want_v = !grid && params->want_variance && v_star;
     const size_t N = (size_t)n_total;
     const int C = (P >= 2048 && !getenv("GPC_HOST_NO_PIPELINE")) ? 4 : 1;
-    if (!ctx->s_in) {
-        GPC_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
-        GPC_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
-        for (auto& row : ctx->ev)
-            for (auto& e : row) GPC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if ((rc = gpc_aux_streams(ctx))) return rc;
     }
     // device arena: [off chunks | x0 | x1 | y planes per chunk | xs0 xs1 | f | v | alpha | status]
     auto al256 = [](size_t v) { return (v + 255) & ~(size_t)255; };

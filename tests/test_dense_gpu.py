@@ -87,7 +87,7 @@ def test_dense_vs_oracle(gp, oracle, kernel_choice, P, n, ny, ragged, seed):
     fo, _, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, want_alpha=True)
     n_max = int(np.max(np.diff(off)))
     want_kernel = {"generic": "dense_generic", "big": "dense_mfma_big"}.get(
-        kernel_choice, ("dense_mfma_nt16 + dense_mfma_big" if P > 1 else "dense_mfma_big") if n_max > 256 else "dense_mfma_nt")
+        kernel_choice, ("dense_mfma_nt16 + " if P > 1 else "dense_mfma_big") if n_max > 256 else "dense_mfma_nt")
     assert ctx.last_dense_kernel().startswith(want_kernel), ctx.last_dense_kernel()
     assert np.array_equal(st, so)
     _close(f, fo, FTOL)
@@ -201,23 +201,24 @@ def test_dense_size_class_split(gp, oracle, monkeypatch):
     capi, ctx = gp
     res, sz = 0.15, 10
     rng = np.random.default_rng(17)
-    counts = np.concatenate([rng.integers(1, 257, 40), rng.integers(257, 700, 25), [0, 256, 257, 1, 1024, 0]])
+    counts = np.concatenate([rng.integers(1, 257, 40), rng.integers(257, 700, 25), [0, 256, 257, 1, 1024, 0, 260, 265, 272, 273]])
     rng.shuffle(counts)
     off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
     P, N = len(counts), int(off[-1])
     x0, x1 = rng.uniform(-res / 2, res / 2, N), rng.uniform(-res / 2, res / 2, N)
     y = rng.normal(0, 0.01, (1, N))
     small = int(np.flatnonzero((counts > 40) & (counts <= 256))[0])
+    mid = int(np.flatnonzero(counts == 265)[0])         # the NT = 17 class (256 < n <= 272)
     big = int(np.flatnonzero(counts > 300)[0])
-    for i in (small, big):                      # a duplicated point: singular without noise
+    for i in (small, mid, big):                 # a duplicated point: singular without noise
         x0[off[i] + 30], x1[off[i] + 30] = x0[off[i] + 3], x1[off[i] + 3]
     p0 = capi.default_params_dense(noise=0.0, sigmaf_sq=1.0, l_sq=0.003 ** 2)
     po = oracle.dense_params(1.0, 0.003 ** 2, 0.0)
     f, st = ctx.dense_fit_predict_grid(p0, off, x0, x1, y, res, sz)
-    assert ctx.last_dense_kernel() == "dense_mfma_nt16 + dense_mfma_big"
+    assert ctx.last_dense_kernel() == "dense_mfma_nt16 + dense_mfma_nt17 + dense_mfma_big"
     xs0, xs1 = oracle.grid(res, sz)
     fo, _, so = oracle.dense_fit_predict_batch(po, off, x0, x1, y, xs0, xs1)
-    assert st.tolist() == so.tolist() and st[small] == 1 and st[big] == 1 and st.sum() == 2
+    assert st.tolist() == so.tolist() and st[small] == 1 and st[mid] == 1 and st[big] == 1 and st.sum() == 3
     for i in range(P):
         if st[i] == 0:
             assert np.max(np.abs(f[i] - fo[i])) <= 1e-8 * max(np.max(np.abs(fo[i])), 1e-12), (i, counts[i])
@@ -230,6 +231,49 @@ def test_dense_size_class_split(gp, oracle, monkeypatch):
     assert ctx.last_dense_kernel() == "dense_mfma_big" and st1.tolist() == st.tolist()
     ok_big = (counts > 256) & (st == 0)
     assert np.max(np.abs(f[ok_big] - f1[ok_big])) <= 1e-10 * np.max(np.abs(f1[ok_big]))
+
+
+@pytest.mark.parametrize("P,lo,hi", [(1, 272, 272), (1, 257, 257), (24, 257, 272), (40, 200, 272)])
+def test_dense_nt17_shape(gp, oracle, monkeypatch, P, lo, hi):
+    """Patches of 257 .. 272 points (what the octree leaves of a cloud cut for 256-point patches mostly are) stay on the
+    register-resident kernel in its NT = 17 shape (depth plane only).  Oracle parity for grid and point-wise entries and alpha; the
+    tiled kernel on the same batch (GPC_NO_NT17) agrees to its own tolerance; three channels still take the tiled kernel."""
+    capi, ctx = gp
+    res, sz = 0.15, 20
+    rng = np.random.default_rng(100 + P + lo)
+    counts = rng.integers(lo, hi + 1, P)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    N = int(off[-1])
+    x0, x1 = rng.uniform(-res / 2, res / 2, N), rng.uniform(-res / 2, res / 2, N)
+    y = 0.01 * np.sin(30 * x0) * np.cos(20 * x1) + rng.normal(0, 0.003, N)
+    y = (y - np.mean(y))[None, :]
+    prm = capi.default_params_dense()
+    xs0, xs1 = oracle.grid(res, sz)
+    f, st, al = ctx.dense_fit_predict_grid(prm, off, x0, x1, y, res, sz, want_alpha=True)
+    name = ctx.last_dense_kernel()
+    assert name == ("dense_mfma_nt17" if P == 1 else "dense_mfma_nt16 + dense_mfma_nt17"), name
+    fo, _, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, want_alpha=True)
+    assert np.all(st == 0) and np.all(so == 0)
+    _close(f, fo, FTOL)
+    _close(al, ao, ATOL)
+    f2, _, st2 = ctx.dense_fit_predict(prm, off, x0, x1, y, xs0, xs1)
+    _close(f2, fo, FTOL)
+    monkeypatch.setenv("GPC_NO_NT17", "1")
+    f3, st3 = ctx.dense_fit_predict_grid(prm, off, x0, x1, y, res, sz)
+    assert "nt17" not in ctx.last_dense_kernel()
+    _close(f3, f, 1e-10)
+    monkeypatch.delenv("GPC_NO_NT17")
+    if P > 1:
+        y3 = np.concatenate([y, 2 * y, -y], axis=0)
+        f4, st4 = ctx.dense_fit_predict_grid(prm, off, x0, x1, y3, res, sz)
+        assert ctx.last_dense_kernel() == "dense_mfma_nt16 + dense_mfma_big"
+        _close(f4[:, 0, :], fo[:, 0, :], FTOL)
+    # stale-LDS check of the new shape: NaN poison in every CU's LDS before the call
+    monkeypatch.setenv("GPC_POISON_LDS", "1")
+    f5, st5 = ctx.dense_fit_predict_grid(prm, off, x0, x1, y, res, sz)
+    monkeypatch.delenv("GPC_POISON_LDS")
+    assert np.all(st5 == 0)
+    _close(f5, fo, FTOL)
 
 
 def test_dense_argument_errors(gp):

@@ -7,7 +7,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_r02
-WL="${1:-c2 c3 c4fill c4defaults c5}"
+WL="${1:-c2 c2var c3 c4fill c4defaults c5}"
 mkdir -p $OUT
 run() { local d=$1; shift; echo "=== $d: $*" | tee -a $OUT/session.log; rm -rf $OUT/$d; mkdir -p $OUT/$d
         timeout -k 10 300 "$@" > $OUT/$d/cmd.log 2>&1; rc=$?; echo "rc=$rc" | tee -a $OUT/session.log
@@ -18,7 +18,7 @@ for w in $WL; do
   run $w/trace rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$w/trace/out -- $B
   run $w/fetch rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/$w/fetch/out -- $B
   run $w/write rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/$w/write/out -- $B
-  if [ $w = c2 ] || [ $w = c3 ] || [ $w = c5 ]; then
+  if [ $w = c2 ] || [ $w = c2var ] || [ $w = c3 ] || [ $w = c5 ]; then
     run $w/sq rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/$w/sq/out -- $B
     run $w/grbm rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/$w/grbm/out -- $B
   fi
