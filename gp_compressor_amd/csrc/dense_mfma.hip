@@ -306,8 +306,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             // the identity padding live in a separate branch.  (Written as one body with wave-uniform conditions, hipcc
             // if-converts them into ~18 selects and compares per ELEMENT -- more than the exponential itself.  The opaque
             // lane id inside the special branch is what keeps it a branch.)
-#define MF_GRAM(RBF)                                                                                                 \
-    _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                                                \
+#define MF_GRAM(RBF, T0, T1)                                                                                         \
+    _Pragma("unroll") for (int t = T0; t < T1; ++t) {                                                                \
         acc[t] = d4{0.0, 0.0, 0.0, 0.0};                                                                             \
         if (live_mask & (1u << t)) {                                                                                 \
             const int ln = mf_opaque(lane), lr = ln & 15, lg = ln >> 4;                                              \
@@ -335,10 +335,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
             }                                                                                                        \
         }                                                                                                            \
     }
-            if (small_gram) {
-                // sigma_f^2 folded into the polynomial coefficients: sf exp(x) in 7 FMAs
-                const double k7 = sf * (1.0 / 5040.0), k6 = sf * (1.0 / 720.0), k5 = sf * (1.0 / 120.0), k4 = sf * (1.0 / 24.0),
-                             k3 = sf * (1.0 / 6.0), k2 = sf * 0.5;
+            // The first three slots hold the tiles the factor wave starts from -- (0,0), (1,0), (1,1) for every NT -- so they are
+            // evaluated and handed over FIRST: the diagonal factor of column 0, the TRSM of (1,0) and the factor of column 1 then
+            // run on the factor wave while the workers are still evaluating the rest of the Gram matrix.
+            constexpr int TH = TPW < 3 ? TPW : 3;
+            // sigma_f^2 folded into the polynomial coefficients: sf exp(x) in 7 FMAs
+            const double k7 = sf * (1.0 / 5040.0), k6 = sf * (1.0 / 720.0), k5 = sf * (1.0 / 120.0), k4 = sf * (1.0 / 24.0),
+                         k3 = sf * (1.0 / 6.0), k2 = sf * 0.5;
 #define MF_RBF_SMALL(xa, ya, xb, yb)                                                                                 \
     ([&]() __attribute__((always_inline)) {                                                                          \
         const double d0_ = (xa) - (xb), d1_ = (ya) - (yb);                                                           \
@@ -351,15 +354,17 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
         p_ = __builtin_fma(x_, p_, sf);                                                                              \
         return __builtin_fma(x_, p_, sf);                                                                            \
     }())
-                MF_GRAM(MF_RBF_SMALL(xi0, xi1, px0[pj], px1[pj]))
+            if (small_gram) {
+                MF_GRAM(MF_RBF_SMALL(xi0, xi1, px0[pj], px1[pj]), 0, TH)
             } else {
-                MF_GRAM(gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T))
+                MF_GRAM(gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T), 0, TH)
             }
             // ---- first hand-overs: tile (0,0), and tiles (1,0) / (1,1) as they are (no panel precedes them) ----
 #define MF_HAND_CASE(t)                                                                                              \
     if constexpr (t < TPW) {                                                                                         \
         if (smask & (1u << t)) *reinterpret_cast<d4*>(hand_to + mf_opaque(lane) * 4) = acc[t];                       \
     }
+            static_assert(1 / MF_WORKERS == 0 && NT / MF_WORKERS < 3, "the chain's first tiles sit in slots 0 .. 2");
             if (wave == 0) {
                 *reinterpret_cast<d4*>(Gzero + mf_opaque(lane) * 4) = acc[0];   // register layout, as the factor wave consumes it
                 mf_publish(t00_ready, 1);
@@ -377,6 +382,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dense_mfma_kernel(MfmaParams g)
                     MF_SLOTS(MF_HAND_CASE)
                     mf_publish(tile_ready, 1);
                 }
+            }
+            if (small_gram) {
+                MF_GRAM(MF_RBF_SMALL(xi0, xi1, px0[pj], px1[pj]), TH, TPW)
+            } else {
+                MF_GRAM(gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T), TH, TPW)
             }
             MF_STAMP(0);
 
