@@ -210,7 +210,7 @@ def bench_dense(env, P, n, steps, warmup, seed=2):
 
 
 def dense_record(name, r, P, n, world, steps, warmup):
-    tkey = {"dense_mfma_nt16": "dense_mfma_nt16", "dense_mfma_big": f"dense_mfma_big@n{n}"}.get(r["kernel"], r["kernel"])
+    tkey = f"dense_mfma_big@n{n}" if ("dense_mfma_big" in r["kernel"] and n > 272) else r["kernel"]
     par = (f"{world * P} patches partitioned over {world} ranks by gpc_partition_patches (LPT), 1 all-gather of f_star + un-permute"
            if world > 1 else "1 GPU")
     return {"metric": "patches/sec (compress+predict)", "value": r["value"], "unit": "patches/s", "n_gpus": world, "steps": steps,

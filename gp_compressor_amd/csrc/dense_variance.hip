@@ -102,6 +102,17 @@ __global__ __launch_bounds__(DV_THREADS, 2) void dense_variance_kernel(VarParams
             pre = *reinterpret_cast<const d4*>(F + (size_t)c1 * DV_CH * MF_IMG + my4);
         }
         __syncthreads();
+        if (!active) {
+            // no block left for this wave in the last round: keep feeding the LDS stream (same barriers, same order) but stay
+            // off the MFMA pipe, which the SIMD's other wave may be using
+            for (int c = 1; c <= last_chunk; ++c) {
+                *reinterpret_cast<d4*>(&Lbuf[c & 1][my4]) = pre;
+                const int cn = min(c + 1, last_chunk);
+                pre = *reinterpret_cast<const d4*>(F + (size_t)cn * DV_CH * MF_IMG + my4);
+                __syncthreads();
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             if (i < nt) {
