@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPC_LIB_PATH", os.path.join(HERE, "libgpc_hip.so"))   # override: diagnostic builds only
 
 GPC_OK, GPC_EINVAL, GPC_ENOMEM, GPC_ENODEV, GPC_EHIP, GPC_ERANGE = 0, -22, -12, -19, -5, -34
-STATUS_OK, STATUS_NOT_SPD, STATUS_NAN, STATUS_SIGMA_CLAMPED = 0, 1, 2, 3
+STATUS_OK, STATUS_NOT_SPD, STATUS_NAN, STATUS_SIGMA_CLAMPED, STATUS_OVERFLOW, STATUS_NOT_CONVERGED = 0, 1, 2, 3, 4, 5
 MAX_POINTS, MAX_BV = 1024, 256
 
 c_dp = C.POINTER(C.c_double)

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         }
         int iter = 0;
         bool nan_w = false;
+        [[maybe_unused]] bool converged = true;      // IRLS: false when the step cap ended the loop
         for (;;) {     // Newton / IRLS iterations (BG_IRLS); a single pass otherwise
         if constexpr (BG_IRLS) {
             // weights and working targets from the functor at the current f (sigma_x = 0); reset the step's hand-over words
@@ -517,7 +518,8 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
             const double delta = __longlong_as_double((long long)*delta_bits);
             ++iter;
             if (delta != delta) { nan_w = true; break; }
-            if (delta <= g.irls_tol || iter >= g.irls_max_iter) break;
+            if (delta <= g.irls_tol) break;
+            if (iter >= g.irls_max_iter) { converged = false; break; }
             __syncthreads();   // delta_bits is reset by the next prologue
         }
         }   // Newton / IRLS iterations
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         BG_STAMP(4);
         if (timed_out && lane == 0) flag[0] = 2;
         __syncthreads();
-        if (tid == 0 && A.status) A.status[patch] = flag[0] ? GPC_STATUS_NAN : GPC_STATUS_OK;
+        if (tid == 0 && A.status) A.status[patch] = flag[0] ? GPC_STATUS_NAN : (BG_IRLS && !converged) ? GPC_STATUS_NOT_CONVERGED : GPC_STATUS_OK;
     }
 }
 

@@ -53,6 +53,7 @@ extern "C" {
 #define GPC_STATUS_NAN 2          /* state became NaN ("sparse_gp::C has become Nan", src/sparse_gp.hpp:245) */
 #define GPC_STATUS_SIGMA_CLAMPED 3 /* predictive sigma^2 < 0 was clamped to 0 (src/sparse_gp.hpp:334-337) */
 #define GPC_STATUS_OVERFLOW 4     /* sparse, capacity == -1 only: basis set would exceed GPC_MAX_BV; point skipped */
+#define GPC_STATUS_NOT_CONVERGED 5 /* gpc_dense_irls_fit_predict: max_iter Newton steps without max|df| <= tol; outputs are the last iterate */
 
 #define GPC_MAX_POINTS 1024 /* largest n per patch of the dense path (BASELINE config 5) */
 #define GPC_MAX_BV 256      /* largest sparse capacity (BASELINE config 4 uses 200) */
@@ -154,7 +155,8 @@ int gpc_dense_fit_predict_grid_dev(gpc_ctx* ctx, const gpc_params* params, int P
  * singular at f = 0, needs f_init > 0) or 2 (proper CDF; f_init = 0 is the textbook start).  y: N labels.
  * Prediction: latent mean f* = K*^T a on X* -- point-wise (xs0, xs1, m) or, when xs0 == NULL, the sz x sz grid of
  * gp_compressor::load_compressed (res, sz; m is ignored).  f_star [P][m]; alpha_out [N] (= a), fhat_out [N] (the mode at the
- * training points), iters [P] (solves performed) and status [P] may be NULL.  Status GPC_STATUS_NAN: a weight W_i was not
+ * training points), iters [P] (solves performed) and status [P] may be NULL.  Status GPC_STATUS_NOT_CONVERGED: the step cap ended
+ * the loop (outputs are the last iterate).  Status GPC_STATUS_NAN: a weight W_i was not
  * finite and positive (with noise_model 1 this is the normal outcome when a step crosses f = 0); outputs of the patch are NaN.
  * Definition and CPU restatement: oracle/gpc_oracle.c (orc_dense_irls_fit). */
 typedef struct gpc_irls_params {

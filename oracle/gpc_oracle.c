@@ -270,7 +270,7 @@ int orc_dense_fit_predict_batch(const orc_dense_params* p, int P, const int32_t*
  * Stop after max_iter solves or when max_i |f_new_i - f_i| <= tol.  A weight that is not finite and positive ends the
  * patch with status 2 (the same NaN the reference's recursion would print, src/sparse_gp.hpp:245).
  * Predictive latent mean: f* = K*^T a  (R&W eq. 3.21: k*^T grad log p(y | f^) = k*^T a at the mode).
- * Returns 0 ok, 1 + j non-SPD pivot j, -2 NaN weight. */
+ * Returns 0 ok, 1 + j non-SPD pivot j, -2 NaN weight, -5 the step cap ended the loop (outputs are the last iterate). */
 int orc_dense_irls_fit(const orc_dense_params* p, int noise_model, int n, const double* x0, const double* x1, const double* y,
                        int max_iter, double tol, double f_init, double* alpha, double* fhat, int32_t* iters)
 {
@@ -339,14 +339,15 @@ int orc_dense_irls_fit(const orc_dense_params* p, int noise_model, int n, const 
         *iters = it + 1;
         if (delta != delta) { rc = -2; break; }
         if (delta <= tol) break;
+        if (it + 1 == max_iter) rc = -5;
     }
-    if (rc)
+    if (rc && rc != -5)
         for (int i = 0; i < n; ++i) alpha[i] = fhat[i] = NAN;
     free(K); free(L); free(d);
     return rc;
 }
 
-/* batch driver, same shape as gpc_dense_irls_fit_predict (include/gpc.h); status: 0 ok, 1 non-SPD, 2 NaN */
+/* batch driver, same shape as gpc_dense_irls_fit_predict (include/gpc.h); status: 0 ok, 1 non-SPD, 2 NaN, 5 not converged */
 int orc_dense_irls_fit_predict_batch(const orc_dense_params* p, int noise_model, int max_iter, double tol, double f_init,
                                      int P, const int32_t* off, const double* x0, const double* x1, const double* y,
                                      int m, const double* xs0, const double* xs1, double* f_star, double* alpha_out,
@@ -363,7 +364,7 @@ int orc_dense_irls_fit_predict_batch(const orc_dense_params* p, int noise_model,
         int32_t it = 0;
         const int rc = orc_dense_irls_fit(p, noise_model, n, x0 + o, x1 + o, y + o, max_iter, tol, f_init, a, fh, &it);
         if (rc == -12) { free(a); return -12; }
-        if (status) status[i] = rc == 0 ? 0 : (rc > 0 ? 1 : 2);
+        if (status) status[i] = rc == 0 ? 0 : (rc > 0 ? 1 : (rc == -5 ? 5 : 2));
         if (iters) iters[i] = it;
         if (alpha_out) memcpy(alpha_out + o, a, sizeof(double) * (size_t)n);
         if (fhat_out) memcpy(fhat_out + o, fh, sizeof(double) * (size_t)n);

@@ -272,7 +272,7 @@ def test_irls_known_answers(gp):
     # (ii)
     off, x0, x1, lab = _irls_inputs(3, 200, seed=12)
     f, al, fh, it, st = ctx.dense_irls_fit_predict(p, capi.default_params_irls(max_iter=1, tol=0.0), off, x0, x1, lab, res=RES, sz=20)
-    assert np.all(it == 1) and np.all(st == 0)
+    assert np.all(it == 1) and np.all(st == capi.STATUS_NOT_CONVERGED)      # one step by construction: the cap ends the loop
     pg = capi.default_params_dense(sigmaf_sq=sf, l_sq=l_sq, noise=np.pi / 2 * s20, ref_double_noise=0)
     fg, stg = ctx.dense_fit_predict_grid(pg, off, x0, x1, (np.sqrt(np.pi / 2) * sig * lab)[None, :], RES, 20)
     assert np.max(np.abs(f - fg[:, 0, :])) <= 1e-10 * np.max(np.abs(fg))
@@ -280,6 +280,38 @@ def test_irls_known_answers(gp):
     K = R.rbf(sf, l_sq, X, X)
     a = np.linalg.solve(K + np.pi / 2 * s20 * np.eye(200), np.sqrt(np.pi / 2) * sig * lab[:200])
     assert np.max(np.abs(al[:200] - a)) <= 1e-9 * np.max(np.abs(a))
+
+
+def test_irls_edge_cases_and_errors(gp, oracle):
+    """empty patches, a ragged batch across both kernel shapes, the step cap (GPC_STATUS_NOT_CONVERGED, outputs = the last
+    iterate, equal to the oracle's), argument errors as return codes"""
+    capi, ctx = gp
+    res, sz = 0.15, 6
+    off, x0, x1, y = synth.make_patches(5, 300, res=res, seed=77, ragged=True)
+    lab = synth.occupancy_labels(off, y[0])
+    off2 = np.concatenate([[0, 0], off[1:], [off[-1]]]).astype(np.int32)          # an empty patch in front and at the end
+    s20, l_sq = 0.25, (res / 3) ** 2
+    p = capi.default_params_dense(sigmaf_sq=1.0, l_sq=l_sq, noise=s20, noise_model=2)
+    op = oracle.dense_params(sigmaf_sq=1.0, l_sq=l_sq, sigman_sq=s20)
+    xs0, xs1 = synth.grid(res, sz)
+    for max_iter, tol in ((20, 1e-9), (2, 1e-12)):
+        f, al, fh, it, st = ctx.dense_irls_fit_predict(p, capi.default_params_irls(max_iter=max_iter, tol=tol), off2, x0, x1, lab, res=res, sz=sz)
+        fo, alo, fho, ito, sto = oracle.dense_irls_fit_predict_batch(op, 2, off2, x0, x1, lab, xs0, xs1, max_iter=max_iter, tol=tol)
+        assert np.array_equal(st, sto) and np.array_equal(it, ito)
+        assert st[0] == 0 and st[-1] == 0 and it[0] == 0 and np.all(f[0] == 0) and np.all(f[-1] == 0)
+        want = capi.STATUS_OK if max_iter == 20 else capi.STATUS_NOT_CONVERGED
+        assert np.all(st[1:-1] == want) and (max_iter == 20 or np.all(it[1:-1] == 2))
+        assert np.max(np.abs(f - fo)) <= 1e-8 * np.max(np.abs(fo)) and np.max(np.abs(fh - fho)) <= 1e-8 * np.max(np.abs(fho))
+    ir = capi.default_params_irls()
+    for bad_p, bad_ir in ((capi.default_params_dense(noise_model=0), ir), (capi.default_params_dense(noise_model=2, noise=0.0), ir),
+                          (p, capi.default_params_irls(max_iter=0)), (p, capi.default_params_irls(tol=-1.0))):
+        with pytest.raises(capi.GpcError) as e:
+            ctx.dense_irls_fit_predict(bad_p, bad_ir, off2, x0, x1, lab, res=res, sz=sz)
+        assert e.value.code == capi.GPC_EINVAL
+    big = np.array([0, 1025], dtype=np.int32)
+    with pytest.raises(capi.GpcError) as e:
+        ctx.dense_irls_fit_predict(p, ir, big, np.zeros(1025), np.zeros(1025), np.ones(1025), res=res, sz=sz)
+    assert e.value.code == capi.GPC_ERANGE
 
 
 def test_irls_full_config5_properties(gp, oracle):
