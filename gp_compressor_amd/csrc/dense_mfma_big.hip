@@ -41,6 +41,8 @@ struct BigParams {
     size_t slot;   // doubles per workgroup slot
     int ntw;       // tile columns of a slot = ceil(n_max / 16)
     unsigned long long* stamps;   // diagnostic (GPC_BIG_STAMPS=1): [phase][wave] cycle sums over all patches, else nullptr
+    int export_factor;            // predictive variance (dense_variance.hip): the factor of EVERY patch stays in the workspace (slot =
+                                  // patch, not workgroup) together with the L_kk^-1 images
     // IRLS instantiation only (BASELINE config 5, gpc_dense_irls_fit_predict): the Newton loop around the factorisation
     int irls_model;               // GPC_NOISE_PROBIT_REF / GPC_NOISE_PROBIT_STD
     int irls_max_iter;
@@ -125,12 +127,18 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
     const double sf = A.prm.sigmaf_sq, cexp = g.c_exp, noise = A.prm.noise;
     double* Lt = g.ws + (size_t)blockIdx.x * g.slot;              // tiles (i, j): Lt + (i * ntw + j) * 256, i = 0 .. ntw
     double* LinvTg = Lt + (size_t)(ntw + 1) * ntw * MF_IMG;       // L_kk^-T images, k = 0 .. ntw-1
+    double* LinvG = LinvTg + (size_t)ntw * MF_IMG;                // L_kk^-1 images (written when the factor is exported)
 
     gpc_exp_table_init(T);
 
     const int n_patches = A.sel ? __builtin_amdgcn_readfirstlane(A.sel_count[0]) : A.P;   // size-class dispatch: sel[0 .. count)
     for (int pk = blockIdx.x; pk < n_patches; pk += gridDim.x) {
         const int patch = A.sel ? __builtin_amdgcn_readfirstlane(A.sel[pk]) : pk;
+        if (g.export_factor) {
+            Lt = g.ws + (size_t)patch * g.slot;
+            LinvTg = Lt + (size_t)(ntw + 1) * ntw * MF_IMG;
+            LinvG = LinvTg + (size_t)ntw * MF_IMG;
+        }
         const int o = __builtin_amdgcn_readfirstlane(A.off[patch]);
         const int n = __builtin_amdgcn_readfirstlane(A.off[patch + 1]) - o;
         double* fs = A.f_star + (size_t)patch * ny * m;
@@ -281,6 +289,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                 const d4 D00 = *reinterpret_cast<const d4*>(Hand + lane * 4);
                 bool ok = mf_diag_factor(D00, rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (g.export_factor) mf_img_store(LinvG + (size_t)k * MF_IMG, lane, mf_img_load(LinvC, lane));
                 if (!ok && lane == 0) flag[0] = 1;
                 if (ok && has2) {
                     mf_publish(ready, k);                                  // L_kk^-1 (the workers start their first TRSM)
@@ -294,6 +303,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                     D11 = bg_mfma4_neg(l10, l10, D11);
                     ok = mf_diag_factor(D11, rsbuf, LinvC + 256, LinvTg + (size_t)(k + 1) * MF_IMG, g.pivot_tol);
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (g.export_factor) mf_img_store(LinvG + (size_t)(k + 1) * MF_IMG, lane, mf_img_load(LinvC + 256, lane));
                     if (!ok && lane == 0) flag[0] = 1;
                 }
                 mf_publish(ready, k1);
@@ -641,10 +651,11 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
 
 bool dense_big_supported(const DenseArgs& a)
 {
-    return a.n_max > 256 && a.n_max <= 1024 && a.v_star == nullptr && (a.ny == 1 || a.ny == 3);
+    // (with the variance: point-wise X* only -- the variance entry has no grid form)
+    return a.n_max > 256 && a.n_max <= 1024 && (a.v_star == nullptr || a.xs0 != nullptr) && (a.ny == 1 || a.ny == 3);
 }
 
-static size_t big_slot_doubles(int ntw) { return ((size_t)(ntw + 1) * ntw + ntw) * MF_IMG; }
+size_t big_slot_doubles(int ntw) { return ((size_t)(ntw + 1) * ntw + 2 * (size_t)ntw) * MF_IMG; }
 
 // <8 waves, 1024 points, 2 rows per pass, 2 waves/SIMD>: 103 KB of LDS, one workgroup per CU: 256 < n <= 1024.
 // <4 waves, 256 points, 2 rows per pass, 2 waves/SIMD>: 37 KB of LDS, two workgroups = two patches per CU: the cross-check
@@ -665,7 +676,11 @@ size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
     if (const char* e = getenv("GPC_BIG_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;   // diagnostic: resident-workgroup experiments
     const int grid = a.P < cap ? a.P : cap;
     if (grid_out) *grid_out = grid;
-    return sizeof(double) * big_slot_doubles(ntw) * (size_t)grid;
+    // with the variance requested the factor of every patch is kept (one slot per patch) + alpha + the per-wave V scratch of
+    // dense_variance_big_kernel
+    const size_t slots = a.v_star ? (size_t)a.P : (size_t)grid;
+    const size_t extra = a.v_star ? sizeof(double) * ((size_t)a.n_total * a.ny + dense_variance_big_scratch_doubles(ctx, ntw)) : 0;
+    return sizeof(double) * big_slot_doubles(ntw) * slots + extra;
 }
 
 template <int W, int NP, int RM, int OC, bool IRLS = false>
@@ -691,6 +706,7 @@ int dense_irls_launch(gpc_ctx* ctx, const DenseArgs& a, const IrlsArgs& ir, int 
     g.ntw = (a.n_max + MF_TS - 1) / MF_TS;
     g.slot = big_slot_doubles(g.ntw);
     g.stamps = nullptr;
+    g.export_factor = 0;
     g.irls_model = a.prm.noise_model;
     g.irls_max_iter = ir.max_iter;
     g.irls_tol = ir.tol;
@@ -707,10 +723,22 @@ int dense_irls_launch(gpc_ctx* ctx, const DenseArgs& a, const IrlsArgs& ir, int 
     return big_launch_t<8, 1024, 2, 2, true>(ctx, g, grid);
 }
 
-int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
+int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
 {
+    DenseArgs a = a_in;
+    double* v_star = a.v_star;
+    const int ntw_ = (a.n_max + MF_TS - 1) / MF_TS;
+    double* ws_alpha = nullptr;
+    if (v_star) {
+        // the variance kernel forms the mean from the same K* tiles: the fit predicts nothing, and leaves alpha behind
+        ws_alpha = static_cast<double*>(ctx->ws) + big_slot_doubles(ntw_) * (size_t)a.P;
+        a.v_star = nullptr;
+        a.m = 0;
+        if (!a.alpha_out) a.alpha_out = ws_alpha;
+    }
     BigParams g;
     g.a = a;
+    g.export_factor = v_star ? 1 : 0;
     g.c_exp = (double)(-0.5f) / a.prm.l_sq;
     g.pivot_tol = GPC_PIVOT_RTOL * (a.prm.sigmaf_sq + a.prm.noise);
     g.ws = static_cast<double*>(ctx->ws);
@@ -747,6 +775,11 @@ int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
         ctx->last_dense_kernel = "dense_mfma_big_w4";
         return big_launch_t<4, 256, 2, 2>(ctx, g, grid);
     }
-    ctx->last_dense_kernel = "dense_mfma_big";
-    return big_launch_t<8, 1024, 2, 2>(ctx, g, grid);
+    ctx->last_dense_kernel = v_star ? "dense_mfma_big + dense_variance_big" : "dense_mfma_big";
+    int rc = big_launch_t<8, 1024, 2, 2>(ctx, g, grid);
+    if (rc != GPC_OK || !v_star) return rc;
+    DenseArgs av = a;
+    av.m = a_in.m;
+    return dense_variance_big_launch(ctx, av, g.ntw, g.ws, g.slot, a.alpha_out,
+                                     ws_alpha + (size_t)a.n_total * a.ny, v_star);
 }

@@ -197,3 +197,254 @@ int dense_variance_launch(gpc_ctx* ctx, const DenseArgs& a, int nt_max, const do
         default: return var_launch_t<16>(ctx, g, a.P);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same solve for 256 < n <= 1024, from the tiled kernel's factor (dense_mfma_big.hip keeps the slot of EVERY patch when the
+// variance is requested: tiles (i, k) at (i * ntw + k) * 256, the L_kk^-1 images behind them).  A block of 16 prediction points
+// now has up to 64 V tiles -- 512 registers -- so the forward substitution runs in SUPER-ROWS of 16 tile rows: the 16
+// residual / V tiles of the current super-row live in registers, finished super-rows go to a per-wave scratch in global memory
+// (L2-resident: written once, read once per later super-row and column, each tile then serving 16 products from registers),
+// and the factor streams through LDS exactly as above, in the order of the traversal:
+//     for I:  for J < I:  for kk: V_(16J+kk) <- scratch;  for ii: R_ii -= L_(16I+ii)(16J+kk) V        (column-major in the block)
+//             for ii:  for kk < ii: R_ii -= L_(16I+ii)(16I+kk) R_kk;   R_ii <- L_ii^-1 R_ii           (row-major, diagonal block)
+// stream position -> tile is a closed form (dv_stream_tile), evaluated by the wave that fetches the tile.
+struct VarBigParams {
+    DenseArgs a;
+    double c_exp;
+    const double* ws;       // factor slots, one per patch
+    size_t slot;            // doubles per slot
+    int ntw;                // tile columns of a slot
+    const double* alpha;    // [ny][n_total]
+    double* scratch;        // [gridDim.x][8 waves][ntw][256]
+    double* v_star;         // [P][m]
+};
+
+// super-row I holds rI = min(16, nt - 16 I) tile rows; its part of the stream: I off-diagonal blocks of 16 columns x rI rows
+// (column-major), then the diagonal block row-major with L_ii^-1 in the diagonal position
+__device__ static __forceinline__ int dv_stream_len(int nt)
+{
+    int len = 0;
+    for (int I = 0; 16 * I < nt; ++I) {
+        const int rI = min(16, nt - 16 * I);
+        len += 16 * rI * I + (rI * (rI + 1)) / 2;
+    }
+    return len;
+}
+// offset (in doubles, relative to the patch's slot) of the image at stream position p
+__device__ static __forceinline__ size_t dv_stream_tile(int p, int nt, int ntw)
+{
+    int I = 0, base = 0;
+    for (;; ++I) {
+        const int rI = min(16, nt - 16 * I);
+        const int len = 16 * rI * I + (rI * (rI + 1)) / 2;
+        if (p < base + len || 16 * (I + 1) >= nt) break;
+        base += len;
+    }
+    const int rI = min(16, nt - 16 * I);
+    int q = p - base;
+    const int offd = 16 * rI * I;
+    int i, k;
+    if (q < offd) {
+        const int J = q / (16 * rI), w = q - J * (16 * rI);
+        k = 16 * J + w / rI;
+        i = 16 * I + w % rI;
+    } else {
+        q -= offd;
+        int ii = 0;
+        while ((ii + 1) * (ii + 2) / 2 <= q) ++ii;
+        const int kk = q - (ii * (ii + 1)) / 2;
+        i = 16 * I + ii;
+        k = 16 * I + kk;
+        if (kk == ii) return ((size_t)(ntw + 1) * ntw + ntw + i) * MF_IMG;        // L_ii^-1 image
+    }
+    return ((size_t)i * ntw + k) * MF_IMG;
+}
+
+#define DVB_NPAD 1024
+__global__ __launch_bounds__(DV_THREADS, 2) void dense_variance_big_kernel(VarBigParams g)
+{
+    extern __shared__ __attribute__((aligned(16))) char dvb_smem[];
+    double* T = reinterpret_cast<double*>(dvb_smem);        // 64
+    double* px0 = T + 64;                                   // DVB_NPAD
+    double* px1 = px0 + DVB_NPAD;
+    double* al = px1 + DVB_NPAD;                            // 3 x DVB_NPAD
+    double* Lbuf = al + 3 * DVB_NPAD;                       // 2 x DV_CH images
+
+    const DenseArgs& A = g.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int m = A.m, ntw = g.ntw;
+    const int ny = __builtin_amdgcn_readfirstlane(A.ny);
+    const double sf = A.prm.sigmaf_sq, cexp = g.c_exp;
+    gpc_exp_table_init(T);
+    double* vs = g.scratch + ((size_t)blockIdx.x * DV_WAVES + wave) * (size_t)ntw * MF_IMG;
+    const int my4 = lane * 4;                               // this lane's 32 bytes of the image its wave fetches
+
+    for (int patch = blockIdx.x; patch < A.P; patch += gridDim.x) {
+        const int o = __builtin_amdgcn_readfirstlane(A.off[patch]);
+        const int n = __builtin_amdgcn_readfirstlane(A.off[patch + 1]) - o;
+        double* vst = g.v_star + (size_t)patch * m;
+        double* fs = A.f_star + (size_t)patch * ny * m;
+        const int st = A.status ? __builtin_amdgcn_readfirstlane(A.status[patch]) : GPC_STATUS_OK;
+        __syncthreads();                                    // previous patch is done with the LDS vectors
+        if (n <= 0 || n > MF_TS * ntw || st != GPC_STATUS_OK) {
+            for (int p = tid; p < m; p += DV_THREADS) vst[p] = (n == 0) ? sf : __builtin_nan("");
+            for (int p = tid; p < m * ny; p += DV_THREADS) fs[p] = (n == 0) ? 0.0 : __builtin_nan("");
+            continue;
+        }
+        const int nt = __builtin_amdgcn_readfirstlane((n + MF_TS - 1) / MF_TS);
+        for (int i = tid; i < MF_TS * nt; i += DV_THREADS) {
+            px0[i] = (i < n) ? A.x0[o + i] : 0.0;
+            px1[i] = (i < n) ? A.x1[o + i] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) al[c * DVB_NPAD + i] = (c < ny && i < n) ? g.alpha[(size_t)c * A.n_total + o + i] : 0.0;
+        }
+        const double* F = g.ws + (size_t)patch * g.slot;
+        const int slen = __builtin_amdgcn_readfirstlane(dv_stream_len(nt));
+        const int last_chunk = (slen - 1) / DV_CH;
+        const int nblk = (m + MF_TS - 1) / MF_TS;
+        const int rounds = (nblk + DV_WAVES - 1) / DV_WAVES;
+        const int SR = (nt + 15) / 16;
+
+        for (int rd = 0; rd < rounds; ++rd) {
+            const int blk = rd * DV_WAVES + wave;
+            const bool active = blk < nblk;
+            const int q = MF_TS * blk + lr;
+            const bool qv = active && q < m;
+            const double gx0 = qv ? A.xs0[q] : 0.0, gx1 = qv ? A.xs1[q] : 0.0;
+            double nrm = 0.0, fm[3] = {0.0, 0.0, 0.0};
+            d4 pre;
+            __syncthreads();                                // previous round (or the vector load) is complete
+            // chunk c = stream positions [8 c, 8 c + 8); wave w fetches position 8 c + w (clamped to the end of the stream)
+            auto fetch = [&](int c) __attribute__((always_inline)) {
+                const int p = min(c * DV_CH + wave, slen - 1);
+                const size_t offd = dv_stream_tile(p, nt, ntw);
+                return *reinterpret_cast<const d4*>(F + offd + ((size_t)(lane >> 5) * 128 + (lane & 31) * 4));
+            };
+            // (an image is 2 planes of 128 doubles; lane l of the fetching wave moves doubles [4 l', 4 l' + 4) of plane l >> 5)
+            auto publish = [&](int c, d4 v) __attribute__((always_inline)) {
+                *reinterpret_cast<d4*>(Lbuf + (size_t)(c & 1) * DV_CH * MF_IMG + wave * MF_IMG + (lane >> 5) * 128 + (lane & 31) * 4) = v;
+            };
+            publish(0, fetch(0));
+            pre = fetch(min(1, last_chunk));
+            __syncthreads();
+            int p = 0;                                      // stream position of the next image to consume (wave-uniform)
+#define DVB_NEXT_IMG(img)                                                                                            \
+    do {                                                                                                             \
+        if ((p & (DV_CH - 1)) == 0 && p > 0) {                                                                       \
+            const int c_ = p / DV_CH;                                                                                \
+            publish(c_, pre);                                                                                        \
+            pre = fetch(min(c_ + 1, last_chunk));                                                                    \
+            __syncthreads();                                                                                         \
+        }                                                                                                            \
+        img = mf_img_load(Lbuf + (size_t)((p / DV_CH) & 1) * DV_CH * MF_IMG + (p & (DV_CH - 1)) * MF_IMG, lane);     \
+        ++p;                                                                                                         \
+    } while (0)
+            for (int I = 0; I < SR; ++I) {
+                const int rI = min(16, nt - 16 * I);
+                d4 R[16];
+#pragma unroll
+                for (int ii = 0; ii < 16; ++ii) {
+                    R[ii] = d4{0.0, 0.0, 0.0, 0.0};
+                    if (ii < rI) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int pt = MF_TS * (16 * I + ii) + lg + 4 * r;
+                            const double kv = (qv && pt < n) ? gpc_rbf_neg(sf, cexp, px0[pt], px1[pt], gx0, gx1, T) : 0.0;
+                            R[ii][r] = kv;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                if (c < ny) fm[c] = __builtin_fma(kv, al[c * DVB_NPAD + pt], fm[c]);
+                        }
+                    }
+                }
+                // older super-rows: V tiles back from the scratch, one at a time, each serving the rI rows of this super-row
+                for (int J = 0; J < I; ++J) {
+                    d4 Vn = *reinterpret_cast<const d4*>(vs + (size_t)(16 * J) * MF_IMG + my4);
+                    for (int kk = 0; kk < 16; ++kk) {
+                        const d4 Vk = Vn;
+                        const int kn = min(16 * J + kk + 1, 16 * I - 1);
+                        Vn = *reinterpret_cast<const d4*>(vs + (size_t)kn * MF_IMG + my4);        // next tile in flight
+#pragma unroll
+                        for (int ii = 0; ii < 16; ++ii) {
+                            if (ii < rI) {
+                                d4 img;
+                                DVB_NEXT_IMG(img);
+                                if (active) {
+#pragma unroll
+                                    for (int s = 0; s < 4; ++s) R[ii] = __builtin_amdgcn_mfma_f64_16x16x4f64(img[s], Vk[s], R[ii], 0, 0, 1);
+                                }
+                            }
+                        }
+                    }
+                }
+                // the diagonal block
+#pragma unroll
+                for (int ii = 0; ii < 16; ++ii) {
+                    if (ii < rI) {
+#pragma unroll
+                        for (int kk = 0; kk < ii; ++kk) {
+                            d4 img;
+                            DVB_NEXT_IMG(img);
+                            if (active) {
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) R[ii] = __builtin_amdgcn_mfma_f64_16x16x4f64(img[s], R[kk][s], R[ii], 0, 0, 1);
+                            }
+                        }
+                        d4 img;
+                        DVB_NEXT_IMG(img);
+                        if (active) {
+                            const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
+                            const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[0], R[ii][0], z4, 0, 0, 0);
+                            const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[1], R[ii][1], z4, 0, 0, 0);
+                            const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[2], R[ii][2], z4, 0, 0, 0);
+                            const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[3], R[ii][3], z4, 0, 0, 0);
+                            R[ii] = (D0 + D1) + (D2 + D3);
+                            nrm += (R[ii][0] * R[ii][0] + R[ii][1] * R[ii][1]) + (R[ii][2] * R[ii][2] + R[ii][3] * R[ii][3]);
+                            if (I + 1 < SR) *reinterpret_cast<d4*>(vs + (size_t)(16 * I + ii) * MF_IMG + my4) = R[ii];
+                        }
+                    }
+                }
+            }
+#undef DVB_NEXT_IMG
+            nrm += __shfl_xor(nrm, 16, 64);
+            nrm += __shfl_xor(nrm, 32, 64);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                fm[c] += __shfl_xor(fm[c], 16, 64);
+                fm[c] += __shfl_xor(fm[c], 32, 64);
+            }
+            if (qv && lg == 0) {
+                vst[q] = sf - nrm;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < ny) fs[(size_t)c * m + q] = fm[c];
+            }
+        }
+    }
+}
+
+static int dvb_grid(const gpc_ctx* ctx, int P) { return P < ctx->num_cus ? P : ctx->num_cus; }
+
+size_t dense_variance_big_scratch_doubles(const gpc_ctx* ctx, int ntw)
+{
+    return (size_t)ctx->num_cus * DV_WAVES * (size_t)ntw * MF_IMG;
+}
+
+int dense_variance_big_launch(gpc_ctx* ctx, const DenseArgs& a, int ntw, const double* ws, size_t slot, const double* alpha,
+                              double* scratch, double* v_star)
+{
+    if (a.P == 0 || a.m == 0) return GPC_OK;
+    if (!a.xs0 || !a.xs1) return gpc_fail(ctx, GPC_EINVAL, "the predictive variance needs point-wise X*");
+    VarBigParams g;
+    g.a = a;
+    g.c_exp = (double)(-0.5f) / a.prm.l_sq;
+    g.ws = ws; g.slot = slot; g.ntw = ntw; g.alpha = alpha; g.scratch = scratch; g.v_star = v_star;
+    const size_t lds = sizeof(double) * (size_t)(64 + 5 * DVB_NPAD + 2 * DV_CH * MF_IMG);
+    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_variance_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+    hipLaunchKernelGGL(dense_variance_big_kernel, dim3(dvb_grid(ctx, a.P)), dim3(DV_THREADS), lds, ctx->stream, g);
+    GPC_HIP(ctx, hipGetLastError());
+    return GPC_OK;
+}

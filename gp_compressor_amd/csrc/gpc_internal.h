@@ -129,6 +129,12 @@ int dense_mfma_launch(gpc_ctx* ctx, const DenseArgs& a);
 // predictive variance from the exported factor of the register-tile kernel (dense_variance.hip): V* [P][m]
 int dense_variance_launch(gpc_ctx* ctx, const DenseArgs& a, int nt_max, const double* factor, const double* alpha, double* v_star);
 
+// ... and from the tiled kernel's per-patch factor slots (n <= 1024); scratch: V blocks of the waves in flight
+size_t big_slot_doubles(int ntw);
+size_t dense_variance_big_scratch_doubles(const gpc_ctx* ctx, int ntw);
+int dense_variance_big_launch(gpc_ctx* ctx, const DenseArgs& a, int ntw, const double* ws, size_t slot, const double* alpha,
+                              double* scratch, double* v_star);
+
 // tiled left-looking MFMA kernel: 256 < n <= 1024, factor in a global-memory workspace slot per workgroup (see dense_mfma_big.hip)
 bool dense_big_supported(const DenseArgs& a);
 size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out);

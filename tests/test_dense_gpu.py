@@ -75,6 +75,9 @@ def test_dense_vs_oracle(gp, oracle, kernel_choice, P, n, ny, ragged, seed):
     for dbl in (1, 0):
         p = capi.default_params_dense(want_variance=1, ref_double_noise=dbl)
         f, v, st, al = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
+        if kernel_choice == "dispatch":      # the variance runs on the MFMA pipe at every size: register-tile or tiled fit + its solve kernel
+            nm = int(np.max(np.diff(off)))
+            assert ctx.last_dense_kernel().endswith(" + dense_variance" if nm <= 256 else " + dense_variance_big"), ctx.last_dense_kernel()
         fo, vo, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(ref_double_noise=dbl), off, x0, x1, y, xs0, xs1,
                                                         variance=True, want_alpha=True)
         assert np.array_equal(st, so)
