@@ -333,19 +333,29 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
                 ctx->stream = main_s;
                 if (rc != GPC_OK) return rc;
             }
+            // Class sizes known on the host (the batch came from gpc_project_cloud on this context): launch exactly that many
+            // workgroups.  Otherwise P per class -- the ones beyond the class count leave at once, but each still waits for a CU
+            // with 158 KB of LDS free.
+            const bool hinted = ctx->hint_off == a.off && ctx->hint_P == a.P && !getenv("GPC_NO_HINT");
+            const int c0 = hinted ? ctx->hint_le256 : a.P;
+            const int c1 = hinted ? (nt17 ? ctx->hint_le272 - ctx->hint_le256 : 0) : a.P;
             DenseArgs s = a;
-            if (nt17) {
+            if (nt17 && c1 > 0) {
                 s.n_max = 17 * 16;
                 s.sel = sel1; s.sel_count = counts + 1;
+                s.P = c1;
                 if (fork) ctx->stream = ctx->s_in;
                 rc = dense_mfma_launch(ctx, s);
                 ctx->stream = main_s;
                 if (rc != GPC_OK) return rc;
             }
-            s.n_max = 256;
-            s.sel = sel0; s.sel_count = counts;
-            rc = dense_mfma_launch(ctx, s);            // workgroups beyond the class count leave at once
-            if (rc != GPC_OK) return rc;
+            if (c0 > 0) {
+                s.n_max = 256;
+                s.sel = sel0; s.sel_count = counts;
+                s.P = c0;
+                rc = dense_mfma_launch(ctx, s);
+                if (rc != GPC_OK) return rc;
+            }
             if (fork) {
                 GPC_HIP(ctx, hipEventRecord(ctx->ev[1][5], ctx->s_in));
                 GPC_HIP(ctx, hipEventRecord(ctx->ev[2][5], ctx->s_out));

@@ -40,6 +40,10 @@ struct gpc_ctx {
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev[3][8] = {};
     std::mutex host_mu;                // one host-pointer call at a time per context (they share the arena)
+    // size classes of the last batch gpc_project_cloud produced on this context (its `off` buffer, how many of its P patches have
+    // <= 256 / <= 272 points): lets the dense dispatch size its class launches exactly instead of P workgroups each
+    const int32_t* hint_off = nullptr;
+    int hint_P = 0, hint_le256 = 0, hint_le272 = 0;
     std::mutex mu;
     char err[512] = {0};
     const char* last_dense_kernel = "";

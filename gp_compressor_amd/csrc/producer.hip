@@ -454,12 +454,27 @@ __global__ __launch_bounds__(PC_THREADS) void pc_claim_kernel(PcArgs A)
     }
 }
 
+// nmax[0] = largest patch; nmax[1], nmax[2] = patches of <= 256 / <= 272 points: the size classes of the dense dispatch
+// (gpc_api.hip), which the host reads together with n_max and hands to it so that the class launches are sized exactly
 __global__ __launch_bounds__(PC_THREADS) void pc_nmax_kernel(const int32_t* cnt, int P, int32_t* nmax)
 {
-    int m = 0;
-    for (int i = blockIdx.x * PC_THREADS + threadIdx.x; i < P; i += gridDim.x * PC_THREADS) m = max(m, cnt[i]);
-    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(nmax, m);
+    int m = 0, c0 = 0, c1 = 0;
+    for (int i = blockIdx.x * PC_THREADS + threadIdx.x; i < P; i += gridDim.x * PC_THREADS) {
+        const int n = cnt[i];
+        m = max(m, n);
+        c0 += n <= 256;
+        c1 += n <= 272;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        m = max(m, __shfl_xor(m, o));
+        c0 += __shfl_xor(c0, o);
+        c1 += __shfl_xor(c1, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(nmax, m);
+        atomicAdd(nmax + 1, c0);
+        atomicAdd(nmax + 2, c1);
+    }
 }
 
 // ---- 6: ordered compaction, means, mask ------------------------------------------------------------------------------------
@@ -599,7 +614,7 @@ size_t carve_scratch(Carver& c, Scratch& s, size_t n, size_t pb, size_t prim_byt
     s.leaf_start = c.take<int32_t>(pb + 1);
     s.nbr = c.take<int32_t>(27 * pb);
     s.kcount = c.take<int32_t>(pb);
-    s.cnt = c.take<int32_t>(pb + 2);
+    s.cnt = c.take<int32_t>(pb + 4);      // P + 1 counts | n_max | patches of <= 256 points | patches of <= 272 points
     s.M = c.take<double>(16 * pb);
     s.cen = c.take<double>(3 * pb);
     s.prim = c.take<char>(prim_bytes);
@@ -627,6 +642,7 @@ void gpc_patches_destroy(gpc_patches* o)
     if (!o) return;
     gpc_ctx* ctx = o->ctx;
     if (ctx) (void)hipSetDevice(ctx->device);
+    if (ctx && ctx->hint_off == o->v.off) ctx->hint_off = nullptr;
     if (o->block) (void)hipFree(o->block);
     delete o;
     if (ctx) gpc_ctx_unref(ctx);
@@ -764,7 +780,7 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
     A.rgb_mean = const_cast<double*>(o->v.rgb_means); A.W = const_cast<uint8_t*>(o->v.W);
     A.x0 = const_cast<double*>(o->v.x0); A.x1 = const_cast<double*>(o->v.x1); A.y = const_cast<double*>(o->v.y);
     A.rgb = const_cast<double*>(o->v.rgb); A.src = const_cast<int32_t*>(o->v.src);
-    PC_HIP(hipMemsetAsync(S.cnt, 0, sizeof(int32_t) * (Pz + 2), st));
+    PC_HIP(hipMemsetAsync(S.cnt, 0, sizeof(int32_t) * (Pz + 4), st));
     PC_HIP(hipMemsetAsync(A.W, 0, Pz * m, st));
     hipLaunchKernelGGL(pc_leaves_kernel, dim3(nblk), dim3(PC_THREADS), 0, st, S.k1, n, (int)P, S.leaf_of, S.leaf_key, S.leaf_start);
     PC_HIP(hipGetLastError());
@@ -784,11 +800,13 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
     // 6: the patch batch (the colour planes' pitch is the total, read from off[P] on the device)
     hipLaunchKernelGGL(pc_emit_kernel, dim3(lblk), dim3(PC_THREADS), 0, st, A);
     PC_HIP(hipGetLastError());
-    int32_t total = 0, nmax = 0;
+    int32_t total = 0, nmax[3] = {0, 0, 0};
     PC_HIP(hipMemcpyAsync(&total, A.off + P, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    PC_HIP(hipMemcpyAsync(&nmax, A.nmax, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipMemcpyAsync(nmax, A.nmax, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     PC_HIP(hipStreamSynchronize(st));
-    o->v.P = P; o->v.n_total = total; o->v.n_max = nmax;
+    o->v.P = P; o->v.n_total = total; o->v.n_max = nmax[0];
+    // the size classes of this batch, for the dense dispatch (keyed by the batch's own `off` buffer, which lives as long as the object)
+    ctx->hint_off = o->v.off; ctx->hint_P = P; ctx->hint_le256 = nmax[1]; ctx->hint_le272 = nmax[2];
     *out = o;
     return GPC_OK;
 }
