@@ -50,7 +50,21 @@ struct BigParams {
     int32_t* irls_iters;          // [P] solves performed, or nullptr
     double* irls_fhat;            // [n_total] latent mode at the training points, or nullptr
 };
-#define BG_NPH 6
+#define BG_NPH 12
+// -DBG_SUBSTAMPS (diagnostic build, tools/stamp_big.py): the factorisation step split into 5 diagonal-block tiles, 6 update loops,
+// 7 waiting for an L^-1 (workers) or a hand-over (wave 0), 8 TRSMs (workers) or the chain (wave 0), 9 end-of-step barrier
+#ifdef BG_SUBSTAMPS
+#define BG_SUB(ph)                                                                                                   \
+    do {                                                                                                             \
+        if (g.stamps) {                                                                                              \
+            const unsigned long long t_now_ = __builtin_amdgcn_s_memtime();                                          \
+            sub_acc_[(ph) - 5] += t_now_ - t_sub_;                                                                   \
+            t_sub_ = t_now_;                                                                                         \
+        }                                                                                                            \
+    } while (0)
+#else
+#define BG_SUB(ph) do { } while (0)
+#endif
 #define BG_STAMP(ph)                                                                                                 \
     do {                                                                                                             \
         if (g.stamps) {                                                                                              \
@@ -61,9 +75,14 @@ struct BigParams {
     } while (0)
 
 // LDS carve (doubles), for NPAD padded points and WAVES waves per workgroup:
-//   exp table 64 | x0, x1 2 NPAD | z, w, alpha 9 NPAD | rsqrt row 32 | flags 8 | 2 L^-1 images 512 | L_(k+1)k image 256 |
-//   predict accumulation buffer 4 x 256 (ds_add_f64 targets; during the factorisation: hand-over of the diagonal-block tiles)
-__host__ __device__ constexpr int bg_lds_doubles(int npad, int waves) { return 64 + 11 * npad + 32 + 8 + 512 + 256 + 1024 + 0 * waves; }
+//   exp table 64 | x0, x1 2 NPAD | z, w, alpha 3 NYP NPAD (NYP = 1: depth plane only, 3: depth + colour, or the IRLS vectors) | rsqrt row 32 | flags 16 | C L^-1 images | C (C-1)/2 images of the strictly
+//   lower tiles of the step's diagonal block | hand-over of the C (C+1)/2 diagonal-block tiles (after the factorisation: the
+//   predict accumulation buffer 4 x 256, ds_add_f64 targets)
+__host__ __device__ constexpr int bg_hand_doubles(int c) { return c * (c + 1) / 2 * 256 > 1024 ? c * (c + 1) / 2 * 256 : 1024; }
+__host__ __device__ constexpr int bg_lds_doubles(int npad, int c, int nyp)
+{
+    return 64 + (2 + 3 * nyp) * npad + 32 + 16 + c * 256 + (c * (c - 1) / 2) * 256 + bg_hand_doubles(c);
+}
 
 __device__ static __forceinline__ d4 bg_mfma4_neg(d4 a, d4 b, d4 acc)
 {
@@ -83,14 +102,18 @@ __device__ static __forceinline__ d4 bg_mfma4_neg(d4 a, d4 b, d4 acc)
 // eigenvalues >= 1 however far the weights spread; the tile TRSMs here multiply by explicit 16 x 16 inverses, which is only
 // as accurate as the tiles are well conditioned): u = B^-1 W^1/2 t, a = W^1/2 u -- the same Newton iterate.  Definition and stopping rule: oracle/gpc_oracle.c (orc_dense_irls_fit).  ny == 1; the unused colour planes of
 // the solve vectors hold f, d, t and the labels.
-template <int BG_WAVES, int BG_NPAD, int BG_RMAX, int BG_OCC, bool BG_IRLS = false>
+template <int BG_WAVES, int BG_NPAD, int BG_RMAX, int BG_OCC, bool BG_IRLS = false, int BG_C = 4, int BG_NYP = 3>
 __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigParams g)
 {
     static_assert(BG_RMAX == 1 || BG_RMAX == 2, "one copy of the update loop per possible row count");
+    static_assert(BG_C == 4, "tile columns per step (the index maps of the diagonal block assume 4)");
     constexpr int BG_THREADS = BG_WAVES * 64;
-    constexpr int B_PX0 = 64, B_PX1 = B_PX0 + BG_NPAD, B_ZV = B_PX1 + BG_NPAD, B_WV = B_ZV + 3 * BG_NPAD, B_AV = B_WV + 3 * BG_NPAD,
-                  B_RS = B_AV + 3 * BG_NPAD, B_FLAG = B_RS + 32, B_LINV = B_FLAG + 8, B_L10 = B_LINV + 512, B_RED = B_L10 + 256;
-    static_assert(B_RED + 1024 == bg_lds_doubles(BG_NPAD, BG_WAVES), "LDS carve");
+    constexpr int NDT = BG_C * (BG_C + 1) / 2;           // tiles of the step's diagonal block
+    static_assert(BG_NYP == 3 || (BG_NYP == 1 && !BG_IRLS), "planes of the solve vectors (the IRLS loop keeps its vectors in planes 1, 2)");
+    constexpr int B_PX0 = 64, B_PX1 = B_PX0 + BG_NPAD, B_ZV = B_PX1 + BG_NPAD, B_WV = B_ZV + BG_NYP * BG_NPAD, B_AV = B_WV + BG_NYP * BG_NPAD,
+                  B_RS = B_AV + BG_NYP * BG_NPAD, B_FLAG = B_RS + 32, B_LINV = B_FLAG + 16, B_LBLK = B_LINV + BG_C * 256,
+                  B_RED = B_LBLK + (BG_C * (BG_C - 1) / 2) * 256;
+    static_assert(B_RED + bg_hand_doubles(BG_C) == bg_lds_doubles(BG_NPAD, BG_C, BG_NYP), "LDS carve");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     double* T = lds;
@@ -102,10 +125,10 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
     double* rsbuf = lds + B_RS;
     int* flag = reinterpret_cast<int*>(lds + B_FLAG);   // ints [0] bad, [1] ready
     int* ready = flag + 1;
-    double* LinvC = lds + B_LINV;      // [2][256]
-    double* L10 = lds + B_L10;
+    double* LinvC = lds + B_LINV;      // [BG_C][256]
+    double* Lblk = lds + B_LBLK;       // image of L_(k+i)(k+c), c < i, at (i (i-1)/2 + c) * 256
     double* red = lds + B_RED;
-    double* Hand = red;                // 3 x 256: hand-over of the diagonal-block tiles to wave 0 (the reduction buffer is idle then)
+    double* Hand = red;                // NDT x 256: hand-over of the diagonal-block tiles to wave 0 (the reduction buffer is idle then)
     // IRLS (ny == 1): planes 1, 2 of the solve vectors are free
     [[maybe_unused]] double* fv = zv + BG_NPAD;         // latent f
     [[maybe_unused]] double* dv = zv + 2 * BG_NPAD;     // W^-1/2
@@ -113,11 +136,10 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
     [[maybe_unused]] double* tv = wv + BG_NPAD;         // working targets
     [[maybe_unused]] double* yl = wv + 2 * BG_NPAD;     // labels
     [[maybe_unused]] unsigned long long* delta_bits = reinterpret_cast<unsigned long long*>(lds + B_FLAG + 4);   // max |f_new - f| of the step, as bits
-    int* h0 = flag + 2;                // k + 1 once tile (k, k) of the step is handed over
-    int* h1 = flag + 3;                // k + 1 once tiles (k+1, k), (k+1, k+1) are handed over
+    int* hflag = flag + 16;            // [NDT]: step + 1 once diagonal-block tile d of the step is handed over
     const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
     const unsigned ready_addr = lds0 + (unsigned)(B_FLAG * 8 + 4);     // highest tile column whose L_kk^-1 is published
-    const unsigned h0_addr = lds0 + (unsigned)(B_FLAG * 8 + 8), h1_addr = lds0 + (unsigned)(B_FLAG * 8 + 12);
+    const unsigned hf_addr = lds0 + (unsigned)(B_FLAG * 8 + 64);
 
     const DenseArgs& A = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -150,12 +172,13 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         }
         const int nt = __builtin_amdgcn_readfirstlane((n + MF_TS - 1) / MF_TS);
         unsigned long long t_prev_ = g.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+        [[maybe_unused]] unsigned long long t_sub_ = t_prev_;
+        [[maybe_unused]] unsigned long long sub_acc_[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
         unsigned long long* ext_bits = reinterpret_cast<unsigned long long*>(lds + B_FLAG + 3);   // max-norm extent, as bits
+        if (tid < NDT) hflag[tid] = 0;
         if (tid == 0) {
             flag[0] = 0;
             flag[1] = -1;
-            flag[2] = 0;
-            flag[3] = 0;
             *ext_bits = 0ull;
         }
         __syncthreads();
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
             px0[i] = live ? q0 : 0.0;
             px1[i] = live ? q1 : 0.0;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { wv[c * BG_NPAD + i] = 0.0; av[c * BG_NPAD + i] = 0.0; }   // av: no stale LDS beyond the solved rows
+            for (int c = 0; c < BG_NYP; ++c) { wv[c * BG_NPAD + i] = 0.0; av[c * BG_NPAD + i] = 0.0; }   // av: no stale LDS beyond the solved rows
         }
 #pragma unroll
         for (int o_ = 32; o_ > 0; o_ >>= 1) dev = __builtin_fmax(dev, __shfl_xor(dev, o_, 64));
@@ -262,166 +285,247 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                 wv[i] = 0.0;
             }
             if (badw) flag[4] = 1;
+            if (tid < NDT) hflag[tid] = 0;
             if (tid == 0) {
                 flag[0] = 0;
                 flag[1] = -1;
-                flag[2] = 0;
-                flag[3] = 0;
                 *delta_bits = 0ull;
             }
             __syncthreads();
             nan_w = flag[4] != 0;
             if (nan_w) break;
         }
-        for (int k = 0; k < nt; k += 2) {
-            const bool has2 = k + 1 < nt;
-            const int k1 = has2 ? k + 1 : k;                               // second column of the pair (== k when absent)
-            const double* rowk = Lt + ((size_t)k * ntw) * MF_IMG;          // L_kj, j < k
-            const double* rowk1 = Lt + ((size_t)k1 * ntw) * MF_IMG;
-            // Rows k .. nt are dealt round-robin to the WORKER waves 1 .. W-1 (row k + q -> wave 1 + q % (W-1)).  Rows k and
-            // k+1 are the diagonal block: their owners update them like any other row (first pass), then hand the tiles
-            // (k,k), (k+1,k), (k+1,k+1) to wave 0 through LDS instead of solving them.  Wave 0 runs nothing but the serial
-            // chain factor (k,k) -> TRSM (k+1,k) -> update, factor (k+1,k+1), concurrently with the workers' later passes.
-            // (With the diagonal-block updates on wave 0 itself it was the critical path: 3 tile updates per j on one wave.)
+        int step = 0;
+        for (int k = 0; k < nt; k += BG_C, ++step) {
+            const int nc = min(BG_C, nt - k);                              // tile columns of this step
             constexpr int NWK = BG_WAVES - 1;
+            // ---- the diagonal block first: its nc (nc + 1) / 2 tiles, one per wave (tile 0 = (k, k) on wave 0 itself) ----
+            // Tile d = i (i + 1) / 2 + c is T_(k+i)(k+c) = A - sum_{j<k} L_(k+i)j L_(k+c)j^T; wave 0 needs them in the order of d.
+            // Nothing else is live here, so eight (j) operand pairs are in flight per wave.
+            d4 Dmine = d4{0.0, 0.0, 0.0, 0.0};
+            BG_SUB(9);
+            {
+                constexpr int DPW = (NDT - 1 + NWK - 1) / NWK;             // tiles per worker, at most (wave 0: tile 0 only)
+                static_assert(DPW >= 1 && DPW <= 3, "diagonal-block tiles per worker");
+                int dd[DPW], nd = 0;
+                const double *ra[DPW], *rb[DPW];
+                d4 dacc[DPW];
+#pragma unroll
+                for (int t = 0; t < DPW; ++t) {
+                    const int d = (wave == 0) ? (t == 0 ? 0 : NDT) : wave + NWK * t;
+                    const int bi = d >= 6 ? 3 : d >= 3 ? 2 : d >= 1 ? 1 : 0;
+                    const bool on = d < NDT && bi < nc;                    // (monotone in t: the valid tiles come first)
+                    const int dv_ = on ? d : 0, bi_ = on ? bi : 0, bc_ = dv_ - bi_ * (bi_ + 1) / 2;
+                    dd[t] = dv_;
+                    nd += on ? 1 : 0;
+                    ra[t] = Lt + ((size_t)(k + bc_) * ntw) * MF_IMG;
+                    rb[t] = Lt + ((size_t)(k + bi_) * ntw) * MF_IMG;
+                }
+                const int kl = k - 1;
+                d4 ga[2][4], gb[2][4];
+#define BG_DG_LOAD(st, j0, NPC)                                                                                      \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int jq_ = 0; jq_ < 4 / NPC; ++jq_) {                                                  \
+            const int jj_ = min((j0) + jq_, kl);                                                                     \
+            _Pragma("unroll") for (int t = 0; t < NPC; ++t) {                                                        \
+                ga[st][jq_ * NPC + t] = mf_img_load(ra[t] + (size_t)jj_ * MF_IMG, lane);                             \
+                gb[st][jq_ * NPC + t] = mf_img_load(rb[t] + (size_t)jj_ * MF_IMG, lane);                             \
+            }                                                                                                        \
+        }                                                                                                            \
+    } while (0)
+#define BG_DG_USE(st, NPC)                                                                                           \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int jq_ = 0; jq_ < 4 / NPC; ++jq_)                                                    \
+            _Pragma("unroll") for (int t = 0; t < NPC; ++t)                                                          \
+                dacc[t] = bg_mfma4_neg(ga[st][jq_ * NPC + t], gb[st][jq_ * NPC + t], dacc[t]);                       \
+    } while (0)
+                // NPC tiles side by side, 4 / NPC values of j per operand stage, two stages; k is a multiple of BG_C = 4.  The
+                // first loads are issued before the Gram tiles are evaluated.
+#define BG_DG_TILES(NPC)                                                                                             \
+    do {                                                                                                             \
+        constexpr int JC_ = 4 / NPC;                                                                                 \
+        if (k > 0) BG_DG_LOAD(0, 0, NPC);                                                                            \
+        _Pragma("unroll") for (int t = 0; t < NPC; ++t) {                                                            \
+            const int bi_ = dd[t] >= 6 ? 3 : dd[t] >= 3 ? 2 : dd[t] >= 1 ? 1 : 0;                                    \
+            BG_INIT_TILE(dacc[t], k + bi_, k + dd[t] - bi_ * (bi_ + 1) / 2);                                         \
+        }                                                                                                            \
+        for (int j = 0; j < k; j += 2 * JC_) {                                                                       \
+            BG_DG_LOAD(1, j + JC_, NPC);                                                                             \
+            BG_DG_USE(0, NPC);                                                                                       \
+            BG_DG_LOAD(0, j + 2 * JC_, NPC);                                                                         \
+            if (j + JC_ < k) BG_DG_USE(1, NPC);                                                                      \
+        }                                                                                                            \
+    } while (0)
+#pragma unroll
+                for (int t = 0; t < DPW; ++t) dacc[t] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int q_ = 0; q_ < 4; ++q_) ga[st][q_] = gb[st][q_] = d4{0.0, 0.0, 0.0, 0.0};
+                if (nd == 1) BG_DG_TILES(1);
+                if constexpr (DPW >= 2) { if (nd == 2) BG_DG_TILES(2); }
+                if constexpr (DPW >= 3) { if (nd == 3) BG_DG_TILES(3); }
+                if (wave == 0) {
+                    Dmine = dacc[0];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < DPW; ++t) {
+                        if (t < nd) {
+                            *reinterpret_cast<d4*>(Hand + dd[t] * 256 + lane * 4) = dacc[t];
+                            mf_publish(hflag + dd[t], step + 1);
+                        }
+                    }
+                }
+            }
+            BG_SUB(5);
             if (wave == 0) {
-                timed_out |= !mf_wait_ge(h0_addr, k + 1);
-                const d4 D00 = *reinterpret_cast<const d4*>(Hand + lane * 4);
-                bool ok = mf_diag_factor(D00, rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol);
+                // the serial chain of the block: factor (k,k); then row by row  L_ic = (T_ic - sum_{c2<c} L_ic2 L_cc2^T) L_cc^-T,
+                // T_ii -= sum_c L_ic L_ic^T, factor -- every L^-1 published as it appears, the block's tiles left in LDS for the workers
+                bool ok = mf_diag_factor(Dmine, rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (g.export_factor) mf_img_store(LinvG + (size_t)k * MF_IMG, lane, mf_img_load(LinvC, lane));
                 if (!ok && lane == 0) flag[0] = 1;
-                if (ok && has2) {
-                    mf_publish(ready, k);                                  // L_kk^-1 (the workers start their first TRSM)
-                    timed_out |= !mf_wait_ge(h1_addr, k + 1);
-                    const d4 D10 = *reinterpret_cast<const d4*>(Hand + 256 + lane * 4);
-                    d4 D11 = *reinterpret_cast<const d4*>(Hand + 512 + lane * 4);
-                    const d4 lv = mf_img_load(LinvC, lane);
-                    const d4 l10 = BG_TRSM(lv, D10);                       // operand image of L_(k+1)k
-                    mf_img_store(Lt + ((size_t)(k + 1) * ntw + k) * MF_IMG, lane, l10);
-                    mf_img_store(L10, lane, l10);
-                    D11 = bg_mfma4_neg(l10, l10, D11);
-                    ok = mf_diag_factor(D11, rsbuf, LinvC + 256, LinvTg + (size_t)(k + 1) * MF_IMG, g.pivot_tol);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    if (g.export_factor) mf_img_store(LinvG + (size_t)(k + 1) * MF_IMG, lane, mf_img_load(LinvC + 256, lane));
-                    if (!ok && lane == 0) flag[0] = 1;
+                if (ok) mf_publish(ready, k);
+#pragma unroll
+                for (int i = 1; i < BG_C; ++i) {
+                    if (ok && i < nc) {
+                        d4 Lrow[BG_C - 1];
+#pragma unroll
+                        for (int c = 0; c < i; ++c) {
+                            // (LDS addresses from an opaque lane id: hoisted out of the step loop they end up in scratch)
+                            const int ln = mf_opaque(lane);
+                            BG_SUB(8);
+                            timed_out |= !mf_wait_ge(hf_addr + 4u * (unsigned)(i * (i + 1) / 2 + c), step + 1);
+                            BG_SUB(7);
+                            d4 Tt = *reinterpret_cast<const d4*>(Hand + (i * (i + 1) / 2 + c) * 256 + ln * 4);
+#pragma unroll
+                            for (int c2 = 0; c2 < c; ++c2)
+                                Tt = bg_mfma4_neg(mf_img_load(Lblk + (c * (c - 1) / 2 + c2) * 256, ln), Lrow[c2], Tt);
+                            const d4 lvc = mf_img_load(LinvC + c * 256, ln);
+                            Lrow[c] = BG_TRSM(lvc, Tt);                     // operand image of L_(k+i)(k+c)
+                            mf_img_store(Lt + ((size_t)(k + i) * ntw + k + c) * MF_IMG, ln, Lrow[c]);
+                            mf_img_store(Lblk + (i * (i - 1) / 2 + c) * 256, ln, Lrow[c]);
+                        }
+                        BG_SUB(8);
+                        timed_out |= !mf_wait_ge(hf_addr + 4u * (unsigned)(i * (i + 1) / 2 + i), step + 1);
+                        BG_SUB(7);
+                        d4 Dii = *reinterpret_cast<const d4*>(Hand + (i * (i + 1) / 2 + i) * 256 + mf_opaque(lane) * 4);
+#pragma unroll
+                        for (int c = 0; c < i; ++c) Dii = bg_mfma4_neg(Lrow[c], Lrow[c], Dii);
+                        ok = mf_diag_factor(Dii, rsbuf, LinvC + i * 256, LinvTg + (size_t)(k + i) * MF_IMG, g.pivot_tol);
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                                if (g.export_factor) mf_img_store(LinvG + (size_t)(k + i) * MF_IMG, lane, mf_img_load(LinvC + i * 256, mf_opaque(lane)));
+                        if (!ok && lane == 0) flag[0] = 1;
+                        if (ok) mf_publish(ready, k + i);
+                    }
                 }
-                mf_publish(ready, k1);
+                mf_publish(ready, k + nc - 1);     // (also on failure: the workers leave their waits and see the flag)
+                BG_SUB(8);
             } else {
-                const int q0 = wave - 1;                                   // first row of this worker: k + q0
-                const int rows_tot = nt - k + 1;                           // rows k .. nt
+                // Rows k + nc .. nt (the last one carries the right-hand sides) are dealt round-robin to the workers, the wave that
+                // shares its SIMD with wave 0 first, the ones with two diagonal-block tiles last.
+                const int q0 = (NWK == 7) ? ((wave == 4) ? 0 : (wave >= 5) ? 8 - wave : 7 - wave) : NWK - wave;
+                const int rows_tot = nt - (k + nc) + 1;
                 const int rows_w = (rows_tot - 1 - q0 >= 0) ? (rows_tot - 1 - q0) / NWK + 1 : 0;
                 bool stop = false;
-                for (int p0 = 0; (p0 < rows_w || p0 == 0) && !stop; p0 += BG_RMAX) {
+                for (int p0 = 0; p0 < rows_w && !stop; p0 += BG_RMAX) {
                     const int np = min(BG_RMAX, rows_w - p0);
-                    d4 acc0[BG_RMAX], acc1[BG_RMAX];
+                    d4 acc[BG_C][BG_RMAX];
                     int rr[BG_RMAX];
+                    // two operand stages: while one feeds the 4 BG_C NPC MFMAs of a j, the loads of the next j are in flight.
+                    // The loads are UNCONDITIONAL (column index clamped into the block, j clamped to k-1: redundant re-reads):
+                    // under runtime conditions hipcc cannot count the outstanding loads and falls back to s_waitcnt vmcnt(0)
+                    // in every iteration, i.e. no prefetch at all.  k is even: no tail.  The first stage is requested before the
+                    // Gram tiles are evaluated (the factor comes from HBM / Infinity Cache, thousands of cycles away).
+                    const double* rc_[BG_C];
+#pragma unroll
+                    for (int c = 0; c < BG_C; ++c) rc_[c] = Lt + ((size_t)(k + min(c, nc - 1)) * ntw) * MF_IMG;
+                    const double* rw_[BG_RMAX];
 #pragma unroll
                     for (int t = 0; t < BG_RMAX; ++t) {
-                        rr[t] = k + q0 + NWK * (p0 + t);
-                        acc0[t] = d4{0.0, 0.0, 0.0, 0.0};
-                        acc1[t] = d4{0.0, 0.0, 0.0, 0.0};
-                        if (t < np) {
-                            BG_INIT_TILE(acc0[t], rr[t], k);
-                            if (has2 && rr[t] != k) BG_INIT_TILE(acc1[t], rr[t], k + 1);     // (k, k+1) is above the diagonal
-                        }
+                        rr[t] = k + nc + q0 + NWK * (p0 + min(t, np - 1));      // (t >= np: a copy of the last row, never stored)
+                        rw_[t] = Lt + ((size_t)rr[t] * ntw) * MF_IMG;
                     }
-                    if (np > 0 && k > 0) {
-                        // three operand stages rotate through the loop (unrolled by 3): while stage s feeds the MFMAs, the
-                        // loads of the next two j are in flight -- the factor tiles come from HBM / Infinity Cache
-                        d4 sa0[3], sa1[3], sb[3][BG_RMAX];
-                        // NPC (rows in the pass) is a compile-time constant inside each copy of the loop and the loads are
-                        // UNCONDITIONAL (index clamped to k-1, a redundant re-read at the tail): with loads under runtime
-                        // conditions hipcc cannot count the outstanding ones and falls back to s_waitcnt vmcnt(0) in every
-                        // iteration, i.e. no prefetch at all
+                    d4 sa[2][BG_C], sb[2][BG_RMAX];
+                    const int kl = k - 1;
 #define BG_LOAD_STAGE(st, jj, NPC)                                                                                   \
     do {                                                                                                             \
-        sa0[st] = mf_img_load(rowk + (size_t)(jj) * MF_IMG, lane);                                                   \
-        sa1[st] = mf_img_load(rowk1 + (size_t)(jj) * MF_IMG, lane);                                                  \
-        _Pragma("unroll") for (int t = 0; t < NPC; ++t)                                                              \
-            sb[st][t] = mf_img_load(Lt + ((size_t)rr[t] * ntw + (jj)) * MF_IMG, lane);                               \
+        _Pragma("unroll") for (int c = 0; c < BG_C; ++c) sa[st][c] = mf_img_load(rc_[c] + (size_t)(jj) * MF_IMG, lane); \
+        _Pragma("unroll") for (int t = 0; t < NPC; ++t) sb[st][t] = mf_img_load(rw_[t] + (size_t)(jj) * MF_IMG, lane);  \
     } while (0)
 #define BG_USE_STAGE(st, NPC)                                                                                        \
     do {                                                                                                             \
-        _Pragma("unroll") for (int t = 0; t < NPC; ++t) {                                                            \
-            acc0[t] = bg_mfma4_neg(sa0[st], sb[st][t], acc0[t]);                                                     \
-            if (has2 && rr[t] != k) acc1[t] = bg_mfma4_neg(sa1[st], sb[st][t], acc1[t]);                             \
-        }                                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < NPC; ++t)                                                              \
+            _Pragma("unroll") for (int c = 0; c < BG_C; ++c) acc[c][t] = bg_mfma4_neg(sa[st][c], sb[st][t], acc[c][t]); \
     } while (0)
 #define BG_UPDATE_LOOP(NPC)                                                                                          \
     do {                                                                                                             \
-        const int kl = k - 1;                                                                                        \
-        BG_LOAD_STAGE(0, 0, NPC);                                                                                    \
-        BG_LOAD_STAGE(1, min(1, kl), NPC);                                                                           \
-        for (int j = 0; j < k; j += 3) {                                                                             \
-            BG_LOAD_STAGE(2, min(j + 2, kl), NPC);                                                                   \
+        if (k > 0) BG_LOAD_STAGE(0, 0, NPC);                                                                         \
+        _Pragma("unroll") for (int t = 0; t < NPC; ++t)                                                              \
+            _Pragma("unroll") for (int c = 0; c < BG_C; ++c)                                                         \
+                if (c < nc) BG_INIT_TILE(acc[c][t], rr[t], k + c);                                                   \
+        for (int j = 0; j < k; j += 2) {                                                                             \
+            BG_LOAD_STAGE(1, j + 1, NPC);                                                                            \
             BG_USE_STAGE(0, NPC);                                                                                    \
-            BG_LOAD_STAGE(0, min(j + 3, kl), NPC);                                                                   \
-            if (j + 1 < k) BG_USE_STAGE(1, NPC);                                                                     \
-            BG_LOAD_STAGE(1, min(j + 4, kl), NPC);                                                                   \
-            if (j + 2 < k) BG_USE_STAGE(2, NPC);                                                                     \
+            BG_LOAD_STAGE(0, min(j + 2, kl), NPC);                                                                   \
+            BG_USE_STAGE(1, NPC);                                                                                    \
         }                                                                                                            \
     } while (0)
 #pragma unroll
-                        for (int st = 0; st < 3; ++st) {
-                            sa0[st] = d4{0.0, 0.0, 0.0, 0.0};
-                            sa1[st] = sa0[st];
+                    for (int t = 0; t < BG_RMAX; ++t)
 #pragma unroll
-                            for (int t = 0; t < BG_RMAX; ++t) sb[st][t] = sa0[st];
-                        }
-                        if constexpr (BG_RMAX == 2) {
-                            if (np == 2) BG_UPDATE_LOOP(2);
-                            else BG_UPDATE_LOOP(1);
-                        } else {
-                            BG_UPDATE_LOOP(1);
-                        }
-                    }
-                    // diagonal-block rows go to wave 0 (first pass only: q = 0 -> wave 1, q = 1 -> wave 2, both t = 0)
-                    if (p0 == 0 && np > 0 && rr[0] == k) {
-                        *reinterpret_cast<d4*>(Hand + lane * 4) = acc0[0];
-                        mf_publish(h0, k + 1);
-                    }
-                    if (p0 == 0 && np > 0 && has2 && rr[0] == k + 1) {
-                        *reinterpret_cast<d4*>(Hand + 256 + lane * 4) = acc0[0];
-                        *reinterpret_cast<d4*>(Hand + 512 + lane * 4) = acc1[0];
-                        mf_publish(h1, k + 1);
-                    }
-                    // L_rk = T_rk L_kk^-T;  T_r(k+1) -= L_rk L_(k+1)k^T;  L_r(k+1) = T_r(k+1) L_(k+1)(k+1)^-T
-                    timed_out |= !mf_wait_ge(ready_addr, k);
-                    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { stop = true; continue; }
-                    if (np > 0) {
-                        const d4 lv0 = mf_img_load(LinvC, lane);
+                        for (int c = 0; c < BG_C; ++c) acc[c][t] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int t = 0; t < BG_RMAX; ++t) {
-                            if (t < np && rr[t] > k1) {
-                                acc0[t] = BG_TRSM(lv0, acc0[t]);
-                                mf_img_store(Lt + ((size_t)rr[t] * ntw + k) * MF_IMG, lane, acc0[t]);
-                            }
-                        }
-                    }
-                    if (has2) {
-                        timed_out |= !mf_wait_ge(ready_addr, k + 1);
-                        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { stop = true; continue; }
-                        if (np > 0) {
-                            const d4 lv1 = mf_img_load(LinvC + 256, lane);
-                            const d4 a10 = mf_img_load(L10, lane);
+                    for (int st = 0; st < 2; ++st) {
 #pragma unroll
-                            for (int t = 0; t < BG_RMAX; ++t) {
-                                if (t < np && rr[t] > k1) {
-                                    acc1[t] = bg_mfma4_neg(a10, acc0[t], acc1[t]);
-                                    mf_img_store(Lt + ((size_t)rr[t] * ntw + k + 1) * MF_IMG, lane, BG_TRSM(lv1, acc1[t]));
+                        for (int c = 0; c < BG_C; ++c) sa[st][c] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int t = 0; t < BG_RMAX; ++t) sb[st][t] = d4{0.0, 0.0, 0.0, 0.0};
+                    }
+                    if constexpr (BG_RMAX == 2) {
+                        if (np == 2) BG_UPDATE_LOOP(2);
+                        else BG_UPDATE_LOOP(1);
+                    } else {
+                        BG_UPDATE_LOOP(1);
+                    }
+                    BG_SUB(6);
+                    // column by column as the inverses appear:  T_r(k+c) -= sum_{c2<c} L_r(k+c2) L_(k+c)(k+c2)^T,  L_r(k+c) = T L_cc^-T
+#pragma unroll
+                    for (int c = 0; c < BG_C; ++c) {
+                        if (c < nc && !stop) {
+                            timed_out |= !mf_wait_ge(ready_addr, k + c);
+                            BG_SUB(7);
+                            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                stop = true;
+                            } else {
+                                const int ln = mf_opaque(lane);     // (see wave 0)
+                                const d4 lv = mf_img_load(LinvC + c * 256, ln);
+#pragma unroll
+                                for (int t = 0; t < BG_RMAX; ++t) {
+                                    if (t < np) {
+#pragma unroll
+                                        for (int c2 = 0; c2 < c; ++c2)
+                                            acc[c][t] = bg_mfma4_neg(mf_img_load(Lblk + (c * (c - 1) / 2 + c2) * 256, ln), acc[c2][t], acc[c][t]);
+                                        acc[c][t] = BG_TRSM(lv, acc[c][t]);
+                                        mf_img_store(Lt + ((size_t)rr[t] * ntw + k + c) * MF_IMG, ln, acc[c][t]);
+                                    }
                                 }
+                                BG_SUB(8);
                             }
                         }
                     }
                 }
             }
-            __syncthreads();   // the column pair is in the workspace; the L^-1 images may be overwritten
+            __syncthreads();   // the column block is in the workspace; the L^-1 images and the hand-over tiles may be overwritten
             bad = flag[0] != 0;
             if (bad) break;
         }
         if (bad) break;
         BG_STAMP(1);
+#ifdef BG_SUBSTAMPS
+        if (g.stamps && lane == 0)
+            for (int q_ = 0; q_ < 5; ++q_) atomicAdd(g.stamps + (5 + q_) * 8 + wave, sub_acc_[q_]);
+#endif
         // z_k^T = tile (nt, k): lane l, slot s = z_(l&15)[16 k + (l>>4) + 4 s]
         for (int k = wave; k < nt; k += BG_WAVES) {
             const d4 zt = mf_img_load(Lt + ((size_t)nt * ntw + k) * MF_IMG, lane);
@@ -661,16 +765,17 @@ size_t big_slot_doubles(int ntw) { return ((size_t)(ntw + 1) * ntw + 2 * (size_t
 // <4 waves, 256 points, 2 rows per pass, 2 waves/SIMD>: 37 KB of LDS, two workgroups = two patches per CU: the cross-check
 // shape for n <= 256 (GPC_FORCE_BIG=1).  (A 1-row, <= 128-VGPR variant with FOUR patches per CU was measured slower, 2.45 M
 // against 2.68 M patches/s on C2: each workgroup runs 2.2x longer -- the shape is bound by the factor stream, not by latency.)
-static void big_shape(const DenseArgs& a, int* waves, int* npad, int* per_cu)
+static void big_shape(const DenseArgs& a, bool irls, int* waves, int* npad, int* per_cu)
 {
     if (a.n_max <= 256) { *waves = 4; *npad = 256; *per_cu = 2; }
+    else if (a.n_max <= 512 && a.ny == 1 && !irls && !getenv("GPC_BIG_NO_W4")) { *waves = 4; *npad = 512; *per_cu = 2; }
     else { *waves = 8; *npad = 1024; *per_cu = 1; }
 }
 
 size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
 {
     int waves, npad, per_cu;
-    big_shape(a, &waves, &npad, &per_cu);
+    big_shape(a, false, &waves, &npad, &per_cu);
     const int ntw = (a.n_max + MF_TS - 1) / MF_TS;
     int cap = ctx->num_cus * per_cu;
     if (const char* e = getenv("GPC_BIG_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;   // diagnostic: resident-workgroup experiments
@@ -683,14 +788,14 @@ size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
     return sizeof(double) * big_slot_doubles(ntw) * slots + extra;
 }
 
-template <int W, int NP, int RM, int OC, bool IRLS = false>
+template <int W, int NP, int RM, int OC, bool IRLS = false, int NYP = 3>
 static int big_launch_t(gpc_ctx* ctx, const BigParams& g, int grid)
 {
-    const size_t lds = sizeof(double) * (size_t)bg_lds_doubles(NP, W);
+    const size_t lds = sizeof(double) * (size_t)bg_lds_doubles(NP, 4, NYP);
     // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
-    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_big_kernel<W, NP, RM, OC, IRLS>),
+    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_big_kernel<W, NP, RM, OC, IRLS, 4, NYP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((dense_big_kernel<W, NP, RM, OC, IRLS>), dim3(grid), dim3(W * 64), lds, ctx->stream, g);
+    hipLaunchKernelGGL((dense_big_kernel<W, NP, RM, OC, IRLS, 4, NYP>), dim3(grid), dim3(W * 64), lds, ctx->stream, g);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;
 }
@@ -714,7 +819,7 @@ int dense_irls_launch(gpc_ctx* ctx, const DenseArgs& a, const IrlsArgs& ir, int 
     g.irls_iters = ir.iters;
     g.irls_fhat = ir.fhat;
     int waves, npad, per_cu;
-    big_shape(a, &waves, &npad, &per_cu);
+    big_shape(a, true, &waves, &npad, &per_cu);
     if (waves == 4) {
         ctx->last_dense_kernel = "dense_mfma_big_w4_irls";
         return big_launch_t<4, 256, 2, 2, true>(ctx, g, grid);
@@ -745,7 +850,7 @@ int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
     g.ntw = (a.n_max + MF_TS - 1) / MF_TS;
     g.slot = big_slot_doubles(g.ntw);
     int waves, npad, per_cu;
-    big_shape(a, &waves, &npad, &per_cu);
+    big_shape(a, false, &waves, &npad, &per_cu);
     g.stamps = nullptr;
     g.irls_model = 0; g.irls_max_iter = 0; g.irls_tol = 0.0; g.irls_f_init = 0.0; g.irls_iters = nullptr; g.irls_fhat = nullptr;
     struct StampDump {
@@ -757,9 +862,10 @@ int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
             (void)hipFree(d);
-            static const char* names[BG_NPH] = {"load", "factorisation", "z gather", "backward", "predict", ""};
+            static const char* names[BG_NPH] = {"load", "factorisation", "z gather", "backward", "predict", "- diag tiles", "- update",
+                                                "- wait", "- trsm/chain", "- barrier", "", ""};
             fprintf(stderr, "[GPC_BIG_STAMPS] mean s_memtime ticks per patch, by wave\n");
-            for (int q = 0; q < 5; ++q) {
+            for (int q = 0; q < 10; ++q) {
                 fprintf(stderr, "%-14s", names[q]);
                 for (int w = 0; w < waves; ++w) fprintf(stderr, " %8.0f", (double)h[q * 8 + w] / P);
                 fprintf(stderr, "\n");
@@ -771,12 +877,18 @@ int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
         GPC_HIP(ctx, hipMemsetAsync(g.stamps, 0, sizeof(unsigned long long) * BG_NPH * 8, ctx->stream));
         dump.d = g.stamps;
     }
-    if (waves == 4) {
+    if (waves == 4 && npad == 256) {
         ctx->last_dense_kernel = "dense_mfma_big_w4";
         return big_launch_t<4, 256, 2, 2>(ctx, g, grid);
     }
-    ctx->last_dense_kernel = v_star ? "dense_mfma_big + dense_variance_big" : "dense_mfma_big";
-    int rc = big_launch_t<8, 1024, 2, 2>(ctx, g, grid);
+    int rc;
+    if (waves == 4) {
+        ctx->last_dense_kernel = v_star ? "dense_mfma_big + dense_variance_big" : "dense_mfma_big";      // (the shape is not part of the name)
+        rc = big_launch_t<4, 512, 2, 2, false, 1>(ctx, g, grid);
+    } else {
+        ctx->last_dense_kernel = v_star ? "dense_mfma_big + dense_variance_big" : "dense_mfma_big";
+        rc = big_launch_t<8, 1024, 2, 2>(ctx, g, grid);
+    }
     if (rc != GPC_OK || !v_star) return rc;
     DenseArgs av = a;
     av.m = a_in.m;

@@ -118,14 +118,17 @@ __device__ __forceinline__ static bool mf_diag_factor(d4 W, double* rsbuf, doubl
     const int lr = lane & 15, lg = lane >> 4;
     double rp = mf_rcp(mf_readlane(W[0], 0));
     double rpv = (lg == 0 && lr > 0) ? rp : 0.0;
+    // The lane masks of a pivot (is this lane in contraction slot q, is it the pivot's own column) are loop-invariant
+    // constants of the CALLER's loops: hipcc hoists all 15 x 2 of them out, runs out of registers and reloads them from
+    // scratch in front of every MFMA of this chain.  They are re-derived from an opaque copy of the lane id instead, in the
+    // shadow of the previous pivot's MFMA (a handful of VALU ops).
+    double one_q = (lg == 0) ? 1.0 : 0.0, ev = (lane == 0) ? 1.0 : 0.0;
 #pragma unroll
     for (int c = 0; c < MF_TS - 1; ++c) {
         const int q = c & 3, r = c >> 2, q1 = (c + 1) & 3, r1 = (c + 1) >> 2;
-        const bool inq = lg == q;
-        const double ev = (inq && lr == c) ? 1.0 : 0.0;
         // on the chain: two VALU ops and the MFMA
         const double a_op = W[r] * rpv;
-        const double b_op = __builtin_fma(W[r], inq ? 1.0 : 0.0, ev);
+        const double b_op = __builtin_fma(W[r], one_q, ev);
         const d4 Wn = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, W, 0, 0, 1);   // blgp = 1: NEG(A)
         __builtin_amdgcn_sched_barrier(0);
         // in the shadow of the MFMA: the reciprocal of the next pivot from the OLD tile (kept alive in its own registers)
@@ -133,27 +136,34 @@ __device__ __forceinline__ static bool mf_diag_factor(d4 W, double* rsbuf, doubl
         const double s11 = mf_readlane(W[r1], 16 * q1 + c + 1);    // W[c+1][c+1]
         const double t = s01 * rp;
         rp = mf_rcp(__builtin_fma(-t, s01, s11));
-        rpv = (lg == q1 && lr > c + 1) ? rp : 0.0;
+        const int lo_ = mf_opaque(lane);
+        const int lr_ = lo_ & 15, lg_ = lo_ >> 4;
+        rpv = (lg_ == q1 && lr_ > c + 1) ? rp : 0.0;
+        one_q = (lg_ == q1) ? 1.0 : 0.0;
+        ev = (lo_ == 16 * q1 + c + 1) ? 1.0 : 0.0;
         __builtin_amdgcn_sched_barrier(0);
         W = Wn;
     }
     // the pivots are the diagonal of the tile: row lg + 4 r == column lr  <=>  lane 16 (i & 3) + i, register i >> 2
-    const int rsel = lr >> 2;
+    // (lane maps again from an opaque copy: see above)
+    const int lt_ = mf_opaque(lane);
+    const int lrt = lt_ & 15, lgt = lt_ >> 4;
+    const int rsel = lrt >> 2;
     const double pd = rsel == 0 ? W[0] : rsel == 1 ? W[1] : rsel == 2 ? W[2] : W[3];
-    const bool on_diag = (lr & 3) == lg;
+    const bool on_diag = (lrt & 3) == lgt;
     const bool ok = __builtin_amdgcn_ballot_w64(on_diag && !(pd > pivot_tol)) == 0;
     const double rs = mf_rsqrt(on_diag ? pd : 1.0);
-    if (on_diag) rsbuf[lr] = rs;       // one wave: LDS operations execute in program order, no barrier needed
+    if (on_diag) rsbuf[lrt] = rs;       // one wave: LDS operations execute in program order, no barrier needed
     d4 fin;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = lg + 4 * r;
+        const int row = lgt + 4 * r;
         const double rsr = rsbuf[row];
-        fin[r] = (lr < row) ? W[r] * rsr : (lr == row ? rsr : 0.0);
+        fin[r] = (lrt < row) ? W[r] * rsr : (lrt == row ? rsr : 0.0);
     }
-    mf_img_store(LinvT_out, lane, fin);     // C/D registers of L^-1 = operand image of L^-T
+    mf_img_store(LinvT_out, lt_, fin);     // C/D registers of L^-1 = operand image of L^-T
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Linv_out[mf_img_rc(lg + 4 * r, lr)] = fin[r];
+    for (int r = 0; r < 4; ++r) Linv_out[mf_img_rc(lgt + 4 * r, lrt)] = fin[r];
     return ok;
 }
 
