@@ -168,6 +168,9 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         if (n <= 0 || n > MF_TS * ntw) {
             for (int p = tid; p < m * ny; p += BG_THREADS) fs[p] = (n == 0) ? 0.0 : __builtin_nan("");
             if (tid == 0 && A.status) A.status[patch] = (n == 0) ? GPC_STATUS_OK : GPC_STATUS_NAN;
+            if constexpr (BG_IRLS) {
+                if (tid == 0 && g.irls_iters) g.irls_iters[patch] = 0;     // no Newton step was taken
+            }
             continue;
         }
         const int nt = __builtin_amdgcn_readfirstlane((n + MF_TS - 1) / MF_TS);
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
             if (wave == 0) {
                 // the serial chain of the block: factor (k,k); then row by row  L_ic = (T_ic - sum_{c2<c} L_ic2 L_cc2^T) L_cc^-T,
                 // T_ii -= sum_c L_ic L_ic^T, factor -- every L^-1 published as it appears, the block's tiles left in LDS for the workers
-                bool ok = mf_diag_factor(Dmine, rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol);
+                bool ok = mf_diag_factor<true>(Dmine, rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (g.export_factor) mf_img_store(LinvG + (size_t)k * MF_IMG, lane, mf_img_load(LinvC, lane));
                 if (!ok && lane == 0) flag[0] = 1;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                         d4 Dii = *reinterpret_cast<const d4*>(Hand + (i * (i + 1) / 2 + i) * 256 + mf_opaque(lane) * 4);
 #pragma unroll
                         for (int c = 0; c < i; ++c) Dii = bg_mfma4_neg(Lrow[c], Lrow[c], Dii);
-                        ok = mf_diag_factor(Dii, rsbuf, LinvC + i * 256, LinvTg + (size_t)(k + i) * MF_IMG, g.pivot_tol);
+                        ok = mf_diag_factor<true>(Dii, rsbuf, LinvC + i * 256, LinvTg + (size_t)(k + i) * MF_IMG, g.pivot_tol);
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                                 if (g.export_factor) mf_img_store(LinvG + (size_t)(k + i) * MF_IMG, lane, mf_img_load(LinvC + i * 256, mf_opaque(lane)));
                         if (!ok && lane == 0) flag[0] = 1;
@@ -768,7 +771,9 @@ size_t big_slot_doubles(int ntw) { return ((size_t)(ntw + 1) * ntw + 2 * (size_t
 static void big_shape(const DenseArgs& a, bool irls, int* waves, int* npad, int* per_cu)
 {
     if (a.n_max <= 256) { *waves = 4; *npad = 256; *per_cu = 2; }
-    else if (a.n_max <= 512 && a.ny == 1 && !irls && !getenv("GPC_BIG_NO_W4")) { *waves = 4; *npad = 512; *per_cu = 2; }
+    // depth plane only, up to 384 points: four waves, two patches per CU (62 KB of LDS each).  Measured on the producer's own batches
+    // (273 .. 324 points): GP phase 3.29 against 3.42 ms; at n = 512 the 8-wave shape wins (13.2 against 13.4 ms on C3)
+    else if (a.n_max <= 384 && a.ny == 1 && !irls && !getenv("GPC_BIG_NO_W4")) { *waves = 4; *npad = 512; *per_cu = 2; }
     else { *waves = 8; *npad = 1024; *per_cu = 1; }
 }
 

@@ -112,20 +112,26 @@ __device__ static __forceinline__ void mf_img_store(double* img, int l, d4 v)
 // one MFMA plus two VALU ops; the square roots are taken once, vectorised, at the end.  (The previous version ran the
 // elimination on the VALU with v_readlane multipliers: ~650 dependent-issue instructions, 4.6k cycles per tile, on
 // the critical path of every step.)  Writes L^-1 and L^-T as operand images; false when a pivot is <= pivot_tol.
+template <bool OPAQUE = false>
 __device__ __forceinline__ static bool mf_diag_factor(d4 W, double* rsbuf, double* Linv_out, double* LinvT_out, double pivot_tol)
 {
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lg = lane >> 4;
     double rp = mf_rcp(mf_readlane(W[0], 0));
     double rpv = (lg == 0 && lr > 0) ? rp : 0.0;
-    // The lane masks of a pivot (is this lane in contraction slot q, is it the pivot's own column) are loop-invariant
-    // constants of the CALLER's loops: hipcc hoists all 15 x 2 of them out, runs out of registers and reloads them from
-    // scratch in front of every MFMA of this chain.  They are re-derived from an opaque copy of the lane id instead, in the
-    // shadow of the previous pivot's MFMA (a handful of VALU ops).
+    // The lane masks of a pivot (is this lane in contraction slot q, is it the pivot's own column) are loop-invariant constants of
+    // the CALLER's loops.  In the register-tile kernel (dense_mfma.hip) hipcc hoists them and keeps them in registers: fine.  In the
+    // tiled kernel it hoists all 15 x 2 of them out of the step loop, runs out of registers and reloads them from scratch in front of
+    // every MFMA of this chain: OPAQUE re-derives them from an opaque copy of the lane id instead, in the shadow of the previous
+    // pivot's MFMA (a handful of VALU ops; 4 % slower than the hoisted form where that one stays in registers).
     double one_q = (lg == 0) ? 1.0 : 0.0, ev = (lane == 0) ? 1.0 : 0.0;
 #pragma unroll
     for (int c = 0; c < MF_TS - 1; ++c) {
         const int q = c & 3, r = c >> 2, q1 = (c + 1) & 3, r1 = (c + 1) >> 2;
+        if constexpr (!OPAQUE) {
+            one_q = (lg == q) ? 1.0 : 0.0;
+            ev = (lg == q && lr == c) ? 1.0 : 0.0;
+        }
         // on the chain: two VALU ops and the MFMA
         const double a_op = W[r] * rpv;
         const double b_op = __builtin_fma(W[r], one_q, ev);
@@ -136,17 +142,21 @@ __device__ __forceinline__ static bool mf_diag_factor(d4 W, double* rsbuf, doubl
         const double s11 = mf_readlane(W[r1], 16 * q1 + c + 1);    // W[c+1][c+1]
         const double t = s01 * rp;
         rp = mf_rcp(__builtin_fma(-t, s01, s11));
-        const int lo_ = mf_opaque(lane);
-        const int lr_ = lo_ & 15, lg_ = lo_ >> 4;
-        rpv = (lg_ == q1 && lr_ > c + 1) ? rp : 0.0;
-        one_q = (lg_ == q1) ? 1.0 : 0.0;
-        ev = (lo_ == 16 * q1 + c + 1) ? 1.0 : 0.0;
+        if constexpr (OPAQUE) {
+            const int lo_ = mf_opaque(lane);
+            const int lr_ = lo_ & 15, lg_ = lo_ >> 4;
+            rpv = (lg_ == q1 && lr_ > c + 1) ? rp : 0.0;
+            one_q = (lg_ == q1) ? 1.0 : 0.0;
+            ev = (lo_ == 16 * q1 + c + 1) ? 1.0 : 0.0;
+        } else {
+            rpv = (lg == q1 && lr > c + 1) ? rp : 0.0;
+        }
         __builtin_amdgcn_sched_barrier(0);
         W = Wn;
     }
     // the pivots are the diagonal of the tile: row lg + 4 r == column lr  <=>  lane 16 (i & 3) + i, register i >> 2
-    // (lane maps again from an opaque copy: see above)
-    const int lt_ = mf_opaque(lane);
+    // (OPAQUE: lane maps again from an opaque copy, see above)
+    const int lt_ = OPAQUE ? mf_opaque(lane) : lane;
     const int lrt = lt_ & 15, lgt = lt_ >> 4;
     const int rsel = lrt >> 2;
     const double pd = rsel == 0 ? W[0] : rsel == 1 ? W[1] : rsel == 2 ? W[2] : W[3];
