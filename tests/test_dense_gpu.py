@@ -236,6 +236,35 @@ def test_dense_size_class_split(gp, oracle, monkeypatch):
     assert np.max(np.abs(f[ok_big] - f1[ok_big])) <= 1e-10 * np.max(np.abs(f1[ok_big]))
 
 
+@pytest.mark.parametrize("P,lo,hi", [(1, 384, 384), (1, 273, 273), (12, 273, 384), (9, 300, 512)])
+def test_dense_tiled_shapes_agree(gp, oracle, monkeypatch, P, lo, hi):
+    """The tiled kernel has two shapes: four waves and two patches per CU for the depth plane up to 384 points (the producer's
+    273 .. 324-point class), eight waves and one patch per CU above.  Both against the oracle on the sizes in between, and against
+    each other (GPC_BIG_NO_W4 forces the 8-wave shape): same arithmetic in the same order, so they agree far below the tolerance."""
+    capi, ctx = gp
+    res, sz = 0.15, 12
+    rng = np.random.default_rng(7 * P + lo)
+    counts = rng.integers(lo, hi + 1, P)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    N = int(off[-1])
+    x0, x1 = rng.uniform(-res / 2, res / 2, N), rng.uniform(-res / 2, res / 2, N)
+    y = 0.01 * np.sin(25 * x0) * np.cos(15 * x1) + rng.normal(0, 0.003, N)
+    y = (y - np.mean(y))[None, :]
+    prm = capi.default_params_dense()
+    xs0, xs1 = oracle.grid(res, sz)
+    monkeypatch.setenv("GPC_FORCE_BIG", "1")
+    f, st, al = ctx.dense_fit_predict_grid(prm, off, x0, x1, y, res, sz, want_alpha=True)
+    assert ctx.last_dense_kernel() == "dense_mfma_big"
+    monkeypatch.setenv("GPC_BIG_NO_W4", "1")
+    f8, st8, al8 = ctx.dense_fit_predict_grid(prm, off, x0, x1, y, res, sz, want_alpha=True)
+    fo, _, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, want_alpha=True)
+    assert np.all(st == 0) and np.all(st8 == 0) and np.all(so == 0)
+    for ff, aa in ((f, al), (f8, al8)):
+        _close(ff, fo, FTOL)
+        _close(aa, ao, ATOL)
+    _close(f, f8, 1e-12)
+
+
 @pytest.mark.parametrize("P,lo,hi", [(1, 272, 272), (1, 257, 257), (24, 257, 272), (40, 200, 272)])
 def test_dense_nt17_shape(gp, oracle, monkeypatch, P, lo, hi):
     """Patches of 257 .. 272 points (what the octree leaves of a cloud cut for 256-point patches mostly are) stay on the

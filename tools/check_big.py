@@ -1,3 +1,5 @@
+"""Diagnostic: the tiled kernel (GPC_FORCE_BIG=1) against the generic kernel on single patches of NS=n1,n2,.. points, four repetitions
+each (a hand-over race shows as an error that changes from run to run).   NS=512,816,1024 python tools/check_big.py"""
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,8 +22,7 @@ for (P, n, rag) in [(1, int(a), False) for a in os.environ.get('NS', '1024').spl
     kb = ctx.last_dense_kernel()
     sc = np.max(np.abs(ag))
     errs = [float(np.max(np.abs(o[1] - ag)) / sc) for o in outs]
-    same = [bool(np.array_equal(outs[0][1], o[1])) for o in outs]
-    print(P, n, kg, kb, "alpha rel err per rep:", ["%.2e" % e for e in errs], "bit-identical to rep0:", same, "status", outs[0][2][:4], flush=True)
+    print(P, n, kg, kb, "alpha rel err per rep:", ["%.2e" % e for e in errs], "status", outs[0][2][:4], flush=True)
     if max(errs) > 1e-7:
         a0 = outs[int(np.argmax(errs))][1].reshape(-1); d = np.abs(a0 - ag.reshape(-1)) / sc
         bad = np.nonzero(d > 1e-8)[0]
