@@ -131,6 +131,37 @@ template <bool WRITE_Q = true, int RB = SP_RMW_NEXT, class F>
 __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int lv, int nb, const double* kvn, double* pnext, F f)
 {
     const int lane = threadIdx.x & 63;
+    if (SP_NTH == 64 && nb <= 32) {
+        // One wave and a small basis (the reference's default hyper-parameters keep it around 13): with a lane per row most of the
+        // wave idles and the four column quarters run one after the other -- ~30 instructions per column, 13 columns, every point.
+        // Here the lanes form 4 groups of 16 rows (nb <= 16) or 2 groups of 32: group g takes the quarters g, g + G, .. at the same
+        // time.  Within a quarter the columns are still visited in ascending order by the lane that owns the row, so every sum
+        // is the same sequence of operations as below: the same bits.
+        const int shift = nb <= 16 ? 4 : 5;
+        const int i = lane & ((1 << shift) - 1), G = 64 >> shift;
+        const int cols = (nb + 3) >> 2;                                 // columns of the widest quarter
+        for (int quarter = lane >> shift; quarter < 4; quarter += G) {
+            const int jlo = (nb * quarter) >> 2, jhi = (nb * (quarter + 1)) >> 2;
+            double ac = 0.0, aq = 0.0;
+            for (int t = 0; t < cols; ++t) {
+                const int j = jlo + t;
+                if (j < jhi && i < nb) {
+                    double c = C[i + (size_t)j * ld], q = Q[i + (size_t)j * ld];
+                    f(i, j, c, q);
+                    C[i + (size_t)j * ld] = c;
+                    if (WRITE_Q) Q[i + (size_t)j * ld] = q;
+                    const double kj = kvn[j];
+                    ac += c * kj;
+                    aq += q * kj;
+                }
+            }
+            if (i < nb) {
+                pnext[(quarter * 2 + 0) * lv + i] = ac;
+                pnext[(quarter * 2 + 1) * lv + i] = aq;
+            }
+        }
+        return;
+    }
     for (int quarter = threadIdx.x >> 6; quarter < 4; quarter += SP_NTH >> 6) {     // one quarter per wave, or all four in turn
     const int jlo = (nb * quarter) >> 2, jhi = (nb * (quarter + 1)) >> 2;
     for (int i = lane; i < nb; i += 64) {
@@ -472,7 +503,24 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
 
             // C k and e_hat = Q k (:140,:160,:171): wave w covers columns j in its quarter, lanes cover rows
             const double* pp = from_prev ? pnext : part;
-            if (!from_prev) {
+            if (!from_prev && SP_NTH == 64 && b <= 32) {
+                // one wave, small basis: the four quarters side by side (see sp_rmw_cq_next)
+                const int shift = b <= 16 ? 4 : 5;
+                const int i = lane & ((1 << shift) - 1), G = 64 >> shift;
+                for (int quarter = lane >> shift; quarter < 4; quarter += G) {
+                    const int jlo = (b * quarter) >> 2, jhi = (b * (quarter + 1)) >> 2;
+                    double ac = 0.0, aq = 0.0;
+                    if (i < b) {
+                        for (int j = jlo; j < jhi; ++j) {
+                            const double kj = kv[j];
+                            ac += S.C[i + (size_t)j * ldm] * kj;
+                            aq += S.Q[i + (size_t)j * ldm] * kj;
+                        }
+                        part[(quarter * 2 + 0) * ld + i] = ac;
+                        part[(quarter * 2 + 1) * ld + i] = aq;
+                    }
+                }
+            } else if (!from_prev) {
                 for (int quarter = wave; quarter < 4; quarter += SP_NTH >> 6) {     // one quarter per wave, or all four in turn
                     const int jlo = (b * quarter) >> 2, jhi = (b * (quarter + 1)) >> 2;
                     for (int i = lane; i < b; i += 64) {
