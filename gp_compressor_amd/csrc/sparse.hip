@@ -44,17 +44,49 @@ struct SpState {
 #define SP_NTH ((int)blockDim.x)
 // ---- block-wide helpers (all SP_NTH threads call) -------------------------------------------------------
 
+template <int CTRL>
+__device__ static __forceinline__ int sp_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ static __forceinline__ double sp_dpp(double v)
+{
+    return __hiloint2double(sp_dpp_i<CTRL>(__double2hiint(v)), sp_dpp_i<CTRL>(__double2loint(v)));
+}
+__device__ static __forceinline__ double sp_readlane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// Sum over the 64 lanes of a wave without LDS traffic (the shuffle form costs two ds_bpermute and an LDS round trip per step, six
+// steps per sum, eight sums per point: a fifth of the instructions and most of the latency of a point in the small-basis regime).
+// Inside a row of 16 the exchanges are symmetric -- quad xor 1, quad xor 2, half-row mirror, row mirror: both partners add the same
+// two numbers -- so the 16 lanes of a row end with the same bits; the four row totals then go through SGPRs and are added in one
+// fixed order by every lane: the result is uniform by construction (a lane-dependent association would let `gamma < eps_tol`
+// diverge inside a wave).
+__device__ static __forceinline__ double sp_wave_sum_dpp(double v)
+{
+    v += sp_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += sp_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += sp_dpp<0x141>(v);     // row_half_mirror
+    v += sp_dpp<0x140>(v);     // row_mirror
+    return (sp_readlane(v, 0) + sp_readlane(v, 16)) + (sp_readlane(v, 32) + sp_readlane(v, 48));
+}
+
 // dot products of up to 4 pairs at once; results broadcast to every thread
 __device__ static inline void sp_block_sum4(double (&v)[4], double* scratch /*4*4 doubles*/)
 {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = gpc_wave_sum(v[q]);
+    for (int q = 0; q < 4; ++q) v[q] = sp_wave_sum_dpp(v[q]);
+    if (SP_NTH == 64) {
+        // one-wave shape: what the four-wave layout below computes with three absent waves contributing +0.0 (x + 0.0 is not x for -0.0)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ((v[q] + 0.0) + 0.0) + 0.0;
+        return;
+    }
     const int w = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) scratch[w * 4 + q] = v[q];
-        if (w == 0)                                   // one-wave shape: the three absent waves contribute the +0.0 they would have summed
+        if (w == 0)                                   // two-wave shape: the absent waves contribute the +0.0 they would have summed
             for (int w2 = SP_NTH >> 6; w2 < 4; ++w2)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) scratch[w2 * 4 + q] = 0.0;
@@ -64,15 +96,35 @@ __device__ static inline void sp_block_sum4(double (&v)[4], double* scratch /*4*
     for (int q = 0; q < 4; ++q) v[q] = scratch[q] + scratch[4 + q] + scratch[8 + q] + scratch[12 + q];
 }
 
-// argmin with first-index tie break (the reference scans i ascending with a strict '<')
+// argmin with first-index tie break (the reference scans i ascending with a strict '<').  The order is total (value, then index, NaN
+// last), so the winner does not depend on the shape of the reduction; rows by DPP, the four row winners through SGPRs.
+#define SP_TAKE(ov, oi, val, idx) ((ov) < (val) || ((ov) == (val) && (oi) < (idx)) || ((val) != (val) && (ov) == (ov)))
 __device__ static inline void sp_block_argmin(double& val, int& idx, double* sval, int* sidx)
 {
+#define SP_ARGMIN_STEP(CTRL)                                                                                          \
+    do {                                                                                                             \
+        const double ov = sp_dpp<CTRL>(val);                                                                         \
+        const int oi = sp_dpp_i<CTRL>(idx);                                                                          \
+        if (SP_TAKE(ov, oi, val, idx)) { val = ov; idx = oi; }                                                       \
+    } while (0)
+    SP_ARGMIN_STEP(0xB1);
+    SP_ARGMIN_STEP(0x4E);
+    SP_ARGMIN_STEP(0x141);
+    SP_ARGMIN_STEP(0x140);
+#undef SP_ARGMIN_STEP
+    {
+        double bv = sp_readlane(val, 0);
+        int bi = __builtin_amdgcn_readlane(idx, 0);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        double ov = __shfl_xor(val, o, 64);
-        int oi = __shfl_xor(idx, o, 64);
-        if (ov < val || (ov == val && oi < idx) || (val != val && ov == ov)) { val = ov; idx = oi; }
+        for (int r = 1; r < 4; ++r) {
+            const double ov = sp_readlane(val, 16 * r);
+            const int oi = __builtin_amdgcn_readlane(idx, 16 * r);
+            if (SP_TAKE(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        val = bv;
+        idx = bi;
     }
+    if (SP_NTH == 64) return;
     const int w = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { sval[w] = val; sidx[w] = idx; }
@@ -82,7 +134,7 @@ __device__ static inline void sp_block_argmin(double& val, int& idx, double* sva
     for (int q = 1; q < SP_NTH / 64; ++q) {
         double ov = sval[q];
         int oi = sidx[q];
-        if (ov < val || (ov == val && oi < idx) || (val != val && ov == ov)) { val = ov; idx = oi; }
+        if (SP_TAKE(ov, oi, val, idx)) { val = ov; idx = oi; }
     }
 }
 
