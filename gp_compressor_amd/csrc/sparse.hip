@@ -70,30 +70,32 @@ __device__ static __forceinline__ double sp_wave_sum_dpp(double v)
     return (sp_readlane(v, 0) + sp_readlane(v, 16)) + (sp_readlane(v, 32) + sp_readlane(v, 48));
 }
 
-// dot products of up to 4 pairs at once; results broadcast to every thread
+// block-wide sums of the first N (<= 4) entries of v; results broadcast to every thread (the other entries are left alone: a wave
+// sum is ~25 instructions, and the callers need 2 + ny of the 8 slots they carry)
+template <int N>
 __device__ static inline void sp_block_sum4(double (&v)[4], double* scratch /*4*4 doubles*/)
 {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = sp_wave_sum_dpp(v[q]);
+    for (int q = 0; q < N; ++q) v[q] = sp_wave_sum_dpp(v[q]);
     if (SP_NTH == 64) {
         // one-wave shape: what the four-wave layout below computes with three absent waves contributing +0.0 (x + 0.0 is not x for -0.0)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ((v[q] + 0.0) + 0.0) + 0.0;
+        for (int q = 0; q < N; ++q) v[q] = ((v[q] + 0.0) + 0.0) + 0.0;
         return;
     }
     const int w = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) scratch[w * 4 + q] = v[q];
+        for (int q = 0; q < N; ++q) scratch[w * 4 + q] = v[q];
         if (w == 0)                                   // two-wave shape: the absent waves contribute the +0.0 they would have summed
             for (int w2 = SP_NTH >> 6; w2 < 4; ++w2)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) scratch[w2 * 4 + q] = 0.0;
+                for (int q = 0; q < N; ++q) scratch[w2 * 4 + q] = 0.0;
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = scratch[q] + scratch[4 + q] + scratch[8 + q] + scratch[12 + q];
+    for (int q = 0; q < N; ++q) v[q] = scratch[q] + scratch[4 + q] + scratch[8 + q] + scratch[12 + q];
 }
 
 // argmin with first-index tie break (the reference scans i ascending with a strict '<').  The order is total (value, then index, NaN
@@ -600,8 +602,9 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                 dots[1] += ki * q_;                        // k^T e_hat (:144)
                 for (int c = 0; c < ny; ++c) sums[c] += S.alpha[c * ld + i] * ki;   // m = alpha^T k (:121)
             }
-            sp_block_sum4(dots, red);
-            sp_block_sum4(sums, red);
+            sp_block_sum4<2>(dots, red);
+            if (ny == 1) sp_block_sum4<1>(sums, red);
+            else sp_block_sum4<3>(sums, red);
             const double s2 = kstar + dots[0];
             double gamma = kstar - dots[1];
             if (gamma < (double)1e-12f) gamma = 0;          // :146-151
