@@ -739,6 +739,9 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                         if (!have || score < best) { best = score; loc = i; have = true; }
                     }
                     if (!have) best = __builtin_inf();
+                    // one wave: if no lane holds a score below the threshold the loop ends whatever the minimum is (>= 1e-9f, or NaN:
+                    // both leave it, nothing else reads minscore) -- the arg-min is only needed to find WHICH vector goes
+                    if (SP_NTH == 64 && __builtin_amdgcn_ballot_w64(have && best < (double)1e-9f) == 0) break;
                     sp_block_argmin(best, loc, sval, sidx);
                     if (loc < 0 || loc >= b) loc = 0;
                     minscore = best;
