@@ -433,7 +433,9 @@ struct SpAddParams {
 // a one-phase run, bit for bit.
 #define SP_BMAX 24
 
-template <bool SMALL>
+// PROBIT: the probit functor (sqrt, erf, exp: ~450 instructions and their constants) is compiled in only where it is used -- in the
+// Gaussian instantiation, the reference's production path, its registers go to the point loop
+template <bool SMALL, bool PROBIT = false>
 __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse_add_kernel(SpAddParams A)   // <= 256 VGPRs (128 for the small-basis phase)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -612,8 +614,8 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
             // r = noise.dx2_ln, q = noise.dx_ln  (/root/reference/src/gaussian_noise.cpp:9-18, gaussian_noise_3d.cpp:11-20,
             // probit_noise.cpp:11-31)
             double rr, qv[3];
-            if (A.prm.noise_model != GPC_NOISE_GAUSSIAN && ny == 1) {
-                gpc_probit_q_r(A.prm.noise_model, s20, yv[0], sums[0], s2, &qv[0], &rr);
+            if (PROBIT && A.prm.noise_model != GPC_NOISE_GAUSSIAN && ny == 1) {
+                if constexpr (PROBIT) gpc_probit_q_r(A.prm.noise_model, s20, yv[0], sums[0], s2, &qv[0], &rr);
             } else {
                 rr = (double)(-1.0f) / (s20 + s2);
                 for (int c = 0; c < ny; ++c) qv[c] = (yv[c] - sums[c]) / (s20 + s2);
@@ -1311,12 +1313,16 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
         int per_cu_s = (int)((160u * 1024u) / lds_s);
         per_cu_s = per_cu_s > 16 ? 16 : per_cu_s;
         A.done_it = g->done_it;
-        hipLaunchKernelGGL(sparse_add_kernel<true>, dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
+        if (A.prm.noise_model != GPC_NOISE_GAUSSIAN)
+            hipLaunchKernelGGL((sparse_add_kernel<true, true>), dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
+        else
+            hipLaunchKernelGGL((sparse_add_kernel<true, false>), dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
         GPC_HIP(ctx, hipGetLastError());
         A.start_it = g->done_it;
         A.done_it = nullptr;
     }
-    hipLaunchKernelGGL(sparse_add_kernel<false>, dim3(grid), dim3(nth), lds, ctx->stream, A);
+    if (A.prm.noise_model != GPC_NOISE_GAUSSIAN) hipLaunchKernelGGL((sparse_add_kernel<false, true>), dim3(grid), dim3(nth), lds, ctx->stream, A);
+    else hipLaunchKernelGGL((sparse_add_kernel<false, false>), dim3(grid), dim3(nth), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;
 }
