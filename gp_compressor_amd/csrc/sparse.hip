@@ -431,7 +431,9 @@ struct SpAddParams {
 // number of points consumed recorded in done_it -- at the first point that would grow its basis beyond SP_BMAX; the regular
 // kernel then continues from there (start_it).  Same operations in the same order: the two-phase run leaves the states of
 // a one-phase run, bit for bit.
+#ifndef SP_BMAX
 #define SP_BMAX 24
+#endif
 
 // PROBIT: the probit functor (sqrt, erf, exp: ~450 instructions and their constants) is compiled in only where it is used -- in the
 // Gaussian instantiation, the reference's production path, its registers go to the point loop
