@@ -1314,6 +1314,7 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
         const size_t lds_s = sp_add_lds_small();
         int per_cu_s = (int)((160u * 1024u) / lds_s);
         per_cu_s = per_cu_s > 16 ? 16 : per_cu_s;
+        if (const char* e = getenv("GPC_SPARSE_SMALL_PER_CU")) per_cu_s = std::max(1, std::min(per_cu_s, atoi(e)));   // diagnostic: occupancy experiments
         A.done_it = g->done_it;
         if (A.prm.noise_model != GPC_NOISE_GAUSSIAN)
             hipLaunchKernelGGL((sparse_add_kernel<true, true>), dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
