@@ -42,6 +42,9 @@ struct SpState {
 // and the quarter-wise mat-vec sums are laid out identically); the narrow one has no cross-wave barriers and keeps four
 // times as many patches in flight, which is what the small-basis regime needs.
 #define SP_NTH ((int)blockDim.x)
+#ifndef SP_BMAX
+#define SP_BMAX 24   // resident block of the small-basis add kernel (see sparse_add_kernel)
+#endif
 // ---- block-wide helpers (all SP_NTH threads call) -------------------------------------------------------
 
 template <int CTRL>
@@ -185,7 +188,7 @@ template <bool WRITE_Q = true, int RB = SP_RMW_NEXT, class F>
 __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int lv, int nb, const double* kvn, double* pnext, F f)
 {
     const int lane = threadIdx.x & 63;
-    if (SP_NTH == 64 && nb <= 32) {
+    if (SP_NTH == 64 && nb <= 32 && ld == SP_BMAX) {     // (ld == SP_BMAX: C and Q are the LDS blocks of the small-basis kernel)
         // One wave and a small basis (the reference's default hyper-parameters keep it around 13): with a lane per row most of the
         // wave idles and the four column quarters run one after the other -- ~30 instructions per column, 13 columns, every point.
         // Here the lanes form 4 groups of 16 rows (nb <= 16) or 2 groups of 32: group g takes the quarters g, g + G, .. at the same
@@ -431,9 +434,6 @@ struct SpAddParams {
 // number of points consumed recorded in done_it -- at the first point that would grow its basis beyond SP_BMAX; the regular
 // kernel then continues from there (start_it).  Same operations in the same order: the two-phase run leaves the states of
 // a one-phase run, bit for bit.
-#ifndef SP_BMAX
-#define SP_BMAX 24
-#endif
 
 // PROBIT: the probit functor (sqrt, erf, exp: ~450 instructions and their constants) is compiled in only where it is used -- in the
 // Gaussian instantiation, the reference's production path, its registers go to the point loop
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
 
             // C k and e_hat = Q k (:140,:160,:171): wave w covers columns j in its quarter, lanes cover rows
             const double* pp = from_prev ? pnext : part;
-            if (!from_prev && SP_NTH == 64 && b <= 32) {
+            if (!from_prev && SMALL && b <= 32) {
                 // one wave, small basis: the four quarters side by side (see sp_rmw_cq_next)
                 const int shift = b <= 16 ? 4 : 5;
                 const int i = lane & ((1 << shift) - 1), G = 64 >> shift;
