@@ -291,7 +291,9 @@ typedef struct gpc_patches_view {
 int gpc_project_cloud(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, double res, int sz, gpc_patches** out);
 int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, double res, int sz, gpc_patches** out);
 /* sizes + DEVICE pointers (valid until gpc_patches_destroy): feed them to gpc_dense_fit_predict_grid_dev /
- * gpc_sparse_add_dev / gpc_reproject_dev without a host round trip */
+ * gpc_sparse_add_dev / gpc_reproject_dev without a host round trip.  The buffers are READ-ONLY for the caller: the dense entry
+ * points recognise the context's most recent batch by its `off` buffer and P, and size their per-size-class launches from the
+ * counts the producer took while cutting it. */
 int gpc_patches_view_dev(const gpc_patches* p, gpc_patches_view* view);
 /* copy to HOST buffers sized by the view's counts; NULL pointers are skipped */
 int gpc_patches_fetch(const gpc_patches* p, int32_t* off, double* x0, double* x1, double* y, double* rgb, double* rotations,
