@@ -350,7 +350,7 @@ def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s):
                                   + (" -- basis-filling kernel l=res/8, sigma_f^2=1, s20=1e-4" if regime == "fill"
                                      else " -- the reference's default hyper-parameters (sigma_f^2=100, l^2=1, s20=0.1)"),
                       "patches_per_gpu": P, "points_per_patch": n, "capacity": cap, "bv_mean": float(bv.mean()), "bv_max": int(bv.max()),
-                      "kernel": "sparse_add_kernel<true> + sparse_add_kernel<false> + sparse_predict_kernel", "results_ok": ok},
+                      "kernel": "sparse_add_kernel<true, false> (small-basis phase) + sparse_add_kernel<false, false> + sparse_predict_kernel", "results_ok": ok},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                         "traffic": _traffic(f"sparse_add@C4_{regime}"), "kernel_ms": add_ms, "bytes_per_patch": bytes_total / P,
                         "what": "the add calls of one pass (small-basis phase + regular kernel): sum over points of 32 b_t^2 bytes / "
