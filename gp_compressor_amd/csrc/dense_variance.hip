@@ -22,6 +22,8 @@
 //     skips its own prediction phase when the variance is requested.
 // Measured on C2 (8192 x 256, m = 400): fit + mean + variance 8.6 ms = 955 k patches/s, 31.8 TFLOP/s = 0.40 of the FP64 peak
 // counting F(n, m) + n^2 m + 2 n m flops per patch (the generic kernel: 91 ms).
+#include <cstdlib>
+
 #include "gpc_device.h"
 #include "gpc_internal.h"
 #include "mfma_tile.h"
@@ -38,9 +40,13 @@ struct VarParams {
     double* v_star;         // [P][m]
 };
 
-template <int NT>
-__global__ __launch_bounds__(DV_THREADS, 2) void dense_variance_kernel(VarParams g)
+// WV waves per workgroup: 8 (one workgroup per CU) or 4 (two: 25 blocks of 16 points are four rounds of eight with one wave busy in
+// the last -- 78 % of the MFMA slots -- but seven rounds of four with 89 %, and the two workgroups of a CU cover each other's barriers)
+template <int NT, int WV = 8>
+__global__ __launch_bounds__(64 * WV, 2) void dense_variance_kernel(VarParams g)
 {
+    constexpr int DVT = 64 * WV;                                  // threads
+    constexpr int NPRE = (DV_CH * MF_IMG) / DVT / 4;              // d4's of a chunk per thread
     constexpr int NTILES = NT * (NT + 1) / 2;
     constexpr int NCHUNK = (NTILES + DV_CH - 1) / DV_CH;
     __shared__ __attribute__((aligned(16))) double T[GPC_EXP_TABLE_SIZE];
@@ -64,12 +70,12 @@ __global__ __launch_bounds__(DV_THREADS, 2) void dense_variance_kernel(VarParams
     const int st = A.status ? __builtin_amdgcn_readfirstlane(A.status[patch]) : GPC_STATUS_OK;
     if (n <= 0 || n > NT * MF_TS || st != GPC_STATUS_OK) {
         // no training points: f* = 0, v = sigma_f^2 (the prior); a failed fit: NaN
-        for (int p = tid; p < m; p += DV_THREADS) vs[p] = (n == 0) ? sf : __builtin_nan("");
-        for (int p = tid; p < m * ny; p += DV_THREADS) fs[p] = (n == 0) ? 0.0 : __builtin_nan("");
+        for (int p = tid; p < m; p += DVT) vs[p] = (n == 0) ? sf : __builtin_nan("");
+        for (int p = tid; p < m * ny; p += DVT) fs[p] = (n == 0) ? 0.0 : __builtin_nan("");
         return;
     }
     const int nt = __builtin_amdgcn_readfirstlane((n + MF_TS - 1) / MF_TS);
-    for (int i = tid; i < NT * MF_TS; i += DV_THREADS) {
+    for (int i = tid; i < NT * MF_TS; i += DVT) {
         px0[i] = (i < n) ? A.x0[o + i] : 0.0;
         px1[i] = (i < n) ? A.x1[o + i] : 0.0;
 #pragma unroll
@@ -77,38 +83,43 @@ __global__ __launch_bounds__(DV_THREADS, 2) void dense_variance_kernel(VarParams
     }
     const double* F = g.factor + (size_t)patch * NTILES * MF_IMG;
     // this thread's 32 bytes of a chunk: chunk c = images [c DV_CH, (c + 1) DV_CH) = 2048 doubles, 4 per thread
-    const int my4 = tid * 4;
+    const int my4 = tid * 4;                                   // + u * 4 DVT, u < NPRE
     const int nblk = (m + MF_TS - 1) / MF_TS;
-    const int rounds = (nblk + DV_WAVES - 1) / DV_WAVES;
+    const int rounds = (nblk + WV - 1) / WV;
     // last chunk that rows < nt touch (the stream is consumed in order; everything behind it is never read)
     const int last_pos = (nt * (nt + 1)) / 2 - 1;
     const int last_chunk = __builtin_amdgcn_readfirstlane(last_pos / DV_CH);
 
     for (int rd = 0; rd < rounds; ++rd) {
-        const int blk = rd * DV_WAVES + wave;
+        const int blk = rd * WV + wave;
         const bool active = blk < nblk;
         const int q = MF_TS * blk + lr;                 // this lane's prediction point (column of the block)
         const bool qv = active && q < m;
         const double gx0 = qv ? A.xs0[q] : 0.0, gx1 = qv ? A.xs1[q] : 0.0;
         d4 V[NT];
         double nrm = 0.0, fm[3] = {0.0, 0.0, 0.0};
-        d4 pre = d4{0.0, 0.0, 0.0, 0.0};
+        d4 pre[NPRE];
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) pre[u] = d4{0.0, 0.0, 0.0, 0.0};
         __syncthreads();                                // previous round (or the px load) is complete; Lbuf may be rewritten
         // chunk 0 -> buffer 0, chunk 1 in flight
         {
-            const d4 c0 = *reinterpret_cast<const d4*>(F + my4);
-            *reinterpret_cast<d4*>(&Lbuf[0][my4]) = c0;
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) *reinterpret_cast<d4*>(&Lbuf[0][my4 + u * 4 * DVT]) = *reinterpret_cast<const d4*>(F + my4 + u * 4 * DVT);
             const int c1 = min(1, NCHUNK - 1);
-            pre = *reinterpret_cast<const d4*>(F + (size_t)c1 * DV_CH * MF_IMG + my4);
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) pre[u] = *reinterpret_cast<const d4*>(F + (size_t)c1 * DV_CH * MF_IMG + my4 + u * 4 * DVT);
         }
         __syncthreads();
         if (!active) {
             // no block left for this wave in the last round: keep feeding the LDS stream (same barriers, same order) but stay
             // off the MFMA pipe, which the SIMD's other wave may be using
             for (int c = 1; c <= last_chunk; ++c) {
-                *reinterpret_cast<d4*>(&Lbuf[c & 1][my4]) = pre;
+#pragma unroll
+                for (int u = 0; u < NPRE; ++u) *reinterpret_cast<d4*>(&Lbuf[c & 1][my4 + u * 4 * DVT]) = pre[u];
                 const int cn = min(c + 1, last_chunk);
-                pre = *reinterpret_cast<const d4*>(F + (size_t)cn * DV_CH * MF_IMG + my4);
+#pragma unroll
+                for (int u = 0; u < NPRE; ++u) pre[u] = *reinterpret_cast<const d4*>(F + (size_t)cn * DV_CH * MF_IMG + my4 + u * 4 * DVT);
                 __syncthreads();
             }
             continue;
@@ -132,9 +143,11 @@ __global__ __launch_bounds__(DV_THREADS, 2) void dense_variance_kernel(VarParams
                     const int c = pos / DV_CH, slot = pos % DV_CH;
                     if (slot == 0 && c > 0) {
                         // entering chunk c: publish it (prefetched during chunk c-1) and start fetching chunk c+1
-                        *reinterpret_cast<d4*>(&Lbuf[c & 1][my4]) = pre;
+#pragma unroll
+                        for (int u = 0; u < NPRE; ++u) *reinterpret_cast<d4*>(&Lbuf[c & 1][my4 + u * 4 * DVT]) = pre[u];
                         const int cn = min(c + 1, last_chunk);
-                        pre = *reinterpret_cast<const d4*>(F + (size_t)cn * DV_CH * MF_IMG + my4);
+#pragma unroll
+                        for (int u = 0; u < NPRE; ++u) pre[u] = *reinterpret_cast<const d4*>(F + (size_t)cn * DV_CH * MF_IMG + my4 + u * 4 * DVT);
                         __syncthreads();
                     }
                     const d4 img = mf_img_load(&Lbuf[c & 1][slot * MF_IMG], lane);
@@ -175,7 +188,14 @@ __global__ __launch_bounds__(DV_THREADS, 2) void dense_variance_kernel(VarParams
 template <int NT>
 static int var_launch_t(gpc_ctx* ctx, const VarParams& g, int grid)
 {
-    hipLaunchKernelGGL(dense_variance_kernel<NT>, dim3(grid), dim3(DV_THREADS), 0, ctx->stream, g);
+    // four waves per workgroup (two workgroups per CU) when that fills the rounds markedly better: m = 400 is 25 blocks -- 0.78 of
+    // the wave slots in rounds of eight, 0.89 in rounds of four (C2 + variance 8.22 -> 8.06 ms; the factor is streamed 7 times
+    // instead of 4, which eats most of the gain)
+    const int nblk = (g.a.m + MF_TS - 1) / MF_TS;
+    const double eff8 = (double)nblk / (8 * ((nblk + 7) / 8)), eff4 = (double)nblk / (4 * ((nblk + 3) / 4));
+    const bool w4 = getenv("GPC_VAR_W4") ? atoi(getenv("GPC_VAR_W4")) != 0 : eff4 > eff8 + 0.08;
+    if (w4) hipLaunchKernelGGL((dense_variance_kernel<NT, 4>), dim3(grid), dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((dense_variance_kernel<NT, 8>), dim3(grid), dim3(DV_THREADS), 0, ctx->stream, g);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;
 }
