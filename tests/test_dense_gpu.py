@@ -39,7 +39,7 @@ def _dense_case(name):
 
 
 @pytest.mark.parametrize("name", ["tiny", "c1", "rgb", "n256"])
-def test_dense_golden(gp, name):
+def test_dense_golden(gp, name, monkeypatch):
     capi, ctx = gp
     d = _dense_case(name)
     p = capi.default_params_dense(want_variance=1)
@@ -48,6 +48,14 @@ def test_dense_golden(gp, name):
     _close(f, d["f_star"], FTOL)
     _close(al, d["alpha"], ATOL)
     assert np.max(np.abs(v - d["v_star"])) <= VTOL
+    # the variance kernel picks four or eight waves per workgroup by how the 16-point blocks fill its rounds: both shapes do the
+    # same arithmetic per block on the same factor, so forcing either one gives the same variance bit for bit (the mean goes through
+    # alpha, whose backward solve adds with LDS atomics in no fixed order: equal to a rounding or two, run to run)
+    for w4 in ("0", "1"):
+        monkeypatch.setenv("GPC_VAR_W4", w4)
+        f2, v2, st2, _ = ctx.dense_fit_predict(p, d["off"], d["x0"], d["x1"], d["y"], d["xs0"], d["xs1"], want_alpha=True)
+        assert np.array_equal(v2, v) and np.array_equal(st2, st)
+        _close(f2, f, 1e-12)
 
 
 @pytest.fixture(params=["dispatch", "generic", "big"])
