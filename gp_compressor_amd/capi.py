@@ -82,6 +82,8 @@ PROTOTYPES = {
     "gpc_sparse_add_dev": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_predict": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "gpc_sparse_predict_dev": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "gpc_sparse_predict_points": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "gpc_sparse_predict_points_dev": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "gpc_sparse_likelihood": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_likelihood_dev": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "gpc_sparse_train_sigmaf": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp]),
@@ -456,6 +458,23 @@ class Sparse:
     def predict_dev(self, m, xs0, xs1, f_star, sigma=None, conf=False, status=None):
         self.ctx._check(self.lib.gpc_sparse_predict_dev(self.h, m, _ptr(xs0), _ptr(xs1), _ptr(f_star), _ptr(sigma),
                                                         int(conf), _ptr(status)))
+
+    def predict_points(self, off, x0, x1, want_sigma=False, conf=False):
+        """predict_measurements with every patch on its own (ragged) point set: f (ny, N), sigma (N,)|None, status (P,)"""
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        N = int(off[-1])
+        assert off.shape[0] == self.P + 1 and x0.shape[0] == N and x1.shape[0] == N
+        f = np.full((self.ny, N), np.nan)
+        s = np.full(N, np.nan) if want_sigma else None
+        st = np.full(self.P, -1, dtype=np.int32)
+        self.ctx._check(self.lib.gpc_sparse_predict_points(self.h, _ptr(off), _ptr(x0), _ptr(x1), _ptr(f), _ptr(s), int(conf), _ptr(st)))
+        return f, s, st
+
+    def predict_points_dev(self, off, n_total, x0, x1, f, sigma=None, conf=False, status=None):
+        self.ctx._check(self.lib.gpc_sparse_predict_points_dev(self.h, _ptr(off), int(n_total), _ptr(x0), _ptr(x1), _ptr(f),
+                                                               _ptr(sigma), int(conf), _ptr(status)))
 
     def likelihood(self, off, x0, x1, y, want_dx=True, want_l=True):
         """compute_derivatives + compute_likelihoods (src/sparse_gp.h:44-45) on a ragged batch: dX (N, 3), l (N)"""

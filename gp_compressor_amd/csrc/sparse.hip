@@ -798,6 +798,11 @@ struct SpPredParams {
     double *f_star, *sigma;
     int32_t* status_out;
     const int32_t* stat;
+    // ragged form (gpc_sparse_predict_points): patch i predicts at ITS OWN points off[i] .. off[i+1]-1 of xs0/xs1 and writes rows
+    // off[i] .. of the output planes (plane stride n_total) -- predict_measurements(f, X_i, sigma) as the reference's training-set
+    // RMS block calls it (/root/reference/src/gp_compressor.cpp:303-315).  nullptr: the shared grid of load_compressed.
+    const int32_t* off;
+    int n_total;
 };
 
 #define SP_PC 32   // grid points per chunk of the sigma path
@@ -875,7 +880,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_predict_kernel(SpPredParams
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    const int ld = A.ld, ny = A.ny, m = A.m;
+    const int ld = A.ld, ny = A.ny;
     double* T = reinterpret_cast<double*>(smem);   // 64
     double* bv = T + 64;                           // 2*ld
     double* al = bv + 2 * ld;                      // ny*ld
@@ -897,26 +902,31 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_predict_kernel(SpPredParams
         }
         if (tid == 0) *clamp = 0;
         __syncthreads();
-        double* fs = A.f_star + (size_t)patch * ny * m;
+        const int po = A.off ? A.off[patch] : 0;                           // first point of this patch in xs0 / xs1
+        const int m = A.off ? A.off[patch + 1] - po : A.m;
+        const size_t fstride = A.off ? (size_t)A.n_total : (size_t)m;     // distance between the output planes
+        const double* xs0 = A.xs0 + po;
+        const double* xs1 = A.xs1 + po;
+        double* fs = A.off ? A.f_star + po : A.f_star + (size_t)patch * ny * m;
         // mean: f = alpha^T k (:329); b == 0 -> 0 (:321-327)
         for (int p = tid; p < m; p += SP_THREADS) {
-            const double q0 = A.xs0[p], q1 = A.xs1[p];
+            const double q0 = xs0[p], q1 = xs1[p];
             double s[3] = {0.0, 0.0, 0.0};
             for (int i = 0; i < b; ++i) {
                 const double k = gpc_rbf(sf, A.c_exp, q0, q1, bv[2 * i], bv[2 * i + 1], T);
                 for (int c = 0; c < ny; ++c) s[c] += al[c * ld + i] * k;
             }
-            for (int c = 0; c < ny; ++c) fs[(size_t)c * m + p] = s[c];
+            for (int c = 0; c < ny; ++c) fs[(size_t)c * fstride + p] = s[c];
         }
         if (A.sigma) {
-            double* sg = A.sigma + (size_t)patch * m;
+            double* sg = A.off ? A.sigma + po : A.sigma + (size_t)patch * m;
             const double kstar = sf;
             for (int p0 = 0; p0 < m; p0 += SP_PC) {
                 const int pc = min(SP_PC, m - p0);
                 __syncthreads();
                 for (int e = tid; e < b * SP_PC; e += SP_THREADS) {
                     const int pp = e & (SP_PC - 1), i = e / SP_PC;
-                    Kc[i * SP_PC + pp] = (pp < pc) ? gpc_rbf(sf, A.c_exp, A.xs0[p0 + pp], A.xs1[p0 + pp], bv[2 * i], bv[2 * i + 1], T) : 0.0;
+                    Kc[i * SP_PC + pp] = (pp < pc) ? gpc_rbf(sf, A.c_exp, xs0[p0 + pp], xs1[p0 + pp], bv[2 * i], bv[2 * i + 1], T) : 0.0;
                 }
                 __syncthreads();
                 if (A.fast) {
@@ -1348,9 +1358,44 @@ int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double
     A.P = g->P; A.ny = g->ny; A.ld = g->ld; A.m = m; A.conf = conf;
     A.xs0 = xs0; A.xs1 = xs1; A.alpha = g->alpha; A.C = g->C; A.BV = g->BV; A.b = g->b;
     A.f_star = f_star; A.sigma = sigma; A.status_out = status; A.stat = g->stat;
+    A.off = nullptr; A.n_total = 0;
     A.fast = (sigma != nullptr && sp_pred_lds(g->ld, true, true) <= 160u * 1024u) ? 1 : 0;
     const size_t lds = sp_pred_lds(g->ld, sigma != nullptr, A.fast != 0);
     // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
+    GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_predict_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int per_cu = (int)((160u * 1024u) / lds);
+    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    int grid = std::min(g->P, ctx->num_cus * per_cu);
+    hipLaunchKernelGGL(sparse_predict_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
+    GPC_HIP(ctx, hipGetLastError());
+    return GPC_OK;
+}
+
+// predict_measurements on every patch's OWN point set (ragged, like the add call's batch): the reference's per-patch training-set
+// RMS block (/root/reference/src/gp_compressor.cpp:303-315) calls gps[i].predict_measurements(f, X_i, sigma) exactly so.
+int gpc_sparse_predict_points_dev(gpc_sparse* g, const int32_t* off, int n_total, const double* x0, const double* x1,
+                                  double* f, double* sigma, int conf, int32_t* status)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
+    if (g->P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    if (n_total < 0) return gpc_fail(ctx, GPC_EINVAL, "negative size");
+    if (n_total > 0 && (!x0 || !x1 || !f)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/f is NULL");
+    if (g->P == 0) return GPC_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcp = gpc_debug_poison_lds(ctx)) return rcp;
+    SpPredParams A;
+    A.prm = g->prm;
+    A.c_exp = (double)(-0.5f) / g->prm.l_sq;
+    A.P = g->P; A.ny = g->ny; A.ld = g->ld; A.m = 0; A.conf = conf;
+    A.xs0 = x0; A.xs1 = x1; A.alpha = g->alpha; A.C = g->C; A.BV = g->BV; A.b = g->b;
+    A.f_star = f; A.sigma = sigma; A.status_out = status; A.stat = g->stat;
+    A.off = off; A.n_total = n_total;
+    A.fast = (sigma != nullptr && sp_pred_lds(g->ld, true, true) <= 160u * 1024u) ? 1 : 0;
+    const size_t lds = sp_pred_lds(g->ld, sigma != nullptr, A.fast != 0);
     GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_predict_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int per_cu = (int)((160u * 1024u) / lds);
@@ -1641,6 +1686,54 @@ int gpc_sparse_predict(gpc_sparse* g, int m, const double* xs0, const double* xs
     if (rc != GPC_OK) return rc;
     if (e != hipSuccess || e2 != hipSuccess)
         return gpc_fail(ctx, GPC_EHIP, "gpc_sparse_predict: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return GPC_OK;
+}
+
+int gpc_sparse_predict_points(gpc_sparse* g, const int32_t* off, const double* x0, const double* x1, double* f, double* sigma,
+                              int conf, int32_t* status)
+{
+    if (!g) return GPC_EINVAL;
+    gpc_ctx* ctx = g->ctx;
+    if (ctx->dead.load()) return GPC_EINVAL;   // the context went first: the object can only be destroyed (include/gpc.h)
+    const int P = g->P;
+    if (P > 0 && !off) return gpc_fail(ctx, GPC_EINVAL, "off is NULL");
+    if (P == 0) return GPC_OK;
+    if (off[0] != 0) return gpc_fail(ctx, GPC_EINVAL, "off[0] must be 0");
+    for (int i = 0; i < P; ++i)
+        if (off[i + 1] < off[i]) return gpc_fail(ctx, GPC_EINVAL, "off must be non-decreasing (patch %d)", i);
+    const size_t N = (size_t)off[P];
+    if (N > 0 && (!x0 || !x1 || !f)) return gpc_fail(ctx, GPC_EINVAL, "x0/x1/f is NULL");
+    GPC_HIP(ctx, hipSetDevice(ctx->device));
+    void *d_off = nullptr, *d_x0 = nullptr, *d_x1 = nullptr, *d_f = nullptr, *d_s = nullptr, *d_st = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {d_off, d_x0, d_x1, d_f, d_s, d_st})
+            if (p) (void)hipFree(p);
+    };
+    hipStream_t s = ctx->stream;
+    const size_t N1 = std::max<size_t>(N, 1);
+    hipError_t e = hipMalloc(&d_off, 4 * (size_t)(P + 1));
+    if (e == hipSuccess) e = hipMalloc(&d_x0, 8 * N1);
+    if (e == hipSuccess) e = hipMalloc(&d_x1, 8 * N1);
+    if (e == hipSuccess) e = hipMalloc(&d_f, 8 * N1 * g->ny);
+    if (e == hipSuccess && sigma) e = hipMalloc(&d_s, 8 * N1);
+    if (e == hipSuccess) e = hipMalloc(&d_st, 4 * (size_t)P);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off, 4 * (size_t)(P + 1), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && N) e = hipMemcpyAsync(d_x0, x0, 8 * N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && N) e = hipMemcpyAsync(d_x1, x1, 8 * N, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+        cleanup();
+        return gpc_fail(ctx, e == hipErrorOutOfMemory ? GPC_ENOMEM : GPC_EHIP, "gpc_sparse_predict_points: %s", hipGetErrorString(e));
+    }
+    int rc = gpc_sparse_predict_points_dev(g, (const int32_t*)d_off, (int)N, (const double*)d_x0, (const double*)d_x1, (double*)d_f,
+                                           (double*)d_s, conf, (int32_t*)d_st);
+    if (rc == GPC_OK && N) e = hipMemcpyAsync(f, d_f, 8 * N * g->ny, hipMemcpyDeviceToHost, s);
+    if (rc == GPC_OK && e == hipSuccess && sigma && N) e = hipMemcpyAsync(sigma, d_s, 8 * N, hipMemcpyDeviceToHost, s);
+    if (rc == GPC_OK && e == hipSuccess && status) e = hipMemcpyAsync(status, d_st, 4 * (size_t)P, hipMemcpyDeviceToHost, s);
+    hipError_t e2 = hipStreamSynchronize(s);
+    cleanup();
+    if (rc != GPC_OK) return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return gpc_fail(ctx, GPC_EHIP, "gpc_sparse_predict_points: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return GPC_OK;
 }
 

@@ -210,6 +210,13 @@ int gpc_sparse_predict(gpc_sparse* g, int m, const double* xs0, const double* xs
                        int conf, int32_t* status);
 int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double* xs1, double* f_star, double* sigma,
                            int conf, int32_t* status);
+/* predict_measurements(f, X_i, sigconf, conf) with every patch on ITS OWN point set (ragged like the add call's batch): what the
+ * reference's per-patch training-set RMS block does (src/gp_compressor.cpp:303-315, printed at :381).  Patch i reads rows
+ * off[i]..off[i+1]-1 of x0, x1 and writes the same rows of f (ny planes of n_total) and sigma (n_total, may be NULL). */
+int gpc_sparse_predict_points(gpc_sparse* g, const int32_t* off, const double* x0, const double* x1, double* f, double* sigma,
+                              int conf, int32_t* status);
+int gpc_sparse_predict_points_dev(gpc_sparse* g, const int32_t* off, int n_total, const double* x0, const double* x1,
+                                  double* f, double* sigma, int conf, int32_t* status);
 /* Registration inner loop: sparse_gp::compute_derivatives + compute_likelihoods
  * (src/sparse_gp.h:44-45 -> src/sparse_gp.hpp:387-427, 463-508; field: src/sparse_gp_field.h:40-41 -> .hpp:322-392; call site
  * src/gp_registration.cpp:175-195), batched over patches: patch i evaluates its own rows off[i]..off[i+1]-1 of x0, x1 and

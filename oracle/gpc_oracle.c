@@ -945,3 +945,44 @@ void orc_flatten_colors(const double* c3, uint8_t* rgb)
         rgb[i] = (uint8_t)v;
     }
 }
+
+/* ---- whole-batch driver of the sparse path: for every patch of a ragged batch, gp_compressor::train_processes' per-patch body
+ * (src/gp_compressor.cpp:146-163: add_measurements on the patch's rows, in the explicit insertion order, F7) followed by the
+ * per-patch body of load_compressed (src/gp_compressor.cpp:333: predict_measurements on the shared grid).  One call covers a
+ * patch range, so bench.py's cpu_baseline threads and the parity statistics of the tests spend their time in C, not in a
+ * Python loop.  perm (may be NULL = identity) holds patch-local row indices, laid out like the rows (perm + off[i]).
+ * f_star: P x ny x m; sigma (P x m), bv_count (P) and f_train (ny planes of N: the prediction at the patch's own points, the
+ * reference's training-set RMS block src/gp_compressor.cpp:303-315) may be NULL.  Returns 0, or -1 when an allocation fails. */
+int orc_sparse_fit_predict_batch(const orc_sparse_params* p, int max_bv, int P, const int32_t* off,
+                                 const double* x0, const double* x1, const double* y, const int32_t* perm,
+                                 int m, const double* xs0, const double* xs1,
+                                 double* f_star, double* sigma, int32_t* bv_count, double* f_train)
+{
+    const int ny = p->ny;
+    const size_t N = (size_t)off[P];
+    orc_sparse* g = orc_sparse_create(p, max_bv);
+    if (!g) return -1;
+    double yy[8];
+    for (int i = 0; i < P; ++i) {
+        orc_sparse_reset(g);
+        const int lo = off[i], n = off[i + 1] - off[i];
+        for (int t = 0; t < n; ++t) {
+            int r = lo + (perm ? perm[lo + t] : t);
+            for (int c = 0; c < ny; ++c) yy[c] = y[(size_t)c * N + (size_t)r];
+            orc_sparse_add(g, x0[r], x1[r], yy);
+        }
+        orc_sparse_predict(g, m, xs0, xs1, f_star + (size_t)i * (size_t)ny * (size_t)m, sigma ? sigma + (size_t)i * (size_t)m : NULL, 0);
+        if (bv_count) bv_count[i] = g->b;
+        if (f_train && n > 0) {
+            /* the reference's training-set RMS block (src/gp_compressor.cpp:303-315): predict_measurements on the patch's own X */
+            double* ft = (double*)malloc(sizeof(double) * (size_t)ny * (size_t)n);
+            if (!ft) { orc_sparse_destroy(g); return -1; }
+            orc_sparse_predict(g, n, x0 + lo, x1 + lo, ft, NULL, 0);
+            for (int c = 0; c < ny; ++c)
+                for (int t = 0; t < n; ++t) f_train[(size_t)c * N + (size_t)(lo + t)] = ft[(size_t)c * n + t];
+            free(ft);
+        }
+    }
+    orc_sparse_destroy(g);
+    return 0;
+}

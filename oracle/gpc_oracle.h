@@ -173,6 +173,17 @@ int orc_dense_fit_predict_batch(const orc_dense_params* p, int P, const int32_t*
                                 const double* x0, const double* x1, const double* y, int ny,
                                 int m, const double* xs0, const double* xs1,
                                 double* f_star, double* v_star, int32_t* status, double* alpha_out);
+/* sparse path for a ragged batch: per patch add_measurements (explicit patch-local insertion order, NULL = identity) then
+ * predict_measurements on the shared grid (src/gp_compressor.cpp:146-163, 333).  f_star P x ny x m; sigma (P x m) and
+ * bv_count (P) may be NULL.  hp_ = the binary128 arbiter running the same traversal. */
+int orc_sparse_fit_predict_batch(const orc_sparse_params* p, int max_bv, int P, const int32_t* off,
+                                 const double* x0, const double* x1, const double* y, const int32_t* perm,
+                                 int m, const double* xs0, const double* xs1,
+                                 double* f_star, double* sigma, int32_t* bv_count, double* f_train);
+int hp_sparse_fit_predict_batch(const orc_sparse_params* p, int max_bv, int P, const int32_t* off,
+                                const double* x0, const double* x1, const double* y, const int32_t* perm,
+                                int m, const double* xs0, const double* xs1,
+                                double* f_star, double* sigma, int32_t* bv_count, double* f_train);
 
 #ifdef __cplusplus
 }

@@ -284,3 +284,36 @@ void hp_sparse_get_state(const hp_sparse* g, double* alpha, double* C, double* Q
         }
     for (int i = 0; i < 2 * b; ++i) BV[i] = (double)g->BV[i];
 }
+
+/* the arbiter's twin of orc_sparse_fit_predict_batch (gpc_oracle.c): same arguments, same traversal, binary128 arithmetic */
+int hp_sparse_fit_predict_batch(const orc_sparse_params* p, int max_bv, int P, const int32_t* off,
+                                const double* x0, const double* x1, const double* y, const int32_t* perm,
+                                int m, const double* xs0, const double* xs1,
+                                double* f_star, double* sigma, int32_t* bv_count, double* f_train)
+{
+    const int ny = p->ny;
+    const size_t N = (size_t)off[P];
+    double yy[8];
+    for (int i = 0; i < P; ++i) {
+        hp_sparse* g = hp_sparse_create(p, max_bv);
+        if (!g) return -1;
+        const int lo = off[i], n = off[i + 1] - off[i];
+        for (int t = 0; t < n; ++t) {
+            int r = lo + (perm ? perm[lo + t] : t);
+            for (int c = 0; c < ny; ++c) yy[c] = y[(size_t)c * N + (size_t)r];
+            hp_add(g, x0[r], x1[r], yy);
+        }
+        hp_sparse_predict(g, m, xs0, xs1, f_star + (size_t)i * (size_t)ny * (size_t)m, sigma ? sigma + (size_t)i * (size_t)m : NULL);
+        if (bv_count) bv_count[i] = g->b;
+        if (f_train && n > 0) {
+            double* ft = (double*)malloc(sizeof(double) * (size_t)ny * (size_t)n);
+            if (!ft) { hp_sparse_destroy(g); return -1; }
+            hp_sparse_predict(g, n, x0 + lo, x1 + lo, ft, NULL);
+            for (int c = 0; c < ny; ++c)
+                for (int t = 0; t < n; ++t) f_train[(size_t)c * N + (size_t)(lo + t)] = ft[(size_t)c * n + t];
+            free(ft);
+        }
+        hp_sparse_destroy(g);
+    }
+    return 0;
+}

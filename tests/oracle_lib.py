@@ -129,6 +129,9 @@ def _bind(L):
     L.orc_sparse_likelihood.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.orc_sparse_train_sigmaf.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, d, C.c_int, c_dp, c_ip, c_dp, c_dp]
     L.orc_sparse_get_state.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp]
+    L.orc_sparse_fit_predict_batch.restype = C.c_int
+    L.orc_sparse_fit_predict_batch.argtypes = [C.POINTER(SparseParams), C.c_int, C.c_int, c_ip, c_dp, c_dp, c_dp, c_ip,
+                                               C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp]
     L.orc_sparse_get_counters.argtypes = [C.c_void_p, c_ip, c_ip, c_ip]
     L.orc_shuffle_libc.argtypes = [C.c_int, c_ip]
     L.orc_shuffle_stream.argtypes = [C.c_int, C.POINTER(C.c_uint32), c_ip]
@@ -316,6 +319,32 @@ class Sparse:
         return tuple(int(v) for v in a)
 
 
+def sparse_fit_predict_batch(p, off, x0, x1, y, xs0, xs1, perm=None, max_bv=None, sigma=False, fast=False, hp=False, train=False):
+    """Per patch of a ragged batch: add_measurements (patch-local insertion order `perm`, None = identity) + predict on the grid,
+    in ONE C call (oracle/gpc_oracle.c orc_sparse_fit_predict_batch; hp=True: the binary128 arbiter's twin).  y: (ny, N) planes.
+    ctypes releases the GIL for the call, so thread pools over patch ranges scale.  Returns f_star (P, ny, m), sigma (P, m)|None,
+    bv_count (P,) [, f_train (ny, N): the prediction at every patch's own points, when train=True]."""
+    off = np.ascontiguousarray(off, dtype=np.int32)
+    P = off.shape[0] - 1
+    y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.float64)
+    assert y.shape[0] == p.ny and y.shape[1] == int(off[-1]) and int(off[0]) == 0
+    m = xs0.shape[0]
+    if max_bv is None:
+        max_bv = (p.capacity + 2) if p.capacity > 0 else int(np.max(np.diff(off))) + 1
+    f = np.zeros((P, p.ny, m))
+    s = np.zeros((P, m)) if sigma else None
+    bv = np.zeros(P, dtype=np.int32)
+    ft = np.zeros_like(y) if train else None
+    pp = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+    fn = hp_lib().hp_sparse_fit_predict_batch if hp else lib(fast).orc_sparse_fit_predict_batch
+    rc = fn(C.byref(p), int(max_bv), P, _ip(off), _dp(np.ascontiguousarray(x0)), _dp(np.ascontiguousarray(x1)), _dp(y), _ip(pp),
+            m, _dp(np.ascontiguousarray(xs0)), _dp(np.ascontiguousarray(xs1)), _dp(f), _dp(s), _ip(bv), _dp(ft))
+    assert rc == 0
+    if train:
+        return f, s, bv, ft
+    return f, s, bv
+
+
 _hp = None
 
 
@@ -331,6 +360,9 @@ def hp_lib():
         L.hp_sparse_add_measurements.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_ip, C.c_void_p]
         L.hp_sparse_predict.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_dp]
         L.hp_sparse_get_state.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp]
+        L.hp_sparse_fit_predict_batch.restype = C.c_int
+        L.hp_sparse_fit_predict_batch.argtypes = [C.POINTER(SparseParams), C.c_int, C.c_int, c_ip, c_dp, c_dp, c_dp, c_ip,
+                                                  C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp]
         _hp = L
     return _hp
 
