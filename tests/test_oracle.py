@@ -598,3 +598,53 @@ def test_arbiter_default_hyperparameters_regime(oracle):
     assert 0.0 < np.mean(wrong_c) < 0.10
     assert np.median(err_c) <= 1e-2 and np.median(err_np) <= 1e-2 and max(err_c) <= 0.1 and max(err_np) <= 0.1
     assert len({b for b, _, _ in sizes}) <= 3 and len({c for _, c, _ in sizes}) >= 3     # exact: stable; fp64: scattered
+
+
+def test_sparse_batch_driver_equals_per_object_calls(oracle):
+    """orc_sparse_fit_predict_batch / hp_sparse_fit_predict_batch (the drivers behind bench.py's cpu_baseline and the parity
+    statistics of tests/sparse_parity.py) are the per-object calls in a loop: same bits, ragged batch, explicit order, ny = 1 and 3."""
+    from gp_compressor_amd import synth
+    for ny, cap in ((1, 12), (3, 9)):
+        off, x0, x1, y = synth.make_patches(6, 40, seed=70 + ny, ragged=True, ny=ny)
+        perm = synth.sattolo_perms(off, seed=5)
+        xs0, xs1 = oracle.grid(0.15, 6)
+        p = oracle.sparse_params(ny, p0=1.0, p1=(0.15 / 4) ** 2, s20=1e-3, capacity=cap)
+        f, s, bv, ft = oracle.sparse_fit_predict_batch(p, off, x0, x1, y, xs0, xs1, perm=perm, sigma=True, train=True)
+        fh, sh, bvh, fth = oracle.sparse_fit_predict_batch(p, off, x0, x1, y, xs0, xs1, perm=perm, sigma=True, train=True, hp=True)
+        for i in range(6):
+            sl = slice(off[i], off[i + 1])
+            g = oracle.Sparse(p, cap + 2)
+            g.add_measurements(x0[sl], x1[sl], y[:, sl], perm[sl])
+            fo, so = g.predict(xs0, xs1)
+            assert np.array_equal(f[i], fo) and np.array_equal(s[i], so) and bv[i] == g.size()
+            assert np.array_equal(ft[:, sl], g.predict(x0[sl], x1[sl])[0])
+            h = oracle.SparseHP(p, cap + 2)
+            h.add_measurements(x0[sl], x1[sl], y[:, sl], perm[sl])
+            fo, so = h.predict(xs0, xs1)
+            assert np.array_equal(fh[i], fo) and np.array_equal(sh[i], so) and bvh[i] == h.size()
+            assert np.array_equal(fth[:, sl], h.predict(x0[sl], x1[sl])[0])
+        if ny == 1:                                    # (the field variant's deletion multiplies where it should divide, F8: it diverges)
+            assert np.max(np.abs(f - fh)) <= 1e-6 * np.max(np.abs(fh))    # well conditioned: fp64 and binary128 agree
+
+
+def test_sparse_parity_statistics_gate(oracle):
+    """tests/sparse_parity.py on CPU-only inputs: with the oracle's own output standing in for the GPU the gate passes; a "GPU"
+    whose predictions are off by 20 % of the data range on every patch, or that blows up on a handful of patches, fails it."""
+    import sparse_parity as SP
+    from gp_compressor_amd import synth
+    P, n = 96, 64
+    off, x0, x1, y = synth.make_patches(P, n, seed=81)
+    xs0, xs1 = oracle.grid(0.15, 8)
+    op = oracle.sparse_params(1, capacity=50)                           # the reference's defaults
+    f, _, _, ft = oracle.sparse_fit_predict_batch(op, off, x0, x1, y, xs0, xs1, train=True)
+    st = SP.stats(op, off, x0, x1, y, xs0, xs1, f, ft, np.arange(64), threads=4)
+    assert st["gate"]["ok"], st["gate"]
+    assert st["rmse_train"]["gpu"] == st["rmse_train"]["oracle"] and st["blowups"]["gpu"] == st["blowups"]["oracle"]
+    bad = f + 0.2 * np.max(np.abs(y))
+    assert not SP.stats(op, off, x0, x1, y, xs0, xs1, bad, ft, np.arange(64), threads=4)["gate"]["ok"]
+    bad = f.copy()
+    bad[::8] *= 400.0
+    s2 = SP.stats(op, off, x0, x1, y, xs0, xs1, bad, ft, np.arange(64), threads=4)
+    assert not s2["gate"]["ok"] and s2["blowups"]["gpu"] >= 8 and len(s2["blowups"]["patches"]) >= 8
+    bad_t = ft * 1.5
+    assert not SP.stats(op, off, x0, x1, y, xs0, xs1, f, bad_t, np.arange(64), threads=4)["gate"]["ok"]

@@ -153,7 +153,10 @@ def test_sparse_online_growth_equals_one_shot(gp, oracle):
     # the same statement as test_sparse_gpu_vs_arbiter makes (RMS and median over the patches: medians ~3e-7, the worst patch of 64
     # ~1e-5 .. 1e-4 for the GPU and for the CPU oracle alike, tools/sparse_vs_arbiter.py -- the error is the conditioning of Q
     # times the rounding of ONE summation order, and it is not the same patch for the two)
-    assert rms(e_gpu) <= 3.0 * rms(e_orc) + 2e-6 and np.median(e_gpu) <= 3.0 * np.median(e_orc) + 2e-6 and e_gpu.max() <= 2e-4
+    # The worst patch is bounded against the oracle's worst too (tests/sparse_parity.py MAX_FACTOR), not by a constant: a kernel
+    # change that makes the single worst patch 10x worse than the CPU's worst fails here.
+    assert rms(e_gpu) <= 3.0 * rms(e_orc) + 2e-6 and np.median(e_gpu) <= 3.0 * np.median(e_orc) + 2e-6
+    assert e_gpu.max() <= 10.0 * e_orc.max() + 2e-6, (e_gpu.max(), e_orc.max())
     # reset() (src/sparse_gp.hpp:573-582)
     g2.reset()
     assert np.all(g2.sizes() == 0)
@@ -198,6 +201,71 @@ def test_sparse_defaults_regime_batch(gp, oracle):
     assert g.sizes().max() <= 40 and bo.max() <= 40
     rms = lambda a: float(np.sqrt(np.mean(a * a)))
     assert rms(f - fo) <= 2e-2 * max(rms(fo), 1e-6)
+    g.close()
+
+
+def test_sparse_predict_points_vs_oracle_and_grid_entry(gp, oracle):
+    """gpc_sparse_predict_points = predict_measurements with every patch on its own (ragged) point set, what the reference's
+    training-set RMS block does (src/gp_compressor.cpp:303-315).  Against the oracle, and bit for bit against the shared-grid entry
+    called with one patch's points as the grid; empty patches; sigma and the 3-channel variant."""
+    capi, ctx = gp
+    for ny, cap in ((1, 20), (3, 12)):
+        P, n, res = 9, 70, 0.15
+        off, x0, x1, y = synth.make_patches(P, n, res=res, seed=90 + ny, ragged=True, ny=ny)
+        off = off.copy()
+        off[4:] -= off[4] - off[3]                                   # patch 3 is empty
+        N = int(off[-1])
+        x0, x1, y = x0[:N].copy(), x1[:N].copy(), np.ascontiguousarray(y[:, :N])
+        kw = dict(sigmaf_sq=1.0, l_sq=(res / 4) ** 2, noise=1e-3, capacity=cap)
+        g = capi.Sparse(ctx, capi.default_params_sparse(ny, **kw), P, ny)
+        g.add(off, x0, x1, y)
+        ft, st_, stat = g.predict_points(off, x0, x1, want_sigma=True)
+        assert ft.shape == (ny, N) and np.all(stat == 0) and np.all(np.isfinite(ft)) and np.all(np.isfinite(st_))
+        op = oracle.sparse_params(ny, p0=1.0, p1=kw["l_sq"], s20=1e-3, capacity=cap)
+        xs0, xs1 = synth.grid(res, 4)
+        _, _, bo, fto = oracle.sparse_fit_predict_batch(op, off, x0, x1, y, xs0, xs1, train=True)
+        assert np.array_equal(g.sizes(), bo)
+        assert np.max(np.abs(ft - fto)) <= 2e-5 * np.max(np.abs(fto))
+        for i in (0, 5, P - 1):
+            sl = slice(off[i], off[i + 1])
+            fg, sg, _ = g.predict(x0[sl], x1[sl])                    # shared-grid entry, X* = patch i's own points
+            assert np.array_equal(fg[i], ft[:, sl]) and np.array_equal(sg[i], st_[sl])
+        g.close()
+
+
+def test_sparse_c4_defaults_full_size_parity(gp, oracle):
+    """BASELINE config 4 at the reference's DEFAULT hyper-parameters (src/sparse_gp.h:48, src/rbf_kernel.h:24) -- the production
+    regime, where `gamma < eps_tol` (src/sparse_gp.hpp:144-163) is decided by rounding noise -- at the full 32768 x 256 size, 4 add
+    calls.  The parity statement is tests/sparse_parity.py's: (a) reconstruction RMSE against the training targets for the GPU, the
+    fp64 oracle and the binary128 arbiter ("matched RMSE"), (b) per-patch error against the arbiter as percentiles, (c) predictions
+    that leave the data range -- and the GPU may not be worse than the fp64 oracle by more than the frozen factors.
+    Measured (round 3, gpurun_out/r3/c4_parity_defaults.json; 1024-patch arbiter sample, oracle on all 32768):
+      rmse_train  GPU 4.113e-3  oracle 4.098e-3  arbiter 4.098e-3   (y rms 6.14e-3)
+      |f* - f*_exact| per patch  p50 / p90 / p99 / max:  GPU 1.3e-5 / 1.5e-4 / 1.5e-3 / 1.9e-2   oracle 1.6e-5 / 1.9e-4 / 1.7e-3 / 1.4e-2
+      max|f*| > 5 max|y|:  GPU 4 of 32768 (worst: patch 21588, 21.6x -- the 0.32 outlier of round 2's bench line),  oracle 1 of 32768
+      (patch 16515, 11.9x), arbiter 0: on every such patch the OTHER fp64 implementation and the exact recursion stay below 0.6x,
+      i.e. the blow-ups are rounding artefacts of one summation order each, and they happen to the CPU restatement too."""
+    import sparse_parity as SP
+    capi, ctx = gp
+    res, sz, P, n, cap, chunks = 0.15, 20, 32768, 256, 200, 4
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=4)
+    prm = capi.default_params_sparse(1, capacity=cap)
+    g = capi.Sparse(ctx, prm, P, 1)
+    cn = n // chunks
+    coff = (np.arange(P + 1) * cn).astype(np.int32)
+    for c in range(chunks):
+        idx = (off[:-1, None] + np.arange(c * cn, (c + 1) * cn)[None, :]).reshape(-1)
+        assert np.all(g.add(coff, x0[idx], x1[idx], y[:, idx]) == 0)
+    xs0, xs1 = synth.grid(res, sz)
+    f, _, st2 = g.predict(xs0, xs1, want_sigma=False)
+    ft, _, st3 = g.predict_points(off, x0, x1)
+    assert np.all(st2 == 0) and np.all(st3 == 0) and np.all(np.isfinite(f)) and np.all(np.isfinite(ft))
+    bv = g.sizes()
+    assert 8 <= bv.mean() <= 25 and bv.max() <= 64                 # the basis stays tiny whatever the capacity
+    op = oracle.sparse_params(1, p0=prm.sigmaf_sq, p1=prm.l_sq, s20=prm.noise, eps_tol=prm.eps_tol, capacity=cap)
+    st = SP.stats(op, off, x0, x1, y, xs0, xs1, f, ft, np.arange(1024), full_oracle=True)
+    print("C4 defaults, full size:", {k: st[k] for k in ("rmse_train", "err_vs_arbiter_abs", "blowups", "gate")})
+    assert st["gate"]["ok"], st["gate"]["why"]
     g.close()
 
 
