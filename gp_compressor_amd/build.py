@@ -39,15 +39,33 @@ def build(force=False, verbose=False, extra_flags=(), lib=None):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libgpc_hip.so (and there is no CPU fallback)")
-    objs = []
+    # an object is rebuilt when its source, any header of csrc/ or include/gpc.h is newer (or always with force / for a variant);
+    # the translation units compile side by side (the big kernels take a minute each)
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
+        [os.path.join(os.path.dirname(HERE), "include", "gpc.h"), os.path.abspath(__file__)]
+    t_hdr = max(os.path.getmtime(h) for h in hdrs)
+    objs, jobs = [], []
     for src in sources():
         obj = os.path.splitext(src)[0] + tag + ".o"
+        objs.append(obj)
+        if not force and not tag and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), t_hdr):
+            continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-c", src, "-o", obj, *extra_flags]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        jobs.append(cmd)
+    nproc = max(1, min(len(jobs), int(os.environ.get("GPC_BUILD_JOBS", str(min(8, os.cpu_count() or 1))))))
+    running = []
+    while jobs or running:
+        while jobs and len(running) < nproc:
+            c = jobs.pop(0)
+            running.append((c, subprocess.Popen(c)))
+        c, pr = running.pop(0)
+        if pr.wait() != 0:
+            for _, other in running:
+                other.kill()
+            raise subprocess.CalledProcessError(pr.returncode, c)
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target + ".tmp", *objs, "-ldl"]
     subprocess.check_call(cmd)
     os.replace(target + ".tmp", target)

@@ -115,6 +115,7 @@ PROTOTYPES = {
     "gpc_unpermute_fstar_dev": (C.c_int, [_vp, _i, _vp, _vp]),
     "gpc_test_exp_host": (None, [_vp, _vp, _i]),
     "gpc_test_exp_small_host": (None, [_vp, _vp, _i]),
+    "gpc_test_par_memcpy": (None, [_vp, _vp, C.c_size_t]),
 }
 
 _lib = None

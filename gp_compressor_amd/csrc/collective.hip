@@ -161,7 +161,13 @@ int gpc_comm_create_all(int ndev, gpc_ctx* const* ctxs, gpc_comm** out)
     if (rc != 0) return gpc_fail(ctxs[0], GPC_EHIP, "ncclCommInitAll: %s", R->GetErrorString ? R->GetErrorString(rc) : "error");
     for (int i = 0; i < ndev; ++i) {
         const int r2 = comm_wrap(ctxs[i], cs[i], true, ndev, i, &out[i]);
-        if (r2 != GPC_OK) return r2;
+        if (r2 != GPC_OK) {
+            // all or nothing: the wrapped ones go (with their context references), the raw communicators not yet wrapped too
+            for (int j = 0; j < i; ++j) { gpc_comm_destroy(out[j]); out[j] = nullptr; }
+            for (int j = i; j < ndev; ++j)
+                if (cs[j] && R->CommDestroy) (void)R->CommDestroy(cs[j]);
+            return r2;
+        }
     }
     return GPC_OK;
 }

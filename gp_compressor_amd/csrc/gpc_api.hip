@@ -317,12 +317,20 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
             // the tail of one kernel -- its last workgroups running on a mostly idle chip -- fills with the next one's work.
             const bool fork = !getenv("GPC_NO_FORK");
             hipStream_t main_s = ctx->stream;
+            bool forked = false;
+            // an error after the fork must not leave work (or the caller's buffers) in flight on the side streams
+            auto bail = [&](int code) {
+                ctx->stream = main_s;
+                if (forked) { (void)hipStreamSynchronize(ctx->s_in); (void)hipStreamSynchronize(ctx->s_out); }
+                return code;
+            };
             if (fork) {
                 rc = gpc_aux_streams(ctx);
                 if (rc != GPC_OK) return rc;
                 GPC_HIP(ctx, hipEventRecord(ctx->ev[0][5], main_s));
                 GPC_HIP(ctx, hipStreamWaitEvent(ctx->s_in, ctx->ev[0][5], 0));
                 GPC_HIP(ctx, hipStreamWaitEvent(ctx->s_out, ctx->ev[0][5], 0));
+                forked = true;
             }
             // largest patches first: the tiled kernel's workgroups are the long ones
             if (need_big) {
@@ -331,7 +339,7 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
                 if (fork) ctx->stream = ctx->s_out;
                 rc = dense_big_launch(ctx, b, grid_b);
                 ctx->stream = main_s;
-                if (rc != GPC_OK) return rc;
+                if (rc != GPC_OK) return bail(rc);
             }
             // Class sizes known on the host (the batch came from gpc_project_cloud on this context): launch exactly that many
             // workgroups.  Otherwise P per class -- the ones beyond the class count leave at once, but each still waits for a CU
@@ -347,14 +355,14 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
                 if (fork) ctx->stream = ctx->s_in;
                 rc = dense_mfma_launch(ctx, s);
                 ctx->stream = main_s;
-                if (rc != GPC_OK) return rc;
+                if (rc != GPC_OK) return bail(rc);
             }
             if (c0 > 0) {
                 s.n_max = 256;
                 s.sel = sel0; s.sel_count = counts;
                 s.P = c0;
                 rc = dense_mfma_launch(ctx, s);
-                if (rc != GPC_OK) return rc;
+                if (rc != GPC_OK) return bail(rc);
             }
             if (fork) {
                 GPC_HIP(ctx, hipEventRecord(ctx->ev[1][5], ctx->s_in));
@@ -432,6 +440,9 @@ public:
     void copy(void* dst, const void* src, size_t bytes)
     {
         if (bytes < (1u << 20) || th_.empty()) { std::memcpy(dst, src, bytes); return; }
+        // One request at a time: the pool is process-wide while the callers' lock (ctx->host_mu) is per context, so two threads on
+        // two contexts do get here together; the request fields below are shared with the workers.
+        std::lock_guard<std::mutex> call(call_mu_);
         std::unique_lock<std::mutex> lk(m_);
         dst_ = (char*)dst; src_ = (const char*)src; bytes_ = bytes;
         remaining_ = (int)th_.size();
@@ -482,7 +493,7 @@ private:
         }
     }
     std::vector<std::thread> th_;
-    std::mutex m_;
+    std::mutex m_, call_mu_;
     std::condition_variable cv_, done_;
     char* dst_ = nullptr;
     const char* src_ = nullptr;
@@ -493,6 +504,7 @@ private:
 };
 }  // namespace
 static void par_memcpy(void* dst, const void* src, size_t bytes) { CopyPool::get().copy(dst, src, bytes); }
+extern "C" void gpc_test_par_memcpy(void* dst, const void* src, size_t bytes) { par_memcpy(dst, src, bytes); }   // host-only test hook
 
 static bool is_pinned(const void* p)
 {
@@ -576,7 +588,11 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
     int32_t* h_st = (int32_t*)ho; ho += b_st;
     double* h_f = (double*)ho; ho += pin_f ? 0 : b_f;
     double* h_v = (double*)ho;
-    hipStream_t sc = ctx->stream, si = ctx->s_in, so = ctx->s_out;
+    hipStream_t sc, si = ctx->s_in, so = ctx->s_out;
+    {   // dense_dispatch swaps ctx->stream for a moment while it forks (under ctx->mu): never read it half-way
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        sc = ctx->stream;
+    }
     // the arena may still be read by work a previous call left on the compute stream
     GPC_HIP(ctx, hipEventRecord(ctx->ev[0][7], sc));
     GPC_HIP(ctx, hipStreamWaitEvent(si, ctx->ev[0][7], 0));

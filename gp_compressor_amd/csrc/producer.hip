@@ -642,7 +642,10 @@ void gpc_patches_destroy(gpc_patches* o)
     if (!o) return;
     gpc_ctx* ctx = o->ctx;
     if (ctx) (void)hipSetDevice(ctx->device);
-    if (ctx && ctx->hint_off == o->v.off) ctx->hint_off = nullptr;
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->mu);       // dense_dispatch reads the hint under the same lock
+        if (ctx->hint_off == o->v.off) ctx->hint_off = nullptr;
+    }
     if (o->block) (void)hipFree(o->block);
     delete o;
     if (ctx) gpc_ctx_unref(ctx);

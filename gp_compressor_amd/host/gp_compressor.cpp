@@ -133,10 +133,20 @@ void gp_compressor::train_dense_sharded()
 {
     const int P = batch_.patches(), m = sz_ * sz_, world = (int)devices_.size();
     if (shard_ctx_.empty()) {
-        shard_ctx_.assign(world, nullptr);
-        for (int r = 0; r < world; ++r) check(gpc_ctx_create(&shard_ctx_[r], devices_[r]), nullptr, "gpc_ctx_create (shard)");
-        shard_comm_.assign(world, nullptr);
-        check(gpc_comm_create_all(world, shard_ctx_.data(), shard_comm_.data()), shard_ctx_[0], "gpc_comm_create_all");
+        // built into locals and committed to the members only when every context and communicator exists: a failure half-way
+        // leaves the object in its single-device state, never with null handles that a later call would pass on
+        std::vector<gpc_ctx*> ctxs(world, nullptr);
+        std::vector<gpc_comm*> comms(world, nullptr);
+        try {
+            for (int r = 0; r < world; ++r) check(gpc_ctx_create(&ctxs[r], devices_[r]), nullptr, "gpc_ctx_create (shard)");
+            check(gpc_comm_create_all(world, ctxs.data(), comms.data()), ctxs[0], "gpc_comm_create_all");
+        } catch (...) {
+            for (gpc_comm* c : comms) if (c) gpc_comm_destroy(c);
+            for (gpc_ctx* c : ctxs) if (c) gpc_ctx_destroy(c);
+            throw;
+        }
+        shard_ctx_.swap(ctxs);
+        shard_comm_.swap(comms);
     }
     const int S = (P + world - 1) / world;
     std::vector<int32_t> slots((size_t)S * world);
@@ -150,6 +160,7 @@ void gp_compressor::train_dense_sharded()
         void *d_lf = nullptr, *d_lc = nullptr, *d_gf = nullptr, *d_gc = nullptr, *d_f = nullptr, *d_c = nullptr;
     };
     std::vector<Shard> sh(world);
+    bool in_group = false;                    // an RCCL group left open would swallow every later collective of the process
     auto free_all = [&]() {
         for (int r = 0; r < world; ++r)
             for (void* q : {sh[r].d_off, sh[r].d_x0, sh[r].d_x1, sh[r].d_y, sh[r].d_rgb, sh[r].d_st, sh[r].d_lf, sh[r].d_lc, sh[r].d_gf,
@@ -212,10 +223,12 @@ void gp_compressor::train_dense_sharded()
         }
         // the one exchange: all-gather of the depth grids and of the colour grids (inside one bracket: one fused exchange)
         check(gpc_group_start(), shard_ctx_[0], "gpc_group_start");
+        in_group = true;
         for (int r = 0; r < world; ++r) {
             check(gpc_allgather_fstar_dev(shard_comm_[r], m, (const double*)sh[r].d_lf, (double*)sh[r].d_gf, nullptr), shard_ctx_[r], "all-gather f*");
             check(gpc_allgather_fstar_dev(shard_comm_[r], 3 * m, (const double*)sh[r].d_lc, (double*)sh[r].d_gc, nullptr), shard_ctx_[r], "all-gather c*");
         }
+        in_group = false;
         check(gpc_group_end(), shard_ctx_[0], "gpc_group_end");
         // device 0 un-permutes to patch order and hands the grids to the host flow (load_compressed reprojects them)
         check(gpc_unpermute_fstar_dev(shard_comm_[0], m, (const double*)sh[0].d_gf, (double*)sh[0].d_f), shard_ctx_[0], "un-permute f*");
@@ -234,6 +247,8 @@ void gp_compressor::train_dense_sharded()
         }
         for (int r = 0; r < world; ++r) check(gpc_ctx_synchronize(shard_ctx_[r]), shard_ctx_[r], "gpc_ctx_synchronize");
     } catch (...) {
+        if (in_group) (void)gpc_group_end();
+        for (int r = 0; r < world; ++r) (void)gpc_ctx_synchronize(shard_ctx_[r]);    // nothing may still read the buffers freed below
         free_all();
         throw;
     }

@@ -352,6 +352,8 @@ void gpc_test_exp_host(const double* x, double* out, int n);
 /* Same for the small-argument polynomial (-2^-5 <= x <= 0) the register-tile kernel switches to when the patch extent
  * proves the range. */
 void gpc_test_exp_small_host(const double* x, double* out, int n);
+/* the multi-threaded staging copy of the host-pointer entries (pageable caller buffers), callable without a GPU: concurrency test */
+void gpc_test_par_memcpy(void* dst, const void* src, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -107,3 +107,30 @@ def test_partition_patches(capi):
     assert slots.shape == (4, 3) and (slots < 0).sum() == 2
     with pytest.raises(capi.GpcError):
         capi.partition_patches(off, 0)
+
+
+def test_staging_copy_is_safe_from_two_threads(capi):
+    """The staging copy of the host-pointer entries is one process-wide thread pool, while the entries serialise per context
+    (include/gpc.h: thread-safe per context): two threads on two contexts reach it together.  Two threads hammer it with different
+    buffers; every copy must arrive intact and nobody may dead-lock (the request fields were shared unguarded)."""
+    import threading
+    lib = capi.load()
+    n = (3 << 20) // 8 + 123                     # > 1 MB: the multi-threaded path
+    bad, done = [], []
+
+    def worker(seed):
+        rng = np.random.default_rng(seed)
+        for it in range(40):
+            src = rng.integers(0, 2 ** 62, size=n, dtype=np.int64)
+            dst = np.zeros_like(src)
+            lib.gpc_test_par_memcpy(dst.ctypes.data, src.ctypes.data, src.nbytes)
+            if not np.array_equal(src, dst):
+                bad.append((seed, it))
+        done.append(seed)
+    ths = [threading.Thread(target=worker, args=(s,), daemon=True) for s in (1, 2, 3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert sorted(done) == [1, 2, 3], "a copy never returned (lost wake-up)"
+    assert not bad, bad
