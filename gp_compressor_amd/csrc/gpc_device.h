@@ -99,7 +99,7 @@ __device__ static inline void gpc_exp_table_init(double* T_lds)
 __device__ static inline double gpc_rbf(double sf, double c, double xi0, double xi1, double xj0, double xj1, const double* T)
 {
     double d0 = xi0 - xj0, d1 = xi1 - xj1;
-    double sq = d0 * d0 + d1 * d1;
+    double sq = __builtin_fma(d0, d0, d1 * d1);   // explicit: left to the compiler, WHICH product is fused differs from one inlining context to the next
     return sf * gpc_exp_tbl(c * sq, T);
 }
 
@@ -107,14 +107,14 @@ __device__ static inline double gpc_rbf(double sf, double c, double xi0, double 
 __device__ static inline double gpc_rbf_neg(double sf, double c, double xi0, double xi1, double xj0, double xj1, const double* T)
 {
     double d0 = xi0 - xj0, d1 = xi1 - xj1;
-    double sq = d0 * d0 + d1 * d1;
+    double sq = __builtin_fma(d0, d0, d1 * d1);   // explicit: left to the compiler, WHICH product is fused differs from one inlining context to the next
     return sf * gpc_exp_neg(c * sq, T);
 }
 
 __device__ static inline double gpc_rbf_small(double sf, double c, double xi0, double xi1, double xj0, double xj1)
 {
     double d0 = xi0 - xj0, d1 = xi1 - xj1;
-    double sq = d0 * d0 + d1 * d1;
+    double sq = __builtin_fma(d0, d0, d1 * d1);   // explicit: left to the compiler, WHICH product is fused differs from one inlining context to the next
     return sf * gpc_exp_small(c * sq);
 }
 

@@ -628,7 +628,7 @@ size_t carve_scratch(Carver& c, Scratch& s, size_t n, size_t pb, size_t prim_byt
     do {                                                                                                       \
         hipError_t e_ = (call);                                                                                \
         if (e_ != hipSuccess) {                                                                                \
-            gpc_patches_destroy(o);                                                                            \
+            pc_patches_release(o);                                                                            \
             return gpc_fail(ctx, e_ == hipErrorOutOfMemory ? GPC_ENOMEM : GPC_EHIP, "gpc_project_cloud: %s failed: %s", \
                             #call, hipGetErrorString(e_));                                                     \
         }                                                                                                      \
@@ -637,18 +637,29 @@ size_t carve_scratch(Carver& c, Scratch& s, size_t n, size_t pb, size_t prim_byt
 extern "C" {
 
 // Safe in either order with gpc_ctx_destroy (the batch holds a reference on its context; hipFree synchronises the device).
-void gpc_patches_destroy(gpc_patches* o)
+// the caller holds ctx->mu (or the object was never published): the error paths of gpc_project_cloud_dev end here
+static void pc_patches_release(gpc_patches* o)
 {
     if (!o) return;
     gpc_ctx* ctx = o->ctx;
     if (ctx) (void)hipSetDevice(ctx->device);
-    if (ctx) {
-        std::lock_guard<std::mutex> lk(ctx->mu);       // dense_dispatch reads the hint under the same lock
-        if (ctx->hint_off == o->v.off) ctx->hint_off = nullptr;
-    }
+    if (ctx && ctx->hint_off == o->v.off) ctx->hint_off = nullptr;
     if (o->block) (void)hipFree(o->block);
     delete o;
     if (ctx) gpc_ctx_unref(ctx);
+}
+
+void gpc_patches_destroy(gpc_patches* o)
+{
+    if (!o) return;
+    gpc_ctx* ctx = o->ctx;
+    if (!ctx) { pc_patches_release(o); return; }
+    gpc_ctx_ref(ctx);                                  // the release may drop the last reference while the lock is held
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);       // dense_dispatch reads the size-class hint under the same lock
+        pc_patches_release(o);
+    }
+    gpc_ctx_unref(ctx);
 }
 
 int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, double res, int sz, gpc_patches** out)
@@ -682,7 +693,7 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
     // 1: bounds (its 32 bytes of scratch sit at the start of the workspace whatever the leaf bound turns out to be)
     {
         const int rc = gpc_ws_reserve(ctx, 4096);
-        if (rc != GPC_OK) { gpc_patches_destroy(o); return rc; }
+        if (rc != GPC_OK) { pc_patches_release(o); return rc; }
     }
     uint32_t* d_bounds = static_cast<uint32_t*>(ctx->ws);
     const uint32_t init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0, 0, 0};
@@ -693,7 +704,7 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
     PC_HIP(hipMemcpyAsync(hb, d_bounds, sizeof(hb), hipMemcpyDeviceToHost, st));
     PC_HIP(hipStreamSynchronize(st));
     if (hb[6]) {
-        gpc_patches_destroy(o);
+        pc_patches_release(o);
         return gpc_fail(ctx, GPC_EINVAL, "the cloud holds a non-finite coordinate");
     }
     PcGrid g;
@@ -706,7 +717,7 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
         g.mn[a] = (double)pc_unordered(hb[a]);
         const double ext = std::floor(((double)pc_unordered(hb[3 + a]) - g.mn[a]) / res);
         if (!(ext < 2097152.0)) {
-            gpc_patches_destroy(o);
+            pc_patches_release(o);
             return gpc_fail(ctx, GPC_ERANGE, "more than 2^21 voxels of side res along an axis");
         }
         g.kmax[a] = (int)ext;
@@ -727,7 +738,7 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
     {
         Carver measure(nullptr);
         const int rc = gpc_ws_reserve(ctx, carve_scratch(measure, S, N, pb, prim_bytes));
-        if (rc != GPC_OK) { gpc_patches_destroy(o); return rc; }
+        if (rc != GPC_OK) { pc_patches_release(o); return rc; }
         Carver c(ctx->ws);
         carve_scratch(c, S, N, pb, prim_bytes);
     }
@@ -748,11 +759,11 @@ int gpc_project_cloud_dev(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, do
     PC_HIP(hipGetLastError());
     PC_HIP(hipStreamSynchronize(st));
     if ((long long)P * (long long)(sz * sz) > 0x7fffffffLL) {
-        gpc_patches_destroy(o);
+        pc_patches_release(o);
         return gpc_fail(ctx, GPC_ERANGE, "P * sz * sz exceeds 2^31-1");
     }
     if ((size_t)P > pb) {
-        gpc_patches_destroy(o);
+        pc_patches_release(o);
         return gpc_fail(ctx, GPC_EHIP, "internal: %d leaves exceed the bound %zu", (int)P, pb);
     }
 

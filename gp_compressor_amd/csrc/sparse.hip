@@ -27,7 +27,8 @@ struct gpc_sparse {
     int P, ny, ld;
     double *alpha, *C, *Q, *BV;
     int32_t *b, *count, *stat;
-    int32_t* done_it;   // P: hand-over between the small-basis phase and the regular add kernel (allocated with the object)
+    int32_t* done_it;   // P: hand-over between the phases of an add call (allocated with the object)
+    int32_t* list;      // P + 4: work list of the phases after the rows phase, then its length and three ticket counters
     uint8_t* trace;     // diagnostic (gpc_sparse_set_trace): device buffer for the decision bytes of the next add calls, or nullptr
 };
 
@@ -426,6 +427,12 @@ struct SpAddParams {
     const int32_t* start_it;   // per patch: points of this call already consumed by the small-basis kernel (nullptr: 0)
     int32_t* done_it;          // small-basis kernel only: how many points of this call it consumed
     uint8_t* trace;            // diagnostic: one decision byte per point of the call, in insertion order (or nullptr)
+    // work list of the phases after the rows phase: the patches it did not finish, in the order they were handed over.  The kernels
+    // that follow take list entries by ticket (one atomic per patch) instead of a static share of all P patches: only a fifth of the
+    // patches reach them, and with static shares the wave that happens to own eight of those decides the launch time.
+    int32_t* list;             // [P] patch ids (nullptr: static shares)
+    int32_t* list_n;           // [0] entries in `list`, [1], [3] ticket counters of the small-basis and the regular launch
+    int ticket_slot;           // which counter this launch draws from
 };
 
 // Small-basis phase.  With the reference's default hyper-parameters the basis stays at a dozen vectors whatever the capacity,
@@ -470,7 +477,19 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
     const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, eps_tol = A.prm.eps_tol;
     const int capacity = A.prm.capacity;
 
-    for (int patch = blockIdx.x; patch < A.P; patch += gridDim.x) {
+    int* s_ticket = reinterpret_cast<int*>(red + 15);             // (the last slot of the reduction scratch is never used: <= 3 sums x 4 waves)
+    for (int slot = blockIdx.x;; slot += gridDim.x) {
+        int patch = slot;
+        if (A.list) {                                                // work list: the next entry nobody has taken yet
+            __syncthreads();
+            if (tid == 0) *s_ticket = atomicAdd(A.list_n + A.ticket_slot, 1);
+            __syncthreads();
+            const int idx = *s_ticket;
+            if (idx >= A.list_n[0]) break;
+            patch = A.list[idx];
+        } else if (patch >= A.P) {
+            break;
+        }
         const int o = A.off[patch], n = A.off[patch + 1] - o;
         SpState S;
         S.ld = ld; S.ny = ny; S.ldm = ldm;
@@ -484,13 +503,13 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
         S.BV = BVL;
         int b = A.b[patch];
         int st = A.stat[patch];
-        const int it0 = (!SMALL && A.start_it) ? A.start_it[patch] : 0;     // the small-basis phase already took these
+        const int it0 = A.start_it ? A.start_it[patch] : 0;     // an earlier phase (rows / small-basis) already took these
         __syncthreads();
         if (SMALL && (b > SP_BMAX || n == 0)) {          // too large from the start (or nothing to do): all of it is the regular kernel's
-            if (tid == 0) A.done_it[patch] = 0;
+            if (tid == 0) A.done_it[patch] = it0;
             continue;
         }
-        if (!SMALL && A.start_it && n > 0 && it0 >= n) continue;  // the small-basis phase finished this patch (and wrote its state and status)
+        if (A.start_it && n > 0 && it0 >= n) continue;   // an earlier phase finished this patch (and wrote its state, status and done_it)
         for (int i = tid; i < b; i += SP_NTH) {
             BVL[2 * i] = BVg[2 * i];
             BVL[2 * i + 1] = BVg[2 * i + 1];
@@ -780,10 +799,358 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
         }
         if (tid == 0) {
             A.b[patch] = b;
-            A.count[patch] += (SMALL ? it_end : n) - it0;
+            A.count[patch] += it_end - it0;
             A.stat[patch] = st;
             if (A.status_out) A.status_out[patch] = st;
         }
+    }
+}
+
+// ---- rows phase: SEVERAL PATCHES PER WAVE -----------------------------------------------------------------------------
+// With the reference's default hyper-parameters (src/rbf_kernel.h:24, src/sparse_gp.h:48) a patch keeps about 13 basis vectors
+// and 95 % of its points take the projected update (src/sparse_gp.hpp:155-163): one wave per patch leaves 50 of 64 lanes idle
+// and the pass is bound by the instruction count of a point's serial skeleton.  Here a patch owns G = 16 (or 32) lanes -- a DPP
+// row, where the reductions of a point already live (sp_wave_sum_dpp) -- so a wave carries 4 (2) patches through the same
+// instruction stream.  Lane i of a patch holds row i of the basis (k_i, (C k)_i, e_hat_i, alpha_i, BV_i in registers); C and Q
+// are G x G blocks in LDS; the lanes of different patches diverge only where their branch decisions differ (predication).
+// The phase covers what needs no dynamic row movement -- first point, projected updates, and full updates that keep the
+// basis within G vectors and trigger no deletion -- and hands a patch over (state written back, points consumed in done_it)
+// BEFORE the first point that needs anything else; sparse_add_kernel<true> continues from there, then the regular kernel.
+// A geometric deletion (src/sparse_gp.hpp:226-242) can only follow a full update (the projected update leaves Q alone), and
+// whether one would follow is decided from the updated diagonal before anything is written.
+// Same operations in the same order per patch as sparse_add_kernel (quarter-wise mat-vec sums, DPP row sums, the next
+// point's mat-vecs formed from the updated values): the states are the same bit for bit
+// (tests/test_sparse_gpu.py::test_sparse_rows_phase_is_bit_identical).  Gaussian noise only.
+template <int G>
+__device__ static __forceinline__ double sp_row_sum(double v)
+{
+    v += sp_dpp<0xB1>(v);      // the four steps of sp_wave_sum_dpp inside the row of 16
+    v += sp_dpp<0x4E>(v);
+    v += sp_dpp<0x141>(v);
+    v += sp_dpp<0x140>(v);
+    if (G == 32) v += __shfl_xor(v, 16, 64);           // (row 0 + row 16): the first pair of sp_wave_sum_dpp
+    // the absent rows of the one-patch-per-wave layout hold +0.0 terms: (R + 0.0) + (0.0 + 0.0), then the +0.0 of the one-wave shape
+    return v + 0.0;
+}
+
+#define SP_FOR_C(c) _Pragma("unroll") for (int c = 0; c < 3; ++c) if (c < ny)   /* static index: the planes stay in registers */
+template <int G>
+__global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
+{
+    constexpr int R = 64 / G, QN = G / 4;
+    constexpr int UNR = G == 16 ? QN : 2;                        // trips of the column loops unrolled together (registers)
+    constexpr int ROWD = 2 * G * G + 4 * G + 16;                 // doubles of LDS per patch row (+16: de-phases the rows' banks)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* T = reinterpret_cast<double*>(smem);   // 64
+    const int lane = threadIdx.x, r = lane / G, i = lane % G;
+    double* Cl = T + 64 + r * ROWD;                // C [G][G] column-major
+    double* Ql = Cl + G * G;
+    double* kvL = Ql + G * G;                      // k of the current point (read by column index)
+    double* svL = kvL + G;                         // s / s_hat
+    double* ehL = svL + G;                         // e_hat
+    double* knL = ehL + G;                         // k of the next point
+    gpc_exp_table_init(T);
+    __syncthreads();
+    const int ldg = A.ld, ny = A.ny;
+    const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, eps_tol = A.prm.eps_tol;
+    const int capacity = A.prm.capacity;
+    const double kstar = sf;
+
+    for (int base = blockIdx.x * R; base < A.P; base += gridDim.x * R) {
+        const int patch = base + r;
+        const bool valid = patch < A.P;
+        const int pc = valid ? patch : A.P - 1;
+        const int o = A.off[pc], n = A.off[pc + 1] - o;
+        int b = A.b[pc];
+        int st = A.stat[pc];
+        double* const alphag = A.alpha + (size_t)pc * ny * ldg;
+        double* const BVg = A.BV + (size_t)pc * ldg * 2;
+        double* const Cg = A.C + (size_t)pc * ldg * ldg;
+        double* const Qg = A.Q + (size_t)pc * ldg * ldg;
+        const unsigned long long rowmask = ((G == 64) ? ~0ull : ((1ull << G) - 1ull)) << (r * G);   // the lanes of this patch
+        const int it0 = A.start_it ? A.start_it[pc] : 0;          // points of this call an earlier phase already took
+        bool take = valid && n > 0 && it0 < n && b <= G;
+        // state of the patch: rows in registers, blocks in LDS
+        double al[3] = {0.0, 0.0, 0.0}, bv0 = 0.0, bv1 = 0.0;
+        if (take && i < b) {
+            bv0 = BVg[2 * i];
+            bv1 = BVg[2 * i + 1];
+            SP_FOR_C(c) al[c] = alphag[c * ldg + i];
+            for (int j = 0; j < b; ++j) {
+                Cl[i + G * j] = Cg[i + (size_t)j * ldg];
+                Ql[i + G * j] = Qg[i + (size_t)j * ldg];
+            }
+        }
+        {   // a state that already asks for a geometric deletion (possible only for one loaded with gpc_sparse_set_state) is not ours
+            const bool asks = take && i < b && b > 1 && (double)1.0f / Ql[i + G * i] < (double)1e-9f;
+            if (__builtin_amdgcn_ballot_w64(asks) & rowmask) take = false;
+        }
+        if (valid && !take && i == 0) {
+            if (!A.start_it) A.done_it[patch] = 0;                  // (a later phase leaves the earlier phase's count)
+            if (A.list && n > 0 && it0 < n) A.list[atomicAdd(A.list_n, 1)] = patch;   // all of it is the later phases' work
+            else if (A.list && A.status_out) A.status_out[patch] = st;                // nothing to do: nobody else visits it
+        }
+        bool active = take;
+        int it = it0, it_end = n;
+        bool have_next = false;
+        double kn_i = 0.0, pcn[4] = {0.0, 0.0, 0.0, 0.0}, pqn[4] = {0.0, 0.0, 0.0, 0.0};
+        // the point in hand, and the next one in flight (two dependent loads: insertion order, then the point)
+        double cx0 = 0.0, cx1 = 0.0, cy[3] = {0.0, 0.0, 0.0};
+        int r_nxt = 0;
+        if (active) {
+            const int r0 = A.perm ? A.perm[o + it0] : it0;
+            cx0 = A.x0[o + r0];
+            cx1 = A.x1[o + r0];
+            SP_FOR_C(c) cy[c] = A.y[(size_t)c * A.n_total + o + r0];
+            if (it0 + 1 < n) r_nxt = A.perm ? A.perm[o + it0 + 1] : it0 + 1;
+        }
+        double nx0 = 0.0, nx1 = 0.0, nyv[3] = {0.0, 0.0, 0.0};
+        int r_nxt2 = 0;
+        while (__builtin_amdgcn_ballot_w64(active)) {
+            if (active) {
+                const double px0 = cx0, px1 = cx1;
+                const double yv[3] = {cy[0], cy[1], cy[2]};
+                const bool more = it + 1 < n;
+                if (more) {
+                    nx0 = A.x0[o + r_nxt];
+                    nx1 = A.x1[o + r_nxt];
+                    SP_FOR_C(c) nyv[c] = A.y[(size_t)c * A.n_total + o + r_nxt];
+                    if (it + 2 < n) r_nxt2 = A.perm ? A.perm[o + it + 2] : it + 2;
+                }
+                const bool from_prev = have_next;
+                have_next = false;
+                bool stop = false;                  // hand the patch over before this point
+                int dec = 0;
+                if (b == 0) {
+                    // First point (src/sparse_gp.hpp:100-114)
+                    if (i == 0) {
+                        SP_FOR_C(c) al[c] = yv[c] / (kstar + s20);
+                        Cl[0] = (double)(-1.0f) / (kstar + s20);
+                        Ql[0] = (double)(1.0f) / kstar;
+                        bv0 = px0;
+                        bv1 = px1;
+                    }
+                    b = 1;
+                    dec = 0x81;
+                } else {
+                    // k, C k, e_hat = Q k (:119, :140, :160): from the previous point's update pass, or from scratch
+                    double k_i = 0.0, pcq[4], pqq[4];
+                    if (from_prev) {
+                        k_i = kn_i;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { pcq[q] = pcn[q]; pqq[q] = pqn[q]; }
+                    } else {
+                        if (i < b) {
+                            k_i = gpc_rbf(sf, A.c_exp, px0, px1, bv0, bv1, T);
+                            kvL[i] = k_i;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        // the four quarters side by side, one column of each per trip: their loads are issued together (clamped column,
+                        // masked value) -- QN LDS round trips per pass instead of one per column
+                        double acc_[4] = {0.0, 0.0, 0.0, 0.0}, acq_[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll UNR
+                        for (int t = 0; t < QN; ++t) {
+                            double cv[4], qw[4], kj[4];
+                            bool ok[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int j = ((b * q) >> 2) + t;
+                                ok[q] = j < ((b * (q + 1)) >> 2) && i < b;
+                                const int jc = ok[q] ? j : 0;
+                                kj[q] = kvL[jc];
+                                cv[q] = Cl[i + G * jc];
+                                qw[q] = Ql[i + G * jc];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const double a1 = acc_[q] + cv[q] * kj[q], a2 = acq_[q] + qw[q] * kj[q];
+                                acc_[q] = ok[q] ? a1 : acc_[q];
+                                acq_[q] = ok[q] ? a2 : acq_[q];
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { pcq[q] = acc_[q]; pqq[q] = acq_[q]; }
+                    }
+                    double ck_i = 0.0, eh_i = 0.0;
+                    double dots[2] = {0.0, 0.0}, sums[3] = {0.0, 0.0, 0.0};
+                    if (i < b) {
+                        const double c_ = pcq[0] + pcq[1] + pcq[2] + pcq[3];
+                        const double q_ = pqq[0] + pqq[1] + pqq[2] + pqq[3];
+                        ck_i = c_;
+                        eh_i = q_;
+                        dots[0] += k_i * c_;                        // k^T C k   (:122)
+                        dots[1] += k_i * q_;                        // k^T e_hat (:144)
+                        SP_FOR_C(c) sums[c] += al[c] * k_i;   // m = alpha^T k (:121)
+                    }
+                    dots[0] = sp_row_sum<G>(dots[0]);
+                    dots[1] = sp_row_sum<G>(dots[1]);
+                    sums[0] = sp_row_sum<G>(sums[0]);
+                    if (ny == 3) {
+                        sums[1] = sp_row_sum<G>(sums[1]);
+                        sums[2] = sp_row_sum<G>(sums[2]);
+                    }
+                    const double s2 = kstar + dots[0];
+                    double gamma = kstar - dots[1];
+                    if (gamma < (double)1e-12f) gamma = 0;          // :146-151
+                    // gaussian_noise / gaussian_noise_3d (src/gaussian_noise.cpp:9-18, src/gaussian_noise_3d.cpp:11-20)
+                    const double rr = (double)(-1.0f) / (s20 + s2);
+                    double qv[3];
+                    SP_FOR_C(c) qv[c] = (yv[c] - sums[c]) / (s20 + s2);
+                    const bool fuse = A.fuse_next && more;
+                    if (gamma < eps_tol && capacity != -1) {
+                        // sparse update (:155-163)
+                        const double eta = 1 / (1 + gamma * rr);
+                        double sh = 0.0;
+                        if (i < b) {
+                            sh = ck_i + eh_i;                        // s_hat = C*k + e_hat
+                            svL[i] = sh;
+                            SP_FOR_C(c) al[c] += sh * (qv[c] * eta);
+                        }
+                        const double re = rr * eta;
+                        if (fuse && i < b) {
+                            kn_i = gpc_rbf(sf, A.c_exp, nx0, nx1, bv0, bv1, T);
+                            knL[i] = kn_i;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        {
+                            double acc_[4] = {0.0, 0.0, 0.0, 0.0}, acq_[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll UNR
+                            for (int t = 0; t < QN; ++t) {
+                                double cv[4], qw[4], kj[4], sj[4];
+                                bool ok[4];
+                                int jj[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int j = ((b * q) >> 2) + t;
+                                    ok[q] = j < ((b * (q + 1)) >> 2) && i < b;
+                                    jj[q] = ok[q] ? j : 0;
+                                    sj[q] = svL[jj[q]];
+                                    cv[q] = Cl[i + G * jj[q]];
+                                    kj[q] = fuse ? knL[jj[q]] : 0.0;
+                                    qw[q] = fuse ? Ql[i + G * jj[q]] : 0.0;
+                                }
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const double c = cv[q] + (re * sh) * sj[q];
+                                    if (ok[q]) Cl[i + G * jj[q]] = c;
+                                    const double a1 = acc_[q] + c * kj[q], a2 = acq_[q] + qw[q] * kj[q];
+                                    acc_[q] = ok[q] ? a1 : acc_[q];
+                                    acq_[q] = ok[q] ? a2 : acq_[q];
+                                }
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { pcn[q] = acc_[q]; pqn[q] = acq_[q]; }
+                        }
+                        have_next = fuse;
+                    } else {
+                        // full update (:164-203) -- if the basis stays within the block and no deletion follows it
+                        const int nb = b + 1;
+                        const double ig = (double)1.0f / gamma;
+                        const double eh_x = (i < b) ? eh_i : (double)(-1.0f);
+                        bool geo = false;
+                        if (i < nb) {
+                            const double q0 = (i < b) ? Ql[i + G * i] : 0.0;
+                            const double qd = q0 + (ig * eh_x) * eh_x;           // the updated diagonal of Q, as the update forms it
+                            geo = (double)1.0f / qd < (double)1e-9f;              // :226-242 would delete
+                        }
+                        const bool any_geo = (__builtin_amdgcn_ballot_w64(geo) & rowmask) != 0;
+                        if (nb > G || nb > ldg || (capacity > 0 && nb > capacity) || any_geo) {
+                            stop = true;                    // nothing of this point has been applied
+                        } else {
+                            dec = 1;
+                            const double si = (i < b) ? ck_i : (double)1.0f;
+                            if (i < nb) {
+                                svL[i] = si;
+                                ehL[i] = eh_x;
+                                SP_FOR_C(c) {
+                                    const double a0 = (i < b) ? al[c] : 0.0;
+                                    al[c] = a0 + qv[c] * si;
+                                }
+                                if (i == b) { bv0 = px0; bv1 = px1; }
+                                if (fuse) {
+                                    kn_i = gpc_rbf(sf, A.c_exp, nx0, nx1, bv0, bv1, T);
+                                    knL[i] = kn_i;
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            {
+                                double acc_[4] = {0.0, 0.0, 0.0, 0.0}, acq_[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll UNR
+                                for (int t = 0; t < QN; ++t) {
+                                    double cv[4], qw[4], kj[4], sj[4], ej[4];
+                                    bool ok[4];
+                                    int jj[4];
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const int j = ((nb * q) >> 2) + t;
+                                        ok[q] = j < ((nb * (q + 1)) >> 2) && i < nb;
+                                        jj[q] = ok[q] ? j : 0;
+                                        sj[q] = svL[jj[q]];
+                                        ej[q] = ehL[jj[q]];
+                                        cv[q] = Cl[i + G * jj[q]];
+                                        qw[q] = Ql[i + G * jj[q]];
+                                        kj[q] = fuse ? knL[jj[q]] : 0.0;
+                                    }
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const bool old = (i < b) && (jj[q] < b);      // the new row / column starts from zero
+                                        const double c = (old ? cv[q] : 0.0) + (rr * si) * sj[q];
+                                        const double qn_ = (old ? qw[q] : 0.0) + (ig * eh_x) * ej[q];
+                                        if (ok[q]) {
+                                            Cl[i + G * jj[q]] = c;
+                                            Ql[i + G * jj[q]] = qn_;
+                                        }
+                                        const double a1 = acc_[q] + c * kj[q], a2 = acq_[q] + qn_ * kj[q];
+                                        acc_[q] = ok[q] ? a1 : acc_[q];
+                                        acq_[q] = ok[q] ? a2 : acq_[q];
+                                    }
+                                }
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) { pcn[q] = acc_[q]; pqn[q] = acq_[q]; }
+                            }
+                            have_next = fuse;
+                            b = nb;
+                        }
+                    }
+                }
+                if (stop) {
+                    it_end = it;
+                    active = false;
+                } else {
+                    __builtin_amdgcn_wave_barrier();
+                    // isnan(C(0,0)) -> "sparse_gp::C has become Nan" (:245)
+                    const double c00 = Cl[0];
+                    if (c00 != c00 && st == GPC_STATUS_OK) st = GPC_STATUS_NAN;
+                    if (A.trace && i == 0) A.trace[o + it] = (uint8_t)dec;
+                    ++it;
+                    cx0 = nx0; cx1 = nx1; cy[0] = nyv[0]; cy[1] = nyv[1]; cy[2] = nyv[2];
+                    r_nxt = r_nxt2;
+                    if (it >= n) active = false;
+                }
+            }
+        }
+        // write the state back (a patch handed over continues from it in the next kernel)
+        if (take) {
+            __builtin_amdgcn_wave_barrier();
+            if (i < b) {
+                BVg[2 * i] = bv0;
+                BVg[2 * i + 1] = bv1;
+                SP_FOR_C(c) alphag[c * ldg + i] = al[c];
+                for (int j = 0; j < b; ++j) {
+                    Cg[i + (size_t)j * ldg] = Cl[i + G * j];
+                    Qg[i + (size_t)j * ldg] = Ql[i + G * j];
+                }
+            }
+            if (i == 0) {
+                if (A.list && it_end < n) A.list[atomicAdd(A.list_n, 1)] = patch;    // handed over: the next phase continues it
+                A.done_it[patch] = it_end;
+                A.b[patch] = b;
+                A.count[patch] += it_end - it0;
+                A.stat[patch] = st;
+                if (A.status_out) A.status_out[patch] = st;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1213,6 +1580,7 @@ int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc
     g->alpha = g->C = g->Q = g->BV = nullptr;
     g->b = g->count = g->stat = nullptr;
     g->done_it = nullptr;
+    g->list = nullptr;
     g->trace = nullptr;
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t ld = (size_t)g->ld, Pn = (size_t)(P > 0 ? P : 1);
@@ -1225,12 +1593,13 @@ int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc
     if (e == hipSuccess) e = hipMalloc(&g->count, 4 * Pn);
     if (e == hipSuccess) e = hipMalloc(&g->stat, 4 * Pn);
     if (e == hipSuccess) e = hipMalloc(&g->done_it, 4 * Pn);
+    if (e == hipSuccess) e = hipMalloc(&g->list, 4 * (Pn + 4));
     if (e == hipSuccess) e = hipMemsetAsync(g->b, 0, 4 * Pn, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(g->count, 0, 4 * Pn, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(g->stat, 0, 4 * Pn, ctx->stream);
     if (e != hipSuccess) {
         int rc = gpc_fail(ctx, e == hipErrorOutOfMemory ? GPC_ENOMEM : GPC_EHIP, "gpc_sparse_create: %s", hipGetErrorString(e));
-        for (void* p : {(void*)g->alpha, (void*)g->C, (void*)g->Q, (void*)g->BV, (void*)g->b, (void*)g->count, (void*)g->stat, (void*)g->done_it})
+        for (void* p : {(void*)g->alpha, (void*)g->C, (void*)g->Q, (void*)g->BV, (void*)g->b, (void*)g->count, (void*)g->stat, (void*)g->done_it, (void*)g->list})
             if (p) (void)hipFree(p);
         delete g;
         return rc;
@@ -1251,7 +1620,7 @@ void gpc_sparse_destroy(gpc_sparse* g)
         std::lock_guard<std::mutex> lk(ctx->mu);
         if (!ctx->dead.load()) (void)hipStreamSynchronize(ctx->stream);
     }
-    for (void* p : {(void*)g->alpha, (void*)g->C, (void*)g->Q, (void*)g->BV, (void*)g->b, (void*)g->count, (void*)g->stat, (void*)g->done_it})
+    for (void* p : {(void*)g->alpha, (void*)g->C, (void*)g->Q, (void*)g->BV, (void*)g->b, (void*)g->count, (void*)g->stat, (void*)g->done_it, (void*)g->list})
         if (p) (void)hipFree(p);
     delete g;
     gpc_ctx_unref(ctx);
@@ -1319,22 +1688,46 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     int grid = std::min(g->P, ctx->num_cus * per_cu);
     A.start_it = nullptr;
     A.done_it = nullptr;
+    A.list = nullptr;
+    A.list_n = nullptr;
+    A.ticket_slot = 0;
+    const bool gauss = A.prm.noise_model == GPC_NOISE_GAUSSIAN;
     if (!getenv("GPC_SPARSE_NO_SMALL")) {
-        // small-basis phase first: one wave per patch, C and Q in LDS, until a patch outgrows SP_BMAX basis vectors
+        // rows phase first (Gaussian noise): four patches per wave while a patch needs at most 16 basis vectors and no deletion;
+        // what it does not finish goes on the work list of the phases below
+        if (gauss && !getenv("GPC_SPARSE_NO_ROWS")) {
+            constexpr int G = 16, R = 64 / G;
+            const size_t lds_r = sizeof(double) * (size_t)(64 + R * (2 * G * G + 4 * G + 16));
+            int per_cu_r = std::min(8, (int)((160u * 1024u) / lds_r));
+            if (const char* e = getenv("GPC_SPARSE_ROWS_PER_CU")) per_cu_r = std::max(1, std::min(per_cu_r, atoi(e)));   // diagnostic
+            A.done_it = g->done_it;
+            if (!getenv("GPC_SPARSE_NO_LIST")) {
+                A.list = g->list;
+                A.list_n = g->list + g->P;
+                GPC_HIP(ctx, hipMemsetAsync(A.list_n, 0, 4 * sizeof(int32_t), ctx->stream));
+            }
+            const int waves = (g->P + R - 1) / R;
+            hipLaunchKernelGGL((sparse_add_rows_kernel<G>), dim3(std::min(waves, ctx->num_cus * per_cu_r)), dim3(64), lds_r, ctx->stream, A);
+            GPC_HIP(ctx, hipGetLastError());
+            A.start_it = g->done_it;
+        }
+        // small-basis phase: one wave per patch, C and Q in LDS, until a patch outgrows SP_BMAX basis vectors
         const size_t lds_s = sp_add_lds_small();
         int per_cu_s = (int)((160u * 1024u) / lds_s);
         per_cu_s = per_cu_s > 16 ? 16 : per_cu_s;
         if (const char* e = getenv("GPC_SPARSE_SMALL_PER_CU")) per_cu_s = std::max(1, std::min(per_cu_s, atoi(e)));   // diagnostic: occupancy experiments
         A.done_it = g->done_it;
-        if (A.prm.noise_model != GPC_NOISE_GAUSSIAN)
+        A.ticket_slot = 1;
+        if (!gauss)
             hipLaunchKernelGGL((sparse_add_kernel<true, true>), dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
         else
             hipLaunchKernelGGL((sparse_add_kernel<true, false>), dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
         GPC_HIP(ctx, hipGetLastError());
         A.start_it = g->done_it;
+        A.ticket_slot = 3;
         A.done_it = nullptr;
     }
-    if (A.prm.noise_model != GPC_NOISE_GAUSSIAN) hipLaunchKernelGGL((sparse_add_kernel<false, true>), dim3(grid), dim3(nth), lds, ctx->stream, A);
+    if (!gauss) hipLaunchKernelGGL((sparse_add_kernel<false, true>), dim3(grid), dim3(nth), lds, ctx->stream, A);
     else hipLaunchKernelGGL((sparse_add_kernel<false, false>), dim3(grid), dim3(nth), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;

@@ -609,6 +609,62 @@ def test_sparse_small_basis_phase_is_bit_identical(gp, ny, cap, kernel, monkeypa
         assert np.array_equal(BV0[i][:nb], BV1[i][:nb], equal_nan=True)
 
 
+@pytest.mark.parametrize("ny,cap,kernel,P,n", [(1, 200, "default", 203, 256), (3, 100, "default", 61, 200), (1, 12, "default", 37, 150),
+                                               (1, 200, "mixed", 50, 180), (3, 40, "mixed", 33, 120), (1, 33, "geo", 29, 180),
+                                               (1, 100, "fill", 21, 90), (1, -1, "mixed", 9, 60)])
+def test_sparse_rows_phase_is_bit_identical(gp, ny, cap, kernel, P, n, monkeypatch):
+    """The add now opens with a ROWS phase -- four patches per wave, one DPP row of 16 lanes each, while a patch needs at most 16
+    basis vectors and no deletion (sparse_add_rows_kernel) -- whose unfinished patches go on a work list that the one-wave
+    small-basis kernel and the regular kernel take by ticket.  With all of it, with static shares instead of the list
+    (GPC_SPARSE_NO_LIST), without the rows phase (GPC_SPARSE_NO_ROWS) and with no early phase at all (GPC_SPARSE_NO_SMALL) the states, basis sizes, status
+    words, point counts and the per-point decision bytes are identical: patches that never leave the rows phase (the
+    reference's default hyper-parameters), patches handed over in the middle of a call (basis > 16, a geometric deletion due,
+    the capacity reached), online growth over two calls, ragged and empty patches, a patch count that is not a multiple of 4."""
+    capi, ctx = gp
+    res = 0.15
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=23 + cap + P, ragged=True, ny=ny, n_min=1)
+    cnt = np.diff(off)
+    keep = np.ones(off[-1], bool)
+    keep[off[5]:off[6]] = False                      # an empty patch
+    cnt[5] = 0
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    x0, x1, y = x0[keep], x1[keep], np.ascontiguousarray(y[:, keep])
+    perm = synth.sattolo_perms(off, seed=9)
+    kw = dict(capacity=cap)
+    if kernel == "fill":
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 8) ** 2, noise=1e-4 if ny == 1 else 1.0)
+    if kernel == "geo":
+        kw.update(sigmaf_sq=1.0, l_sq=(res * 2) ** 2, noise=1e-6, eps_tol=1e-14)
+    if kernel == "mixed":
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 3) ** 2, noise=1e-3 if ny == 1 else 1.0, eps_tol=1e-3)
+    p = capi.default_params_sparse(ny, **kw)
+    results = []
+    for env in (None, "GPC_SPARSE_NO_LIST", "GPC_SPARSE_NO_ROWS", "GPC_SPARSE_NO_SMALL"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        g = capi.Sparse(ctx, p, P, ny)
+        st1, tr1 = g.add(off, x0, x1, y, perm, trace=True)
+        st2, tr2 = g.add(off, x0, x1, y, trace=True)          # online growth: the second call starts from trained states
+        results.append((st1, st2, tr1, tr2, g.sizes(), *g.state()))
+        g.close()
+        if env:
+            monkeypatch.delenv(env)
+    a = results[0]
+    assert a[4][5] == 0 and a[0][5] == 0
+    if kernel == "default":
+        assert a[4].max() <= 40                       # the regime the rows phase exists for
+    for b_ in results[1:]:
+        for q in range(5):
+            assert np.array_equal(a[q], b_[q]), q
+        for i in range(P):
+            nb = int(a[4][i])
+            (al0, C0, Q0, BV0), (al1, C1, Q1, BV1) = a[5:], b_[5:]
+            assert np.array_equal(al0[i][:, :nb], al1[i][:, :nb], equal_nan=True), i
+            assert np.array_equal(C0[i][:nb, :nb], C1[i][:nb, :nb], equal_nan=True), i
+            assert np.array_equal(Q0[i][:nb, :nb], Q1[i][:nb, :nb], equal_nan=True), i
+            assert np.array_equal(BV0[i][:nb], BV1[i][:nb], equal_nan=True), i
+
+
 # ------------------------------------------------------------------ the tolerances, stated against the exact recursion
 
 def _arbiter_batch(oracle, kw, off, x0, x1, y, perm, xs0, xs1, cap):
