@@ -41,6 +41,12 @@ RES, SZ = 0.15, 20
 M = SZ * SZ
 
 
+def _log(msg):
+    """progress on stderr (GPC_BENCH_VERBOSE=1): the JSON line on stdout stays the only output there"""
+    if os.environ.get("GPC_BENCH_VERBOSE") == "1":
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def algorithmic_flops(n, m):
     """dense fit + predictive mean, kernel evaluation = 7 flops, symmetric K counted once."""
     return 3.5 * n * n + n ** 3 / 3.0 + 2.0 * n * n + 9.0 * n * m
@@ -153,7 +159,15 @@ def bench_dense(env, P, n, steps, warmup, seed=2):
     nb = 2 if use_dist else 1
     f_bufs = [torch.empty((S, 1, M), dtype=torch.float64, device=dev) for _ in range(nb)]
     status = torch.empty((S,), dtype=torch.int32, device=dev)
-    gathers = [gdist.ShardedGather(slots, Pg, f_bufs[0], world) for _ in range(nb)] if use_dist else None
+    gathers, exchange = None, None
+    if use_dist:
+        # the exchange goes through the C-ABI's own communicator (gpc_comm_create + gpc_allgather_fstar_dev) -- what a reference-side
+        # binding would call; torch.distributed only if RCCL cannot be bound (or GPC_BENCH_TORCH_GATHER=1, for comparison)
+        g0, exchange = gdist.make_gather(slots, Pg, f_bufs[0], world, rank, dev.index or 0,
+                                         prefer_cabi=os.environ.get("GPC_BENCH_TORCH_GATHER") != "1")
+        g1 = (gdist.CabiGather(slots, Pg, f_bufs[0], world, rank, dev.index or 0, share=g0) if isinstance(g0, gdist.CabiGather)
+              else gdist.ShardedGather(slots, Pg, f_bufs[0], world))
+        gathers = [g0, g1]
     pending = [None]
 
     def step(k, ev=None):
@@ -204,9 +218,14 @@ def bench_dense(env, P, n, steps, warmup, seed=2):
     kernel = ctx.last_dense_kernel()
     flops = algorithmic_flops(n, M) * P
     achieved = flops / (kern_ms * 1e-3) / 1e12
+    if gathers:
+        torch.cuda.synchronize()
+        for g_ in gathers[::-1]:
+            if hasattr(g_, "close"):
+                g_.close()
     del d_off, d_x0, d_x1, d_y, f_bufs, gathers
     return {"value": world * P * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kern_ms": kern_ms, "ok": ok,
-            "kernel": kernel, "achieved": achieved, "host": (off, x0, x1, y, f_host) if not use_dist else None}
+            "kernel": kernel, "achieved": achieved, "exchange": exchange, "host": (off, x0, x1, y, f_host) if not use_dist else None}
 
 
 def dense_record(name, r, P, n, world, steps, warmup):
@@ -219,7 +238,7 @@ def dense_record(name, r, P, n, world, steps, warmup):
             "config": {"workload": f"{name}: {P} patches x {n} pts per GPU, RBF + Gaussian noise, dense Cholesky fit + predictive mean "
                                    f"on the {SZ}x{SZ} grid (m={M})",
                        "patches_per_gpu": P, "points_per_patch": n, "grid_points": M, "parallelism": par, "kernel": r["kernel"],
-                       "results_ok": r["ok"]},
+                       "results_ok": r["ok"], **({"exchange": r["exchange"]} if r.get("exchange") else {})},
             "roofline": {"bound": "mfma", "achieved": r["achieved"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": r["achieved"] / FP64_PEAK_TFLOPS, "traffic": _traffic(tkey), "kernel_ms": r["kern_ms"],
                          "flops_per_patch": algorithmic_flops(n, M)}}
@@ -401,6 +420,83 @@ def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s, ny=1):
     return rec
 
 
+def bench_sparse_c4_sharded(env, regime, P, n, chunks, cap, steps):
+    """BASELINE configs[3] at N > 1 ("sparse_gp online update ... 1 -> 8 GPU scaling"): the job's patches (N x P, rank-seeded
+    shards) are dealt to the ranks by gpc_partition_patches(sparse_capacity = cap) ONCE -- the per-patch state (alpha, C, Q, BV)
+    lives on its GPU across the add calls (fixed affinity, as gp_mapping::train_processes keeps adding to trained GPs,
+    /root/reference/src/gp_mapping.cpp:293-343) -- then `chunks` add calls, predict, and the one exchange of the path: the
+    all-gather of f_star through the C-ABI's communicator + un-permutation.  P is patches PER GPU (weak scaling)."""
+    import torch
+    import torch.distributed as dist
+    from gp_compressor_amd import capi, dist as gdist, synth
+    ctx, dev, world, rank = env["ctx"], env["dev"], env["world"], env["rank"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    goff, gx0, gx1, gy = gdist.global_batch(world, P, n, res=RES, seed=4)
+    Pg = len(goff) - 1
+    slots, off, x0, x1, y = gdist.shard_batch(goff, gx0, gx1, gy, world, rank, sparse_capacity=cap)
+    del gx0, gx1, gy
+    S = slots.shape[1]
+    kw = dict(sigmaf_sq=1.0, l_sq=(RES / 8) ** 2, noise=1e-4, capacity=cap) if regime == "fill" else dict(capacity=cap)
+    prm = capi.default_params_sparse(1, **kw)
+    g = capi.Sparse(ctx, prm, S, 1)
+    xs0, xs1 = synth.grid(RES, SZ)
+    d_xs0, d_xs1 = t(xs0), t(xs1)
+    f = torch.empty((S, 1, M), dtype=torch.float64, device=dev)
+    cnt = np.diff(off)
+    cn = n // chunks
+    bufs = []
+    for c in range(chunks):
+        ccnt = np.minimum(np.maximum(cnt - c * cn, 0), cn)                 # points of this chunk per slot (padding slots: 0)
+        coff = np.zeros(S + 1, dtype=np.int32)
+        coff[1:] = np.cumsum(ccnt)
+        idx = np.concatenate([np.arange(off[i] + c * cn, off[i] + c * cn + ccnt[i]) for i in range(S)]) if S else np.zeros(0, np.int64)
+        bufs.append((t(coff), int(ccnt.max()) if S else 0, int(coff[-1]), t(x0[idx]), t(x1[idx]), t(y[:, idx])))
+    gather, exchange = gdist.make_gather(slots, Pg, f, world, rank, dev.index or 0,
+                                         prefer_cabi=os.environ.get("GPC_BENCH_TORCH_GATHER") != "1")
+
+    def one_pass():
+        g.reset()
+        for c in range(chunks):
+            g.add_dev(*bufs[c])
+        g.predict_dev(M, d_xs0, d_xs1, f)
+        gather.start(f, async_op=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+            torch.cuda.synchronize()
+    one_pass()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist.is_initialized():
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    bv = g.sizes()
+    ok = bool(torch.isfinite(gather.out).all().item()) and gather.own_rows_match(f, rank, slots)
+    if dist.is_initialized():
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+    rec = {"metric": "patches/sec (compress+predict)", "value": world * P * steps / elapsed, "unit": "patches/s", "n_gpus": world, "steps": steps,
+           "warmup": 1, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"C4 sparse_gp online ({regime}), sharded: {world * P} patches x {n} pts, {P} per GPU, streamed in {chunks} add calls "
+                                  f"with fixed patch -> GPU affinity, capacity {cap}, predictive mean on the {SZ}x{SZ} grid, 1 all-gather of f_star",
+                      "patches_per_gpu": P, "points_per_patch": n, "capacity": cap, "bv_mean_rank0": float(bv.mean()),
+                      "parallelism": f"gpc_partition_patches(sparse_capacity={cap}) -> {S} slots per rank; state stays on its GPU across the add calls",
+                      "exchange": exchange, "results_ok": ok},
+           "roofline": None}
+    if hasattr(gather, "close"):
+        gather.close()
+    g.close()
+    return rec
+
+
 # ------------------------------------------------------------------------------------------------ C5: probit IRLS
 
 def bench_irls_c5(env, P, n, steps, budget_s):
@@ -481,6 +577,18 @@ def main():
     ap.add_argument("--only", default="", help="profiling: run just one workload -- c3 | c4fill | c4defaults | c4defaults3 | c5 | c2var -- and print its record")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line: whatever else writes to fd 1 while the bench runs (RCCL prints a version banner there when a
+    # communicator is created) is sent to stderr, and fd 1 comes back for the line itself
+    sys.stdout.flush()
+    fd_out = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(fd_out, 1)
+        print(json.dumps(obj), flush=True)
+        os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from gp_compressor_amd import capi
@@ -521,14 +629,16 @@ def main():
         else:
             raise SystemExit("--only: c3 | c4fill | c4defaults | c4defaults3 | c5 | c2var")
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit(out)
         ctx.close()
         if dist.is_initialized():
             dist.destroy_process_group()
         return
 
     P, n = args.patches, args.points
+    _log(f"headline: dense {P} x {n}, world {world}, use_dist {use_dist}")
     r = bench_dense(env, P, n, args.steps, args.warmup)
+    _log(f"headline done: {r['value']:.0f} patches/s, exchange: {r.get('exchange')}")
     name = "C2 room scan" if (P, n) == (8192, 256) else "room scan (non-default size)"
     out = dense_record(name, r, P, n, world, args.steps, args.warmup)
     if cpu:
@@ -584,6 +694,12 @@ def main():
             rec3["speedup_vs_cpu_baseline"] = rec3["value"] / rec3["cpu_baseline"]["value"]
         r3["host"] = None
         secondary.append(rec3)
+        if use_dist:
+            # BASELINE configs[3] sharded: fixed affinity over the add calls, one gather (8192 patches per GPU: 5.7 GB of state each)
+            for regime in ("fill", "defaults"):
+                _log(f"sharded sparse C4 ({regime})")
+                secondary.append(bench_sparse_c4_sharded(env, regime, 8192, 256, 4, 200, 2))
+                torch.cuda.empty_cache()
         if world == 1 and not use_dist:
             secondary.append(bench_dense_variance(env, 8192, 256, 3, 3.0 if cpu else 0.0))
             torch.cuda.empty_cache()
@@ -591,10 +707,11 @@ def main():
                 secondary.append(bench_sparse_c4(env, regime, 32768, 256, 4, 200, 2, 4.0 if cpu else 0.0, ny=ny_))
                 torch.cuda.empty_cache()
             secondary.append(bench_irls_c5(env, 4096, 1024, 2, 3.0 if cpu else 0.0))
+    _log("printing the line")
     if rank == 0:
         if secondary:
             out["secondary"] = secondary
-        print(json.dumps(out), flush=True)
+        emit(out)
     ctx.close()
     if dist.is_initialized():
         dist.destroy_process_group()

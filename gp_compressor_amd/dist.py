@@ -105,6 +105,97 @@ class ShardedGather:
         return ok
 
 
+class CabiGather:
+    """The same exchange through the C-ABI a reference-side binding would call (include/gpc.h "multi-GPU"): gpc_comm_create
+    (RCCL communicator from a unique id that rank 0 draws and torch.distributed merely carries to the other ranks),
+    gpc_comm_set_partition, then per step ONE gpc_allgather_fstar_dev = ncclAllGather + the un-permutation kernel.
+    The collective runs on a context of its own, bound to a side stream, so that the next step's kernel overlaps it
+    (start() orders it behind the producing kernel with an event; finish() makes the caller's stream wait for it).
+    Interface of ShardedGather.  Raises GpcError when RCCL cannot be bound (the caller falls back to ShardedGather)."""
+
+    def __init__(self, slots, P, like, world, rank, device_index, share=None):
+        """share: another CabiGather of the same partition whose communicator, context and side stream this one uses (a second
+        set of buffers for double-buffered steps; one RCCL communicator per rank is enough)"""
+        import torch
+        import torch.distributed as dist
+        self.torch = torch
+        self.world, self.S = slots.shape
+        assert self.world == world
+        self.P, self.rank = P, rank
+        self.row = int(np.prod(like.shape[1:]))
+        self.owner = share is None
+        if share is None:
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid[0] = capi.Comm.unique_id()
+                except Exception:
+                    uid[0] = None                            # the other ranks must not be left waiting in the broadcast
+            if dist.is_initialized() and world > 1:
+                dist.broadcast_object_list(uid, src=0)       # the channel "the host has" for the 128 bytes
+            if uid[0] is None:
+                raise RuntimeError("rank 0 could not draw an RCCL unique id")
+            self.side = torch.cuda.Stream(device=like.device)
+            self.cctx = capi.Context(device_index)
+            self.cctx.set_stream(self.side.cuda_stream)
+            self.comm = capi.Comm(self.cctx, world, rank, uid[0])
+            self.comm.set_partition(P, slots)
+        else:
+            self.side, self.cctx, self.comm = share.side, share.cctx, share.comm
+        shape = tuple(like.shape[1:])
+        self.flat = torch.empty((world * self.S,) + shape, dtype=like.dtype, device=like.device)
+        self.out = torch.empty((P,) + shape, dtype=like.dtype, device=like.device)
+        self.ev_in = torch.cuda.Event()
+        self.ev_out = torch.cuda.Event()
+        self.pending = False
+
+    def start(self, local_f, async_op=True):
+        assert local_f.shape[0] == self.S and local_f.is_contiguous()
+        cur = self.torch.cuda.current_stream()
+        self.ev_in.record(cur)                               # the kernel that produced local_f
+        self.side.wait_event(self.ev_in)
+        self.comm.allgather_fstar_dev(self.row, local_f, self.flat, self.out)
+        self.ev_out.record(self.side)
+        self.pending = True
+        if not async_op:
+            self.finish()
+
+    def finish(self):
+        if self.pending:
+            self.torch.cuda.current_stream().wait_event(self.ev_out)
+            self.pending = False
+        return self.out
+
+    own_rows_match = ShardedGather.own_rows_match
+
+    def close(self):
+        if self.owner:
+            self.comm.close()
+            self.cctx.close()
+
+
+def make_gather(slots, P, like, world, rank, device_index, prefer_cabi=True):
+    """The exchange object of the N-rank path and a word on which one it is: the C-ABI's communicator when RCCL binds on every
+    rank, torch.distributed's all_gather_into_tensor otherwise (all ranks take the same branch)."""
+    import torch
+    import torch.distributed as dist
+    g, why = None, ""
+    if prefer_cabi and like.is_cuda:
+        try:
+            g = CabiGather(slots, P, like, world, rank, device_index)
+        except Exception as e:          # RCCL not found / communicator refused: every rank must learn of it
+            why = f"{type(e).__name__}: {e}"
+        if dist.is_initialized() and world > 1:
+            okt = torch.tensor([1 if g is not None else 0], dtype=torch.int32, device=like.device)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 0 and g is not None:
+                g.close()
+                g, why = None, "another rank could not bind RCCL"
+    if g is not None:
+        return g, "C-ABI: gpc_comm_create + gpc_allgather_fstar_dev (ncclAllGather + un-permute kernel, " + capi.load().gpc_comm_library().decode() + ")"
+    return ShardedGather(slots, P, like, world), "torch.distributed.all_gather_into_tensor + index_select" + (f" (C-ABI communicator unavailable: {why})" if why else "")
+
+
 def gather_fstar(local_f, slots, P):
     """local_f: torch tensor (S, ny, m) of this rank's slots.  One all_gather_into_tensor, then un-permute to patch
     order: returns (P, ny, m) on the same device."""

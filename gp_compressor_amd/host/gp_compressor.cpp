@@ -120,6 +120,11 @@ void gp_compressor::release_device()
 
 void gp_compressor::set_devices(const std::vector<int>& devices)
 {
+    for (gpc_sparse* q : shard_gps_) if (q) gpc_sparse_destroy(q);
+    for (gpc_sparse* q : shard_rgb_) if (q) gpc_sparse_destroy(q);
+    shard_gps_.clear();
+    shard_rgb_.clear();
+    shard_slots_.clear();
     for (gpc_comm* c : shard_comm_) gpc_comm_destroy(c);
     for (gpc_ctx* c : shard_ctx_) gpc_ctx_destroy(c);
     shard_comm_.clear();
@@ -127,27 +132,199 @@ void gp_compressor::set_devices(const std::vector<int>& devices)
     devices_ = devices;
 }
 
+// one context per device and the communicators of the one exchange
+void gp_compressor::init_shards()
+{
+    if (!shard_ctx_.empty()) return;
+    const int world = (int)devices_.size();
+    // built into locals and committed to the members only when every context and communicator exists: a failure half-way
+    // leaves the object in its single-device state, never with null handles that a later call would pass on
+    std::vector<gpc_ctx*> ctxs(world, nullptr);
+    std::vector<gpc_comm*> comms(world, nullptr);
+    try {
+        for (int r = 0; r < world; ++r) check(gpc_ctx_create(&ctxs[r], devices_[r]), nullptr, "gpc_ctx_create (shard)");
+        check(gpc_comm_create_all(world, ctxs.data(), comms.data()), ctxs[0], "gpc_comm_create_all");
+    } catch (...) {
+        for (gpc_comm* c : comms) if (c) gpc_comm_destroy(c);
+        for (gpc_ctx* c : ctxs) if (c) gpc_ctx_destroy(c);
+        throw;
+    }
+    shard_ctx_.swap(ctxs);
+    shard_comm_.swap(comms);
+}
+
+// The sparse model over several GPUs (BASELINE configs[3]; the reference keeps adding to trained GPs,
+// /root/reference/src/gp_mapping.cpp:338-339): gpc_partition_patches with the sparse cost model deals the patches ONCE, the
+// depth and colour GPs of a device's slots are created there and stay there.  perm_d / perm_c: the insertion orders in
+// patch order, as train_processes() drew them.
+void gp_compressor::train_sparse_sharded(const std::vector<int32_t>& perm_d, const std::vector<int32_t>& perm_c)
+{
+    const int P = batch_.patches(), world = (int)devices_.size();
+    init_shards();
+    const int S = (P + world - 1) / world;
+    if (shard_slots_.empty()) {
+        shard_slots_.assign((size_t)S * world, -1);
+        check(gpc_partition_patches(P, batch_.off.data(), world, depth_params.capacity > 0 ? depth_params.capacity : 1, shard_slots_.data()),
+              nullptr, "gpc_partition_patches");
+        shard_gps_.assign(world, nullptr);
+        shard_rgb_.assign(world, nullptr);
+        for (int r = 0; r < world; ++r) {
+            check(gpc_sparse_create(shard_ctx_[r], &depth_params, S, 1, &shard_gps_[r]), shard_ctx_[r], "gpc_sparse_create(depth, shard)");
+            check(gpc_sparse_create(shard_ctx_[r], &rgb_params, S, 3, &shard_rgb_[r]), shard_ctx_[r], "gpc_sparse_create(rgb, shard)");
+        }
+    }
+    const size_t N = batch_.x0.size();
+    struct Shard {
+        std::vector<int32_t> off, pd, pc;
+        std::vector<double> x0, x1, y, rgb;
+        int n_max = 0;
+        void *d_off = nullptr, *d_x0 = nullptr, *d_x1 = nullptr, *d_y = nullptr, *d_rgb = nullptr, *d_pd = nullptr, *d_pc = nullptr, *d_st = nullptr;
+    };
+    std::vector<Shard> sh(world);
+    auto free_all = [&]() {
+        for (int r = 0; r < world; ++r) {
+            (void)gpc_ctx_synchronize(shard_ctx_[r]);
+            for (void* q : {sh[r].d_off, sh[r].d_x0, sh[r].d_x1, sh[r].d_y, sh[r].d_rgb, sh[r].d_pd, sh[r].d_pc, sh[r].d_st})
+                if (q) (void)gpc_dev_free(shard_ctx_[r], q);
+        }
+    };
+    try {
+        for (int r = 0; r < world; ++r) {
+            Shard& s = sh[r];
+            gpc_ctx* c = shard_ctx_[r];
+            s.off.assign(S + 1, 0);
+            for (int q = 0; q < S; ++q) {
+                const int p = shard_slots_[(size_t)r * S + q];
+                const int n = p >= 0 ? batch_.off[p + 1] - batch_.off[p] : 0;
+                s.off[q + 1] = s.off[q] + n;
+                s.n_max = std::max(s.n_max, n);
+            }
+            const size_t Nl = (size_t)s.off[S];
+            s.x0.resize(Nl); s.x1.resize(Nl); s.y.resize(Nl); s.rgb.resize(3 * Nl); s.pd.resize(Nl); s.pc.resize(Nl);
+            for (int q = 0; q < S; ++q) {
+                const int p = shard_slots_[(size_t)r * S + q];
+                if (p < 0) continue;
+                const size_t o = (size_t)batch_.off[p], n = (size_t)(batch_.off[p + 1] - batch_.off[p]), lo = (size_t)s.off[q];
+                std::copy_n(&batch_.x0[o], n, &s.x0[lo]);
+                std::copy_n(&batch_.x1[o], n, &s.x1[lo]);
+                std::copy_n(&batch_.y[o], n, &s.y[lo]);
+                std::copy_n(&perm_d[o], n, &s.pd[lo]);            // patch-local indices: they travel with the patch
+                std::copy_n(&perm_c[o], n, &s.pc[lo]);
+                for (int a = 0; a < 3; ++a) std::copy_n(&batch_.rgb[a * N + o], n, &s.rgb[a * Nl + lo]);
+            }
+            auto up = [&](void** d, const void* h, size_t bytes) {
+                check(gpc_dev_malloc(c, bytes ? bytes : 8, d), c, "gpc_dev_malloc (shard)");
+                if (bytes) check(gpc_dev_memcpy(c, *d, h, bytes, GPC_COPY_H2D), c, "gpc_dev_memcpy (shard)");
+            };
+            up(&s.d_off, s.off.data(), sizeof(int32_t) * (size_t)(S + 1));
+            up(&s.d_x0, s.x0.data(), 8 * Nl);
+            up(&s.d_x1, s.x1.data(), 8 * Nl);
+            up(&s.d_y, s.y.data(), 8 * Nl);
+            up(&s.d_rgb, s.rgb.data(), 24 * Nl);
+            up(&s.d_pd, s.pd.data(), 4 * Nl);
+            up(&s.d_pc, s.pc.data(), 4 * Nl);
+            check(gpc_dev_malloc(c, sizeof(int32_t) * (size_t)S, &s.d_st), c, "gpc_dev_malloc");
+        }
+        // the add calls only enqueue: the devices run side by side
+        for (int r = 0; r < world; ++r) {
+            Shard& s = sh[r];
+            check(gpc_sparse_add_dev(shard_gps_[r], (const int32_t*)s.d_off, s.n_max, s.off[S], (const double*)s.d_x0, (const double*)s.d_x1,
+                                     (const double*)s.d_y, (const int32_t*)s.d_pd, (int32_t*)s.d_st), shard_ctx_[r], "gpc_sparse_add_dev (shard, depth)");
+            check(gpc_sparse_add_dev(shard_rgb_[r], (const int32_t*)s.d_off, s.n_max, s.off[S], (const double*)s.d_x0, (const double*)s.d_x1,
+                                     (const double*)s.d_rgb, (const int32_t*)s.d_pc, (int32_t*)s.d_st), shard_ctx_[r], "gpc_sparse_add_dev (shard, rgb)");
+        }
+        std::vector<int32_t> st(S);
+        for (int r = 0; r < world; ++r) {
+            check(gpc_dev_memcpy(shard_ctx_[r], st.data(), sh[r].d_st, sizeof(int32_t) * (size_t)S, GPC_COPY_D2H), shard_ctx_[r], "download status");
+            for (int q = 0; q < S; ++q) {
+                const int p = shard_slots_[(size_t)r * S + q];
+                if (p >= 0) status_[p] = st[q];
+            }
+        }
+    } catch (...) {
+        free_all();
+        throw;
+    }
+    free_all();
+}
+
+// load_compressed() of the sharded sparse model: every device predicts the grids of its slots, ONE grouped all-gather of the depth and
+// the colour grids reassembles them on device 0 in patch order; basis sizes come back slot by slot.
+void gp_compressor::predict_sparse_sharded(const std::vector<double>& xs0, const std::vector<double>& xs1, std::vector<double>& f_star,
+                                           std::vector<double>& c_star, std::vector<int32_t>& bv)
+{
+    const int P = batch_.patches(), m = sz_ * sz_, world = (int)devices_.size();
+    const int S = (P + world - 1) / world;
+    struct Buf { void *xs0 = nullptr, *xs1 = nullptr, *lf = nullptr, *lc = nullptr, *gf = nullptr, *gc = nullptr, *f = nullptr, *c = nullptr; };
+    std::vector<Buf> b(world);
+    bool in_group = false;
+    auto free_all = [&]() {
+        for (int r = 0; r < world; ++r) {
+            (void)gpc_ctx_synchronize(shard_ctx_[r]);
+            for (void* q : {b[r].xs0, b[r].xs1, b[r].lf, b[r].lc, b[r].gf, b[r].gc, b[r].f, b[r].c})
+                if (q) (void)gpc_dev_free(shard_ctx_[r], q);
+        }
+    };
+    try {
+        for (int r = 0; r < world; ++r) {
+            gpc_ctx* c = shard_ctx_[r];
+            check(gpc_dev_malloc(c, 8 * (size_t)m, &b[r].xs0), c, "gpc_dev_malloc");
+            check(gpc_dev_malloc(c, 8 * (size_t)m, &b[r].xs1), c, "gpc_dev_malloc");
+            check(gpc_dev_memcpy(c, b[r].xs0, xs0.data(), 8 * (size_t)m, GPC_COPY_H2D), c, "upload grid");
+            check(gpc_dev_memcpy(c, b[r].xs1, xs1.data(), 8 * (size_t)m, GPC_COPY_H2D), c, "upload grid");
+            check(gpc_dev_malloc(c, 8 * (size_t)S * m, &b[r].lf), c, "gpc_dev_malloc");
+            check(gpc_dev_malloc(c, 8 * (size_t)S * 3 * m, &b[r].lc), c, "gpc_dev_malloc");
+            check(gpc_dev_malloc(c, 8 * (size_t)S * world * m, &b[r].gf), c, "gpc_dev_malloc");
+            check(gpc_dev_malloc(c, 8 * (size_t)S * world * 3 * m, &b[r].gc), c, "gpc_dev_malloc");
+            if (r == 0) {
+                check(gpc_dev_malloc(c, 8 * (size_t)P * m, &b[r].f), c, "gpc_dev_malloc");
+                check(gpc_dev_malloc(c, 8 * (size_t)P * 3 * m, &b[r].c), c, "gpc_dev_malloc");
+            }
+            check(gpc_comm_set_partition(shard_comm_[r], P, shard_slots_.data()), c, "gpc_comm_set_partition");
+        }
+        for (int r = 0; r < world; ++r) {
+            check(gpc_sparse_predict_dev(shard_gps_[r], m, (const double*)b[r].xs0, (const double*)b[r].xs1, (double*)b[r].lf, nullptr, 0, nullptr),
+                  shard_ctx_[r], "gpc_sparse_predict_dev (shard, depth)");
+            check(gpc_sparse_predict_dev(shard_rgb_[r], m, (const double*)b[r].xs0, (const double*)b[r].xs1, (double*)b[r].lc, nullptr, 0, nullptr),
+                  shard_ctx_[r], "gpc_sparse_predict_dev (shard, rgb)");
+        }
+        check(gpc_group_start(), shard_ctx_[0], "gpc_group_start");
+        in_group = true;
+        for (int r = 0; r < world; ++r) {
+            check(gpc_allgather_fstar_dev(shard_comm_[r], m, (const double*)b[r].lf, (double*)b[r].gf, nullptr), shard_ctx_[r], "all-gather f*");
+            check(gpc_allgather_fstar_dev(shard_comm_[r], 3 * m, (const double*)b[r].lc, (double*)b[r].gc, nullptr), shard_ctx_[r], "all-gather c*");
+        }
+        in_group = false;
+        check(gpc_group_end(), shard_ctx_[0], "gpc_group_end");
+        check(gpc_unpermute_fstar_dev(shard_comm_[0], m, (const double*)b[0].gf, (double*)b[0].f), shard_ctx_[0], "un-permute f*");
+        check(gpc_unpermute_fstar_dev(shard_comm_[0], 3 * m, (const double*)b[0].gc, (double*)b[0].c), shard_ctx_[0], "un-permute c*");
+        f_star.assign((size_t)P * m, 0.0);
+        c_star.assign((size_t)P * 3 * m, 0.0);
+        check(gpc_dev_memcpy(shard_ctx_[0], f_star.data(), b[0].f, 8 * (size_t)P * m, GPC_COPY_D2H), shard_ctx_[0], "download f*");
+        check(gpc_dev_memcpy(shard_ctx_[0], c_star.data(), b[0].c, 8 * (size_t)P * 3 * m, GPC_COPY_D2H), shard_ctx_[0], "download c*");
+        std::vector<int32_t> sz_slot(S);
+        bv.assign(P, 0);
+        for (int r = 0; r < world; ++r) {
+            check(gpc_sparse_sizes(shard_gps_[r], sz_slot.data()), shard_ctx_[r], "gpc_sparse_sizes (shard)");
+            for (int q = 0; q < S; ++q) {
+                const int p = shard_slots_[(size_t)r * S + q];
+                if (p >= 0) bv[p] = sz_slot[q];
+            }
+        }
+    } catch (...) {
+        if (in_group) (void)gpc_group_end();
+        free_all();
+        throw;
+    }
+    free_all();
+}
+
 // The dense model over several GPUs: the batched form of "patches shard embarrassingly, one all-gather reassembles the
 // decompressed cloud" (BASELINE north_star; patches are independent, src/gp_compressor.cpp:146-163).
 void gp_compressor::train_dense_sharded()
 {
     const int P = batch_.patches(), m = sz_ * sz_, world = (int)devices_.size();
-    if (shard_ctx_.empty()) {
-        // built into locals and committed to the members only when every context and communicator exists: a failure half-way
-        // leaves the object in its single-device state, never with null handles that a later call would pass on
-        std::vector<gpc_ctx*> ctxs(world, nullptr);
-        std::vector<gpc_comm*> comms(world, nullptr);
-        try {
-            for (int r = 0; r < world; ++r) check(gpc_ctx_create(&ctxs[r], devices_[r]), nullptr, "gpc_ctx_create (shard)");
-            check(gpc_comm_create_all(world, ctxs.data(), comms.data()), ctxs[0], "gpc_comm_create_all");
-        } catch (...) {
-            for (gpc_comm* c : comms) if (c) gpc_comm_destroy(c);
-            for (gpc_ctx* c : ctxs) if (c) gpc_ctx_destroy(c);
-            throw;
-        }
-        shard_ctx_.swap(ctxs);
-        shard_comm_.swap(comms);
-    }
+    init_shards();
     const int S = (P + world - 1) / world;
     std::vector<int32_t> slots((size_t)S * world);
     check(gpc_partition_patches(P, batch_.off.data(), world, 0, slots.data()), nullptr, "gpc_partition_patches");
@@ -257,6 +434,8 @@ void gp_compressor::train_dense_sharded()
 
 gp_compressor::~gp_compressor()
 {
+    for (gpc_sparse* q : shard_gps_) if (q) gpc_sparse_destroy(q);
+    for (gpc_sparse* q : shard_rgb_) if (q) gpc_sparse_destroy(q);
     for (gpc_comm* c : shard_comm_) gpc_comm_destroy(c);
     for (gpc_ctx* c : shard_ctx_) gpc_ctx_destroy(c);
     release_device();
@@ -520,8 +699,11 @@ void gp_compressor::train_processes()
         trained_ = true;
         return;
     }
-    if (!gps_) check(gpc_sparse_create(ctx_, &depth_params, P, 1, &gps_), ctx_, "gpc_sparse_create(depth)");
-    if (!rgb_gps_) check(gpc_sparse_create(ctx_, &rgb_params, P, 3, &rgb_gps_), ctx_, "gpc_sparse_create(rgb)");
+    const bool sharded = !devices_.empty();
+    if (!sharded) {
+        if (!gps_) check(gpc_sparse_create(ctx_, &depth_params, P, 1, &gps_), ctx_, "gpc_sparse_create(depth)");
+        if (!rgb_gps_) check(gpc_sparse_create(ctx_, &rgb_params, P, 3, &rgb_gps_), ctx_, "gpc_sparse_create(rgb)");
+    }
     // the reference shuffles inside gps[i].add_measurements and again inside RGB_gps[i].add_measurements, patch by
     // patch (:162-163): draw the two orders in that interleaving
     std::vector<int32_t> perm_d, perm_c;
@@ -530,7 +712,9 @@ void gp_compressor::train_processes()
         shuffle(perm_d, n);
         shuffle(perm_c, n);
     }
-    if (on_device) {
+    if (sharded) {
+        train_sparse_sharded(perm_d, perm_c);
+    } else if (on_device) {
         // the points are already in HBM: only the two insertion orders go up
         const size_t N = (size_t)dv.n_total;
         void *d_pd = nullptr, *d_pc = nullptr, *d_st = nullptr;
@@ -554,8 +738,18 @@ void gp_compressor::train_processes()
         check(gpc_sparse_add(rgb_gps_, batch_.off.data(), batch_.x0.data(), batch_.x1.data(), batch_.rgb.data(), perm_c.data(),
                              status_.data()), ctx_, "gpc_sparse_add(rgb)");
     }
-    std::vector<int32_t> bv(P);
-    check(gpc_sparse_sizes(gps_, bv.data()), ctx_, "gpc_sparse_sizes");
+    std::vector<int32_t> bv(P, 0);
+    if (sharded) {
+        const int world = (int)devices_.size(), S = (P + world - 1) / world;
+        std::vector<int32_t> sz_slot(S);
+        for (int r = 0; r < world; ++r) {
+            check(gpc_sparse_sizes(shard_gps_[r], sz_slot.data()), shard_ctx_[r], "gpc_sparse_sizes (shard)");
+            for (int q = 0; q < S; ++q)
+                if (shard_slots_[(size_t)r * S + q] >= 0) bv[shard_slots_[(size_t)r * S + q]] = sz_slot[q];
+        }
+    } else {
+        check(gpc_sparse_sizes(gps_, bv.data()), ctx_, "gpc_sparse_sizes");
+    }
     double mean = 0, added = 0;                  // "Mean added" / "Max added" (:164-168, 173-174)
     int maxm = 0;
     for (int i = 0; i < P; ++i) {
@@ -648,6 +842,8 @@ pointcloud gp_compressor::load_compressed()
         f_star = dense_f_;
         c_star = dense_c_;
         for (int i = 0; i < P; ++i) bv[i] = batch_.off[i + 1] - batch_.off[i];
+    } else if (!devices_.empty()) {
+        predict_sparse_sharded(xs0, xs1, f_star, c_star, bv);
     } else {
         f_star.assign((size_t)P * m, 0.0);
         c_star.assign((size_t)P * 3 * m, 0.0);
@@ -693,6 +889,7 @@ gp_compressor::gp_compressor(double res, int sz, int device)
 size_t gp_compressor::save_model(const std::string& path)
 {
     if (model_ != gp_model::sparse) throw std::runtime_error("save_model: the sparse model only");
+    if (!devices_.empty()) throw std::runtime_error("save_model: the single-device flow only (the sharded states live on their devices)");
     if (!trained_) { project_cloud(); train_processes(); }
     const int P = batch_.patches();
     std::unique_ptr<FILE, file_closer> f(std::fopen(path.c_str(), "wb"));

@@ -92,8 +92,11 @@ public:
     int max_added() const { return max_added_; }
     // Multi-GPU: the reference is one process, so one process drives the GPUs of the node -- one gpc_ctx per
     // device, gpc_partition_patches (longest-processing-time) deals the patches, every device fits + predicts its slots and ONE
-    // RCCL all-gather (gpc_comm_create_all + gpc_group bracket) reassembles the grids.  Dense model, host-cut patches
-    // (save_compressed() then runs project_cloud() on the host); an empty list returns to the single-device flow.
+    // RCCL all-gather (gpc_comm_create_all + gpc_group bracket) reassembles the grids.  Host-cut patches (save_compressed() then
+    // runs project_cloud() on the host); an empty list returns to the single-device flow.  Dense model: fit + predict per device
+    // at training time.  Sparse model (what the reference runs): the partition is drawn with the sparse cost model and the two GPs
+    // of a patch live on ITS device from train_processes() to load_compressed() (fixed affinity: the state never moves), which
+    // predicts per device and gathers the grids once.
     void set_devices(const std::vector<int>& devices);
     // insertion-order source; default std::rand like sparse_gp::shuffle (src/sparse_gp.hpp:43-56)
     std::function<int()> rng;
@@ -124,7 +127,13 @@ protected:
     double *d_dense_f_ = nullptr, *d_dense_c_ = nullptr;
     void release_device();
     void train_dense_sharded();
-    std::vector<int> devices_;                // set_devices(): non-empty = the sharded dense flow
+    void init_shards();
+    void train_sparse_sharded(const std::vector<int32_t>& perm_d, const std::vector<int32_t>& perm_c);
+    void predict_sparse_sharded(const std::vector<double>& xs0, const std::vector<double>& xs1, std::vector<double>& f_star,
+                                std::vector<double>& c_star, std::vector<int32_t>& bv);
+    std::vector<gpc_sparse*> shard_gps_, shard_rgb_;   // sparse model, sharded: the GPs of a device's slots
+    std::vector<int32_t> shard_slots_;                 // world * S: slot -> patch (-1 padding), from gpc_partition_patches
+    std::vector<int> devices_;                // set_devices(): non-empty = the sharded flow
     std::vector<gpc_ctx*> shard_ctx_;         // one per device (shard_ctx_[0] is its own context, not ctx_)
     std::vector<gpc_comm*> shard_comm_;
     std::vector<int32_t> status_;

@@ -87,6 +87,59 @@ def test_compress_roundtrip_c1(H, model, oracle):
         assert max_added <= 400
 
 
+def test_compress_c1_at_the_reference_constants(H, oracle):
+    """BASELINE config 1 as the reference ships it: gp_compressor comp(cloud, 0.15f, 20); save_compressed; load_compressed
+    (src/test_gp_compress.cpp:21-24) with sparse_gp(100, 1e-1f) / rbf_kernel(100, 1) / sparse_gp_field(100, 1e2f) -- no kernel
+    override (src/sparse_gp.h:48, src/rbf_kernel.h:24, src/sparse_gp_field.h:43).  At these constants every K_ij lies within 2 % of
+    sigma_f^2, the basis stays tiny and the branch `gamma < eps_tol` rides on rounding noise, so the statement is the statistical
+    one of tests/sparse_parity.py: (1) the host class's cloud reconstructs the surface as well as the CPU oracle's reconstruction
+    of the same patch batch does (other insertion orders: the host draws its own), (2) on that batch, with one explicit insertion
+    order, GPU vs fp64 oracle vs binary128 arbiter: reconstruction RMSE, per-patch error percentiles, blow-ups."""
+    import sparse_parity as SP
+    from gp_compressor_amd import capi, synth
+    res, sz = 0.15, 20
+    xyz, rgb = H.synthetic_plane_cloud(10000, seed=1)
+    g = H.GpCompressor(xyz, rgb, res=res, sz=sz, model="sparse", seed=7)           # set_sparse_kernel NOT called
+    oxyz, orgb, mean_added, max_added = g.roundtrip()
+    batch = g.project_cloud()
+    off, x0, x1 = batch["off"], batch["x0"], batch["x1"]
+    y = np.ascontiguousarray(batch["y"][None, :])
+    P = len(off) - 1
+    assert P == 64 and len(oxyz) == P * sz * sz and np.all(np.isfinite(oxyz))
+    assert 1 <= mean_added <= 40 and max_added <= 64                               # "Mean added" / "Max added": the basis stays tiny
+    err = oxyz[:, 2].astype(np.float64) - _surface(oxyz[:, 0].astype(np.float64), oxyz[:, 1].astype(np.float64))
+    rms_host = float(np.sqrt(np.mean(err ** 2)))
+    # the oracle's reconstruction of the same batch (depth GP at the defaults) under two other insertion orders
+    op = oracle.sparse_params(1)
+    xs0, xs1 = oracle.grid(res, sz)
+    rms_orc = []
+    for seed in (3, 4):
+        perm = synth.sattolo_perms(off, seed=seed)
+        fo, _, _ = oracle.sparse_fit_predict_batch(op, off, x0, x1, y, xs0, xs1, perm=perm)
+        e = []
+        for i in range(P):
+            Rm, mu = batch["R"][i], batch["mean"][i]
+            pts = mu[None, :] + np.outer(fo[i, 0], Rm[:, 0]) + np.outer(xs0, Rm[:, 1]) + np.outer(xs1, Rm[:, 2])
+            e.append(pts[:, 2] - _surface(pts[:, 0], pts[:, 1]))
+        rms_orc.append(float(np.sqrt(np.mean(np.concatenate(e) ** 2))))
+    print(f"C1 at the reference constants: surface rms host class {rms_host:.3e}, oracle (two insertion orders) {rms_orc[0]:.3e} / {rms_orc[1]:.3e}")
+    assert rms_host <= 1.25 * max(rms_orc) + 1e-4, (rms_host, rms_orc)
+    # the same batch through the C-ABI with ONE explicit insertion order: the statistics of tests/sparse_parity.py
+    ctx = capi.Context(0)
+    perm = synth.sattolo_perms(off, seed=5)
+    gs = capi.Sparse(ctx, capi.default_params_sparse(1), P, 1)
+    assert np.all(gs.add(off, x0, x1, y, perm) == 0)
+    f, _, _ = gs.predict(xs0, xs1, want_sigma=False)
+    ft, _, _ = gs.predict_points(off, x0, x1)
+    # (the statistics take the points in insertion order: re-lay the batch by perm)
+    idx = np.concatenate([off[i] + perm[off[i]:off[i + 1]] for i in range(P)])
+    st = SP.stats(op, off, x0[idx], x1[idx], np.ascontiguousarray(y[:, idx]), xs0, xs1, f, ft[:, idx], np.arange(P), full_oracle=True)
+    print("C1 at the reference constants:", {k: st[k] for k in ("rmse_train", "err_vs_arbiter_abs", "blowups", "gate")})
+    assert st["gate"]["ok"], st["gate"]["why"]
+    gs.close()
+    ctx.close()
+
+
 def test_model_file_roundtrip_c1(H, tmp_path):
     """Row f3, the wire format the reference never wrote: save_model -> load_model -> load_compressed reconstructs the
     SAME cloud bit for bit from the file alone (frames + (BV, alpha) per patch), and the file is smaller than the cloud."""
@@ -150,20 +203,30 @@ def test_device_resident_round_trip_equals_host_buffers(H, model):
         assert np.max(np.abs(a_xyz - b_xyz)) <= 1e-6 and np.max(np.abs(a_rgb.astype(int) - b_rgb.astype(int))) <= 1
 
 
-def test_multi_gpu_mode_of_the_host_class(H):
-    """gp_compressor::set_devices: the C++ surface -- not only the Python bench -- shards the dense flow: one gpc_ctx per device,
-    gpc_partition_patches, per-device fit + predict, ONE RCCL all-gather (gpc_comm_create_all + gpc_group bracket), un-permute.
+@pytest.mark.parametrize("model", ["dense", "sparse"])
+def test_multi_gpu_mode_of_the_host_class(H, model):
+    """gp_compressor::set_devices: the C++ surface -- not only the Python bench -- shards the flow: one gpc_ctx per device,
+    gpc_partition_patches, per-device work, ONE RCCL all-gather (gpc_comm_create_all + gpc_group bracket), un-permute.  Dense
+    model: fit + predict per device.  Sparse model (what the reference runs): the partition uses the sparse cost model, the depth
+    and colour GPs of a patch are created on ITS device and stay there from train_processes() to load_compressed() (fixed
+    affinity), which predicts per device and gathers once.
     The box has one GPU, so the device list is [0] (world 1: the exchange degenerates, every other step is the N-device
-    code); the cloud must equal the single-device flow's (dense partial sums meet in LDS atomics: equal to a float ulp)."""
+    code); the cloud must equal the single-device flow's -- bit for bit with the sparse model (deterministic kernels, the same
+    insertion orders), to a float ulp with the dense one (its partial sums meet in LDS atomics)."""
     res, sz = 0.15, 20
     xyz, rgb = H.synthetic_plane_cloud(10000, seed=5)
     clouds = []
     for devices in (None, [0]):
-        g = H.GpCompressor(xyz, rgb, res=res, sz=sz, model="dense", seed=3)
+        g = H.GpCompressor(xyz, rgb, res=res, sz=sz, model=model, seed=3)
         g.set_gpu_producer(False)
+        if model == "sparse":
+            g.set_sparse_kernel(1.0, (res / 2) ** 2, 1e-2, 25.0, 40)
         if devices is not None:
             g.set_devices(devices)
         clouds.append(g.roundtrip())
     (a_xyz, a_rgb, a_mean, a_max), (b_xyz, b_rgb, b_mean, b_max) = clouds
     assert a_xyz.shape == b_xyz.shape and len(a_xyz) == 64 * sz * sz and (a_mean, a_max) == (b_mean, b_max)
-    assert np.max(np.abs(a_xyz - b_xyz)) <= 1e-6 and np.max(np.abs(a_rgb.astype(int) - b_rgb.astype(int))) <= 1
+    if model == "sparse":
+        assert np.array_equal(a_xyz, b_xyz) and np.array_equal(a_rgb, b_rgb)
+    else:
+        assert np.max(np.abs(a_xyz - b_xyz)) <= 1e-6 and np.max(np.abs(a_rgb.astype(int) - b_rgb.astype(int))) <= 1
