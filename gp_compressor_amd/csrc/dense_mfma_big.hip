@@ -242,12 +242,8 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                 if (pi_ >= n || pj_ >= n) v_ = (pi_ == pj_) ? 1.0 : 0.0;     /* identity padding */                  \
                 (dst)[q_] = v_;                                                                                      \
             }                                                                                                        \
-        } else {   /* right-hand sides: row c = channel, columns = the points of tile column kc_ */                  \
-            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
-                const int pj_ = MF_TS * (kc_) + lg + 4 * q_;                                                         \
-                if constexpr (BG_IRLS) (dst)[q_] = (lr == 0 && pj_ < n) ? sv[pj_] * tv[pj_] : 0.0;                   \
-                else (dst)[q_] = (lr < ny && pj_ < n) ? A.y[(size_t)lr * A.n_total + o + pj_] : 0.0;                 \
-            }                                                                                                        \
+        } else {   /* beyond the last tile row: nothing (the right-hand sides are a vector object, see the forward solve) */ \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) (dst)[q_] = 0.0;                                        \
         }                                                                                                            \
     } while (0)
 #define BG_TRSM(lv_, src_)                                                                                           \
@@ -424,11 +420,94 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                 }
                 mf_publish(ready, k + nc - 1);     // (also on failure: the workers leave their waits and see the flag)
                 BG_SUB(8);
+                // ---- forward solve of the step's columns: z_(k+c) = L_cc^-1 (y_(k+c) - sum_{j<k} L_(k+c)j z_j - sum_{c2<c} L_(k+c)(k+c2) z_(k+c2)) ----
+                // A vector object: per tile one 16 x 16 mat-vec on the VALU (4 FMAs per lane and channel) against 16 MFMAs when the
+                // right-hand sides were a tile row.  The operand image of M gives lane l the entries M[l & 15][(l >> 4) + 4 s]: the
+                // lane's partial sum over its four columns, then the four lane groups of a row are added.  z lives in LDS (zv).
+                if (ok) {
+                    const int ln = mf_opaque(lane), row = ln & 15, grp = ln >> 4;
+                    double part[BG_C][BG_NYP];
+#pragma unroll
+                    for (int c = 0; c < BG_C; ++c)
+#pragma unroll
+                        for (int ch = 0; ch < BG_NYP; ++ch) part[c][ch] = 0.0;
+                    // the rows k .. k+nc-1 of the factor, columns j < k: in the workspace since the earlier steps (the workers stream the
+                    // same tiles as their column operands right now: L1 / L2 hits); one j ahead in flight
+                    const double* rc_[BG_C];
+#pragma unroll
+                    for (int c = 0; c < BG_C; ++c) rc_[c] = Lt + ((size_t)(k + min(c, nc - 1)) * ntw) * MF_IMG;
+                    d4 fa[2][BG_C];
+#pragma unroll
+                    for (int c = 0; c < BG_C; ++c) fa[0][c] = fa[1][c] = d4{0.0, 0.0, 0.0, 0.0};
+                    if (k > 0) {
+#pragma unroll
+                        for (int c = 0; c < BG_C; ++c) fa[0][c] = mf_img_load(rc_[c], ln);
+                    }
+                    for (int j = 0; j < k; j += 2) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int jn = min(j + h + 1, k - 1);
+#pragma unroll
+                            for (int c = 0; c < BG_C; ++c) fa[h ^ 1][c] = mf_img_load(rc_[c] + (size_t)jn * MF_IMG, ln);
+                            if (j + h < k) {
+#pragma unroll
+                                for (int ch = 0; ch < BG_NYP; ++ch) {
+                                    if (ch < ny) {
+                                        const double* zq = zv + ch * BG_NPAD + MF_TS * (j + h) + grp;
+                                        const double z0 = zq[0], z1 = zq[4], z2 = zq[8], z3 = zq[12];
+#pragma unroll
+                                        for (int c = 0; c < BG_C; ++c)
+                                            part[c][ch] += (fa[h][c][0] * z0 + fa[h][c][1] * z1) + (fa[h][c][2] * z2 + fa[h][c][3] * z3);
+                                    }
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < BG_C; ++c) {
+                        if (c < nc) {
+                            const int pj = MF_TS * (k + c) + row;
+#pragma unroll
+                            for (int ch = 0; ch < BG_NYP; ++ch) {
+                                if (ch < ny) {
+                                    // within the block: the tiles of the step's diagonal block are in LDS (Lblk), as are the z of its earlier columns
+                                    double pp = part[c][ch];
+#pragma unroll
+                                    for (int c2 = 0; c2 < c; ++c2) {
+                                        const d4 lb = mf_img_load(Lblk + (c * (c - 1) / 2 + c2) * 256, ln);
+                                        const double* zq = zv + ch * BG_NPAD + MF_TS * (k + c2) + grp;
+                                        pp += (lb[0] * zq[0] + lb[1] * zq[4]) + (lb[2] * zq[8] + lb[3] * zq[12]);
+                                    }
+                                    pp += __shfl_xor(pp, 16, 64);
+                                    pp += __shfl_xor(pp, 32, 64);
+                                    double yv_;
+                                    if constexpr (BG_IRLS) yv_ = (pj < n) ? sv[pj] * tv[pj] : 0.0;
+                                    else yv_ = (pj < n) ? A.y[(size_t)ch * A.n_total + o + pj] : 0.0;
+                                    if (grp == 0) zv[ch * BG_NPAD + pj] = yv_ - pp;          // t_c, where z_c goes next
+                                    __builtin_amdgcn_wave_barrier();
+                                    const d4 lv = mf_img_load(LinvC + c * 256, ln);
+                                    const double* tq = zv + ch * BG_NPAD + MF_TS * (k + c) + grp;
+                                    double zz = (lv[0] * tq[0] + lv[1] * tq[4]) + (lv[2] * tq[8] + lv[3] * tq[12]);
+                                    zz += __shfl_xor(zz, 16, 64);
+                                    zz += __shfl_xor(zz, 32, 64);
+                                    __builtin_amdgcn_wave_barrier();
+                                    if (grp == 0) zv[ch * BG_NPAD + pj] = zz;
+                                    __builtin_amdgcn_wave_barrier();
+                                }
+                            }
+                        }
+                    }
+                }
+                BG_SUB(8);
             } else {
-                // Rows k + nc .. nt (the last one carries the right-hand sides) are dealt round-robin to the workers, the wave that
-                // shares its SIMD with wave 0 first, the ones with two diagonal-block tiles last.
+                // Rows k + nc .. nt - 1 are dealt round-robin to the workers, the wave that shares its SIMD with wave 0 first, the
+                // ones with two diagonal-block tiles last.  (The right-hand sides used to ride along as one more tile row -- a full
+                // row of MFMAs for 1..3 live channels of 16, and with 4 m + 1 rows per step the busiest SIMD always carried m + 1
+                // where m + 1/4 was its share; they are a vector object now, solved by wave 0 behind its chain: C3 13.1 -> 12.7 ms.
+                // Dealing SIMD by SIMD instead -- wave 4, alone with the chain wave on its SIMD, taking a whole SIMD's share in more
+                // passes -- was measured and is slower, 13.3 ms: one wave does not keep its pipe as busy as two that interleave.)
                 const int q0 = (NWK == 7) ? ((wave == 4) ? 0 : (wave >= 5) ? 8 - wave : 7 - wave) : NWK - wave;
-                const int rows_tot = nt - (k + nc) + 1;
+                const int rows_tot = nt - (k + nc);
                 const int rows_w = (rows_tot - 1 - q0 >= 0) ? (rows_tot - 1 - q0) / NWK + 1 : 0;
                 bool stop = false;
                 for (int p0 = 0; p0 < rows_w && !stop; p0 += BG_RMAX) {
@@ -529,16 +608,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         if (g.stamps && lane == 0)
             for (int q_ = 0; q_ < 5; ++q_) atomicAdd(g.stamps + (5 + q_) * 8 + wave, sub_acc_[q_]);
 #endif
-        // z_k^T = tile (nt, k): lane l, slot s = z_(l&15)[16 k + (l>>4) + 4 s]
-        for (int k = wave; k < nt; k += BG_WAVES) {
-            const d4 zt = mf_img_load(Lt + ((size_t)nt * ntw + k) * MF_IMG, lane);
-            if (lr < ny) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) zv[lr * BG_NPAD + MF_TS * k + lg + 4 * s] = zt[s];
-            }
-        }
-        __syncthreads();
-
+        __syncthreads();   // z (LDS, written by wave 0 step by step) is complete
         BG_STAMP(2);
         // ---- backward solve L^T alpha = z, tile columns from the last to the first ----
         // Column k needs the tiles (i, k), i = k+1+wave+W t, and L_kk^-T: they do not depend on alpha, so the loads of
