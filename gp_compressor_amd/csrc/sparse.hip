@@ -1758,7 +1758,8 @@ int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double
     GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_predict_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int per_cu = (int)((160u * 1024u) / lds);
-    per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+    { const int cap_blocks = sigma ? 4 : 8;   // mean only: a patch is a few hundred kernel evaluations, more resident blocks hide their latency
+      per_cu = per_cu > cap_blocks ? cap_blocks : (per_cu < 1 ? 1 : per_cu); }
     int grid = std::min(g->P, ctx->num_cus * per_cu);
     hipLaunchKernelGGL(sparse_predict_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());
