@@ -79,9 +79,11 @@ struct BigParams {
 //   lower tiles of the step's diagonal block | hand-over of the C (C+1)/2 diagonal-block tiles (after the factorisation: the
 //   predict accumulation buffer 4 x 256, ds_add_f64 targets)
 __host__ __device__ constexpr int bg_hand_doubles(int c) { return c * (c + 1) / 2 * 256 > 1024 ? c * (c + 1) / 2 * 256 : 1024; }
-__host__ __device__ constexpr int bg_lds_doubles(int npad, int c, int nyp)
+// lalias (the two-wave shape): the images of the block's strictly lower tiles L_(k+i)(k+c) take the place of the hand-over tiles
+// they were computed from (wave 0 reads T_ic, solves, stores L_ic over it) -- 12 KB less, which is what lets FOUR workgroups share a CU
+__host__ __device__ constexpr int bg_lds_doubles(int npad, int c, int nyp, bool lalias = false)
 {
-    return 64 + (2 + 3 * nyp) * npad + 32 + 16 + c * 256 + (c * (c - 1) / 2) * 256 + bg_hand_doubles(c);
+    return 64 + (2 + 3 * nyp) * npad + 32 + 16 + c * 256 + (lalias ? 0 : (c * (c - 1) / 2) * 256) + bg_hand_doubles(c);
 }
 
 __device__ static __forceinline__ d4 bg_mfma4_neg(d4 a, d4 b, d4 acc)
@@ -109,11 +111,17 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
     static_assert(BG_C == 4, "tile columns per step (the index maps of the diagonal block assume 4)");
     constexpr int BG_THREADS = BG_WAVES * 64;
     constexpr int NDT = BG_C * (BG_C + 1) / 2;           // tiles of the step's diagonal block
+    constexpr bool LALIAS = BG_WAVES == 2;               // see bg_lds_doubles
+    // Two-wave shape: the row passes of a step are not dealt but TAKEN -- both waves draw pass numbers from an LDS counter, the
+    // worker from the start, wave 0 once its chain and the forward solve are done (with one worker the rows are the long pole of
+    // a step and the chain wave would idle half of it at the barrier)
+    constexpr bool STEAL = BG_WAVES == 2;
+    static_assert(!STEAL || BG_NPAD <= 256, "one pass counter per step in four spare flag words");
     static_assert(BG_NYP == 3 || (BG_NYP == 1 && !BG_IRLS), "planes of the solve vectors (the IRLS loop keeps its vectors in planes 1, 2)");
     constexpr int B_PX0 = 64, B_PX1 = B_PX0 + BG_NPAD, B_ZV = B_PX1 + BG_NPAD, B_WV = B_ZV + BG_NYP * BG_NPAD, B_AV = B_WV + BG_NYP * BG_NPAD,
                   B_RS = B_AV + BG_NYP * BG_NPAD, B_FLAG = B_RS + 32, B_LINV = B_FLAG + 16, B_LBLK = B_LINV + BG_C * 256,
-                  B_RED = B_LBLK + (BG_C * (BG_C - 1) / 2) * 256;
-    static_assert(B_RED + bg_hand_doubles(BG_C) == bg_lds_doubles(BG_NPAD, BG_C, BG_NYP), "LDS carve");
+                  B_RED = B_LBLK + (LALIAS ? 0 : (BG_C * (BG_C - 1) / 2) * 256);
+    static_assert(B_RED + bg_hand_doubles(BG_C) == bg_lds_doubles(BG_NPAD, BG_C, BG_NYP, LALIAS), "LDS carve");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     double* T = lds;
@@ -126,9 +134,12 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
     int* flag = reinterpret_cast<int*>(lds + B_FLAG);   // ints [0] bad, [1] ready
     int* ready = flag + 1;
     double* LinvC = lds + B_LINV;      // [BG_C][256]
-    double* Lblk = lds + B_LBLK;       // image of L_(k+i)(k+c), c < i, at (i (i-1)/2 + c) * 256
     double* red = lds + B_RED;
     double* Hand = red;                // NDT x 256: hand-over of the diagonal-block tiles to wave 0 (the reduction buffer is idle then)
+    // image of L_(k+i)(k+c), c < i: its own array at (i (i-1)/2 + c) * 256, or (LALIAS) in the slot of the hand-over tile (i, c)
+    auto Lblk_at = [&](int i, int c) __attribute__((always_inline)) {
+        return LALIAS ? Hand + (i * (i + 1) / 2 + c) * 256 : lds + B_LBLK + (i * (i - 1) / 2 + c) * 256;
+    };
     // IRLS (ny == 1): planes 1, 2 of the solve vectors are free
     [[maybe_unused]] double* fv = zv + BG_NPAD;         // latent f
     [[maybe_unused]] double* dv = zv + 2 * BG_NPAD;     // W^-1/2
@@ -143,7 +154,17 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
 
     const DenseArgs& A = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (BG_WAVES == 2) {
+        // Two-wave shape, four workgroups per CU: the dispatcher puts the first waves of two workgroups on one SIMD and their second
+        // waves on the next, so with fixed roles a SIMD would host two chain waves (its MFMA pipe mostly idle) and its neighbour two
+        // workers (sharing one pipe).  The wave slot a workgroup's first wave got on its SIMD (HW_ID.WAVE_ID: 0 for the first
+        // resident, 1 for the second) decides which of the two waves runs the chain: every SIMD then hosts one of each.  A
+        // placement heuristic only -- any outcome is correct.
+        if (tid == 0) flag[27] = (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u);     // hwreg(HW_REG_HW_ID, 0, 4)
+        __syncthreads();
+        wave ^= __builtin_amdgcn_readfirstlane(flag[27]);
+    }
     const int lr = lane & 15, lg = lane >> 4;
     const int ny = __builtin_amdgcn_readfirstlane(A.ny), m = A.m, ntw = g.ntw;
     const double sf = A.prm.sigmaf_sq, cexp = g.c_exp, noise = A.prm.noise;
@@ -179,6 +200,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         [[maybe_unused]] unsigned long long sub_acc_[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
         unsigned long long* ext_bits = reinterpret_cast<unsigned long long*>(lds + B_FLAG + 3);   // max-norm extent, as bits
         if (tid < NDT) hflag[tid] = 0;
+        if (STEAL && tid < 4) flag[28 + tid] = 0;              // pass counters of the four steps
         if (tid == 0) {
             flag[0] = 0;
             flag[1] = -1;
@@ -304,24 +326,9 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
             d4 Dmine = d4{0.0, 0.0, 0.0, 0.0};
             BG_SUB(9);
             {
-                constexpr int DPW = (NDT - 1 + NWK - 1) / NWK;             // tiles per worker, at most (wave 0: tile 0 only)
-                static_assert(DPW >= 1 && DPW <= 3, "diagonal-block tiles per worker");
-                int dd[DPW], nd = 0;
-                const double *ra[DPW], *rb[DPW];
-                d4 dacc[DPW];
-#pragma unroll
-                for (int t = 0; t < DPW; ++t) {
-                    const int d = (wave == 0) ? (t == 0 ? 0 : NDT) : wave + NWK * t;
-                    const int bi = d >= 6 ? 3 : d >= 3 ? 2 : d >= 1 ? 1 : 0;
-                    const bool on = d < NDT && bi < nc;                    // (monotone in t: the valid tiles come first)
-                    const int dv_ = on ? d : 0, bi_ = on ? bi : 0, bc_ = dv_ - bi_ * (bi_ + 1) / 2;
-                    dd[t] = dv_;
-                    nd += on ? 1 : 0;
-                    ra[t] = Lt + ((size_t)(k + bc_) * ntw) * MF_IMG;
-                    rb[t] = Lt + ((size_t)(k + bi_) * ntw) * MF_IMG;
-                }
-                const int kl = k - 1;
-                d4 ga[2][4], gb[2][4];
+                constexpr int TPW_ALL = (NDT - 1 + NWK - 1) / NWK;         // tiles per worker, at most (wave 0: tile 0 only)
+                constexpr int DPW = TPW_ALL < 3 ? TPW_ALL : 3;             // ... side by side; the rest in further batches (one worker: 3 x 3)
+                static_assert(DPW >= 1, "diagonal-block tiles per worker");
 #define BG_DG_LOAD(st, j0, NPC)                                                                                      \
     do {                                                                                                             \
         _Pragma("unroll") for (int jq_ = 0; jq_ < 4 / NPC; ++jq_) {                                                  \
@@ -355,6 +362,73 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
             if (j + JC_ < k) BG_DG_USE(1, NPC);                                                                      \
         }                                                                                                            \
     } while (0)
+                if (NWK == 1) {
+                    // Two-wave shape: ONE sweep over j per wave, the row operands L_(k+i)j fetched once per j for every product they
+                    // feed (tile by tile it was two loads per tile and j), two stages.  Wave 0 takes the three tiles its chain starts
+                    // with -- (0,0), (1,0), (1,1): rows k, k+1 -- so that the first two diagonal factors do not wait for the worker;
+                    // the worker takes the seven tiles of the block rows 2 and 3.
+                    const int d_lo = (wave == 0) ? 0 : 3, d_hi = (wave == 0) ? 2 : NDT - 1;
+                    const int i_hi = (wave == 0) ? 1 : BG_C - 1;
+                    const int kl = k - 1;
+                    const double* rrow[BG_C];
+#pragma unroll
+                    for (int i = 0; i < BG_C; ++i) rrow[i] = Lt + ((size_t)(k + min(i, nc - 1)) * ntw) * MF_IMG;
+                    d4 op[2][BG_C], tacc[NDT];
+#pragma unroll
+                    for (int i = 0; i < BG_C; ++i) op[0][i] = op[1][i] = d4{0.0, 0.0, 0.0, 0.0};
+                    if (k > 0) {
+#pragma unroll
+                        for (int i = 0; i < BG_C; ++i)
+                            if (i <= i_hi) op[0][i] = mf_img_load(rrow[i], lane);
+                    }
+#pragma unroll
+                    for (int d = 0; d < NDT; ++d) {
+                        const int bi = d >= 6 ? 3 : d >= 3 ? 2 : d >= 1 ? 1 : 0, bc = d - bi * (bi + 1) / 2;
+                        tacc[d] = d4{0.0, 0.0, 0.0, 0.0};
+                        if (d >= d_lo && d <= d_hi && bi < nc) BG_INIT_TILE(tacc[d], k + bi, k + bc);
+                    }
+                    for (int j = 0; j < k; j += 2) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int jn = min(j + h + 1, kl);
+#pragma unroll
+                            for (int i = 0; i < BG_C; ++i)
+                                if (i <= i_hi) op[h ^ 1][i] = mf_img_load(rrow[i] + (size_t)jn * MF_IMG, lane);
+#pragma unroll
+                            for (int d = 0; d < NDT; ++d) {
+                                const int bi = d >= 6 ? 3 : d >= 3 ? 2 : d >= 1 ? 1 : 0, bc = d - bi * (bi + 1) / 2;
+                                if (d >= d_lo && d <= d_hi && bi < nc) tacc[d] = bg_mfma4_neg(op[h][bc], op[h][bi], tacc[d]);
+                            }
+                        }
+                    }
+                    Dmine = tacc[0];                               // (wave 0; the worker's copy is zero and unused)
+#pragma unroll
+                    for (int d = 1; d < NDT; ++d) {
+                        const int bi = d >= 6 ? 3 : d >= 3 ? 2 : 1;
+                        if (d >= d_lo && d <= d_hi && bi < nc) {
+                            *reinterpret_cast<d4*>(Hand + d * 256 + mf_opaque(lane) * 4) = tacc[d];
+                            mf_publish(hflag + d, step + 1);
+                        }
+                    }
+                } else
+                for (int tb = 0; tb < TPW_ALL; tb += DPW) {
+                int dd[DPW], nd = 0;
+                const double *ra[DPW], *rb[DPW];
+                d4 dacc[DPW];
+#pragma unroll
+                for (int t = 0; t < DPW; ++t) {
+                    const int d = (wave == 0) ? (tb + t == 0 ? 0 : NDT) : wave + NWK * (tb + t);
+                    const int bi = d >= 6 ? 3 : d >= 3 ? 2 : d >= 1 ? 1 : 0;
+                    const bool on = d < NDT && bi < nc;                    // (monotone in t: the valid tiles come first)
+                    const int dv_ = on ? d : 0, bi_ = on ? bi : 0, bc_ = dv_ - bi_ * (bi_ + 1) / 2;
+                    dd[t] = dv_;
+                    nd += on ? 1 : 0;
+                    ra[t] = Lt + ((size_t)(k + bc_) * ntw) * MF_IMG;
+                    rb[t] = Lt + ((size_t)(k + bi_) * ntw) * MF_IMG;
+                }
+                if (nd == 0) break;
+                const int kl = k - 1;
+                d4 ga[2][4], gb[2][4];
 #pragma unroll
                 for (int t = 0; t < DPW; ++t) dacc[t] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -374,6 +448,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                             mf_publish(hflag + dd[t], step + 1);
                         }
                     }
+                }
                 }
             }
             BG_SUB(5);
@@ -399,11 +474,11 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                             d4 Tt = *reinterpret_cast<const d4*>(Hand + (i * (i + 1) / 2 + c) * 256 + ln * 4);
 #pragma unroll
                             for (int c2 = 0; c2 < c; ++c2)
-                                Tt = bg_mfma4_neg(mf_img_load(Lblk + (c * (c - 1) / 2 + c2) * 256, ln), Lrow[c2], Tt);
+                                Tt = bg_mfma4_neg(mf_img_load(Lblk_at(c, c2), ln), Lrow[c2], Tt);
                             const d4 lvc = mf_img_load(LinvC + c * 256, ln);
                             Lrow[c] = BG_TRSM(lvc, Tt);                     // operand image of L_(k+i)(k+c)
                             mf_img_store(Lt + ((size_t)(k + i) * ntw + k + c) * MF_IMG, ln, Lrow[c]);
-                            mf_img_store(Lblk + (i * (i - 1) / 2 + c) * 256, ln, Lrow[c]);
+                            mf_img_store(Lblk_at(i, c), ln, Lrow[c]);
                         }
                         BG_SUB(8);
                         timed_out |= !mf_wait_ge(hf_addr + 4u * (unsigned)(i * (i + 1) / 2 + i), step + 1);
@@ -474,7 +549,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                                     double pp = part[c][ch];
 #pragma unroll
                                     for (int c2 = 0; c2 < c; ++c2) {
-                                        const d4 lb = mf_img_load(Lblk + (c * (c - 1) / 2 + c2) * 256, ln);
+                                        const d4 lb = mf_img_load(Lblk_at(c, c2), ln);
                                         const double* zq = zv + ch * BG_NPAD + MF_TS * (k + c2) + grp;
                                         pp += (lb[0] * zq[0] + lb[1] * zq[4]) + (lb[2] * zq[8] + lb[3] * zq[12]);
                                     }
@@ -499,7 +574,8 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                     }
                 }
                 BG_SUB(8);
-            } else {
+            }
+            if (STEAL || wave != 0) {
                 // Rows k + nc .. nt - 1 are dealt round-robin to the workers, the wave that shares its SIMD with wave 0 first, the
                 // ones with two diagonal-block tiles last.  (The right-hand sides used to ride along as one more tile row -- a full
                 // row of MFMAs for 1..3 live channels of 16, and with 4 m + 1 rows per step the busiest SIMD always carried m + 1
@@ -510,8 +586,22 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                 const int rows_tot = nt - (k + nc);
                 const int rows_w = (rows_tot - 1 - q0 >= 0) ? (rows_tot - 1 - q0) / NWK + 1 : 0;
                 bool stop = false;
-                for (int p0 = 0; p0 < rows_w && !stop; p0 += BG_RMAX) {
-                    const int np = min(BG_RMAX, rows_w - p0);
+                for (int p0 = 0; !stop; p0 += BG_RMAX) {
+                    int np, first_row, row_stride;
+                    if constexpr (STEAL) {
+                        int pnum = 0;
+                        if (lane == 0) pnum = __hip_atomic_fetch_add(flag + 28 + step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        pnum = __builtin_amdgcn_readfirstlane(pnum);
+                        first_row = pnum * BG_RMAX;
+                        if (first_row >= rows_tot) break;
+                        np = min(BG_RMAX, rows_tot - first_row);
+                        row_stride = 1;
+                    } else {
+                        if (p0 >= rows_w) break;
+                        np = min(BG_RMAX, rows_w - p0);
+                        first_row = q0 + NWK * p0;
+                        row_stride = NWK;
+                    }
                     d4 acc[BG_C][BG_RMAX];
                     int rr[BG_RMAX];
                     // two operand stages: while one feeds the 4 BG_C NPC MFMAs of a j, the loads of the next j are in flight.
@@ -525,7 +615,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                     const double* rw_[BG_RMAX];
 #pragma unroll
                     for (int t = 0; t < BG_RMAX; ++t) {
-                        rr[t] = k + nc + q0 + NWK * (p0 + min(t, np - 1));      // (t >= np: a copy of the last row, never stored)
+                        rr[t] = k + nc + first_row + row_stride * min(t, np - 1);   // (t >= np: a copy of the last row, never stored)
                         rw_[t] = Lt + ((size_t)rr[t] * ntw) * MF_IMG;
                     }
                     d4 sa[2][BG_C], sb[2][BG_RMAX];
@@ -587,7 +677,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                                     if (t < np) {
 #pragma unroll
                                         for (int c2 = 0; c2 < c; ++c2)
-                                            acc[c][t] = bg_mfma4_neg(mf_img_load(Lblk + (c * (c - 1) / 2 + c2) * 256, ln), acc[c2][t], acc[c][t]);
+                                            acc[c][t] = bg_mfma4_neg(mf_img_load(Lblk_at(c, c2), ln), acc[c2][t], acc[c][t]);
                                         acc[c][t] = BG_TRSM(lv, acc[c][t]);
                                         mf_img_store(Lt + ((size_t)rr[t] * ntw + k + c) * MF_IMG, ln, acc[c][t]);
                                     }
@@ -840,7 +930,9 @@ size_t big_slot_doubles(int ntw) { return ((size_t)(ntw + 1) * ntw + 2 * (size_t
 // against 2.68 M patches/s on C2: each workgroup runs 2.2x longer -- the shape is bound by the factor stream, not by latency.)
 static void big_shape(const DenseArgs& a, bool irls, int* waves, int* npad, int* per_cu)
 {
-    if (a.n_max <= 256) { *waves = 4; *npad = 256; *per_cu = 2; }
+    // depth plane, n <= 256: TWO waves per workgroup (the chain wave + one worker) and FOUR workgroups per CU (40 KB of LDS each)
+    if (a.n_max <= 256 && a.ny == 1 && !irls && !a.v_star && !getenv("GPC_BIG_NO_W2")) { *waves = 2; *npad = 256; *per_cu = 4; }
+    else if (a.n_max <= 256) { *waves = 4; *npad = 256; *per_cu = 2; }
     // depth plane only, up to 384 points: four waves, two patches per CU (62 KB of LDS each).  Measured on the producer's own batches
     // (273 .. 324 points): GP phase 3.29 against 3.42 ms; at n = 512 the 8-wave shape wins (13.2 against 13.4 ms on C3)
     else if (a.n_max <= 384 && a.ny == 1 && !irls && !getenv("GPC_BIG_NO_W4")) { *waves = 4; *npad = 512; *per_cu = 2; }
@@ -866,7 +958,7 @@ size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
 template <int W, int NP, int RM, int OC, bool IRLS = false, int NYP = 3>
 static int big_launch_t(gpc_ctx* ctx, const BigParams& g, int grid)
 {
-    const size_t lds = sizeof(double) * (size_t)bg_lds_doubles(NP, 4, NYP);
+    const size_t lds = sizeof(double) * (size_t)bg_lds_doubles(NP, 4, NYP, W == 2);
     // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
     GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_big_kernel<W, NP, RM, OC, IRLS, 4, NYP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -951,6 +1043,10 @@ int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
         GPC_HIP(ctx, hipMalloc(&g.stamps, sizeof(unsigned long long) * BG_NPH * 8));
         GPC_HIP(ctx, hipMemsetAsync(g.stamps, 0, sizeof(unsigned long long) * BG_NPH * 8, ctx->stream));
         dump.d = g.stamps;
+    }
+    if (waves == 2) {
+        ctx->last_dense_kernel = "dense_mfma_big_w2";
+        return big_launch_t<2, 256, 2, 2, false, 1>(ctx, g, grid);
     }
     if (waves == 4 && npad == 256) {
         ctx->last_dense_kernel = "dense_mfma_big_w4";
