@@ -296,6 +296,16 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
     const bool ny_ok = a.ny == 1 || a.ny == 3;
     if (!force_generic && !force_big && ny_ok) {
         const bool no_split = a.P == 1 || getenv("GPC_NO_SPLIT");
+        // 192 < n <= 256, depth plane, mean only (BASELINE config 2): the tiled kernel in its TWO-WAVE shape -- four patches in flight
+        // per CU instead of one, so that a patch's serial chain runs under the MFMAs of three others (C2: 2.15 against 2.57 ms for
+        // the register-resident kernel, which keeps the colour planes, the variance export, the small sizes and 257 .. 272 points)
+        if (a.n_max > 192 && a.n_max <= 256 && a.ny == 1 && !a.v_star && a.P > 1 && !getenv("GPC_NO_W2")) {
+            int grid_w2 = 0;
+            const size_t w2_bytes = (dense_big_ws_bytes(ctx, a, &grid_w2) + 255) & ~(size_t)255;
+            const int rcw = gpc_ws_reserve(ctx, w2_bytes);
+            if (rcw != GPC_OK) return rcw;
+            return dense_big_launch(ctx, a, grid_w2);
+        }
         if (a.n_max <= 256 || (no_split && dense_mfma_supported(a) && !getenv("GPC_NO_NT17")))
             return dense_mfma_launch(ctx, a);                                                               // one shape for the whole batch
         if (!a.v_star && a.n_max <= GPC_MAX_POINTS && !no_split) {
