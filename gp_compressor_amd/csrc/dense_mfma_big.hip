@@ -6,21 +6,24 @@
 // 16 x 16 tiles in MFMA *operand image* layout (mfma_tile.h; 2 KB each, read back with two coalesced 16-byte loads per
 // lane) and the factorisation is a tiled LEFT-looking Cholesky:
 //
-//   columns k, k+1:  T_rc = A_rc - sum_{j<k} L_rj L_cj^T   (4 v_mfma_f64_16x16x4_f64 per (r, c, j)),   r = k .. nt
+//   columns k .. k+3:  T_rc = A_rc - sum_{j<k} L_rj L_cj^T   (4 v_mfma_f64_16x16x4_f64 per (r, c, j)),   r = k .. nt-1
 //              L_kk^-1 by the in-place Gauss-Jordan on the MFMA pipe (mf_diag_factor),   L_rk = T_rk L_kk^-T (4 MFMAs)
 //
 // * K itself is never stored: A_rk is evaluated (RBF + noise diagonal) straight into the accumulator registers when
 //   column k starts.  HBM/L2 see the factor only: one write per tile, nt/3 reads on average.
-// * TWO tile columns per step: every fetched tile L_rj feeds the accumulators of both columns (the kernel streams the
-//   factor from HBM / Infinity Cache: 4 TB/s measured, it was 5.8 TB/s and 25 % slower with one column per step).  Tile
-//   rows are dealt round-robin to the waves; a wave keeps up to BG_RMAX rows (x 2 columns) of accumulators, loads the
-//   shared operands L_kj, L_(k+1)j once per j for all of them, and keeps the loads of the next two j in flight.
-// * The right-hand sides ride along as one more tile row (row nt holds y^T padded to 16 channels): its TRSM result is
-//   z^T, so the forward solve needs no code of its own.
-// * Wave 0 owns the 2 x 2 diagonal block of the step (update, factor, TRSM, update, factor) while the other waves stream
-//   their row updates; they poll an LDS word for each L^-1 (bounded asm poll, mfma_tile.h).  One workgroup barrier per step.
-// * The kernel is a template over waves per workgroup and padded size: <8, 1024> is the production shape (one workgroup
-//   per CU); <4, 256> runs two workgroups per CU and is kept as a cross-check of dense_mfma.hip (GPC_FORCE_BIG=1).
+// * FOUR tile columns per step (BG_C): every fetched tile L_rj feeds the accumulators of all four columns (the kernel streams
+//   the factor from HBM / Infinity Cache: with one column per step it was plainly bound by that stream).  Tile rows are dealt
+//   round-robin to the workers; a wave keeps up to BG_RMAX rows (x 4 columns) of accumulators, loads the shared column
+//   operands once per j for all of them, and keeps the loads of the next j in flight.
+// * The right-hand sides are a vector object: wave 0 solves z for the step's columns behind its chain (16 x 16 mat-vecs on the
+//   VALU from the operand images, z in LDS).  (They used to ride along as one more tile row of MFMAs.)
+// * Wave 0 owns the 4 x 4 diagonal block of the step -- its ten tiles are computed first (by all waves) and handed over; then the
+//   chain: four diagonal factors, six TRSM / update pairs -- while the other waves stream their row updates; they poll an LDS
+//   word for each L^-1 (bounded asm poll, mfma_tile.h).  One workgroup barrier per step.
+// * The kernel is a template over waves per workgroup and padded size: <8, 1024> is the shape for 256 < n <= 1024 (one workgroup
+//   per CU); <2, 256> -- chain wave + ONE worker, FOUR workgroups = four patches per CU, row passes taken from an LDS counter by
+//   both waves -- is the C2 headline kernel (depth plane, 193 .. 256 points); <4, 256> (two workgroups per
+//   CU) serves the colour planes under GPC_FORCE_BIG and is a cross-check.
 // * Backward solve: alpha_k = L_kk^-T (z_k - sum_{i>k} L_ik^T alpha_i); the tile products contract over the ROW index,
 //   which the image layout cannot feed to an MFMA, so they run on the VALU with the DPP row reduction of mfma_tile.h
 //   (O(n^2) work against the O(n^3) of the factorisation).  Predictive mean: the separable-grid MFMA form of
@@ -236,13 +239,12 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         bool bad = false;
         BG_STAMP(0);
 
-        // ---- tiled left-looking Cholesky, two tile columns (k, k+1) per step; tile row nt carries the right-hand sides ----
-        // Two columns per step halve the dominant HBM stream: every tile L_rj fetched for the update of row r feeds the
-        // accumulators of both columns (8 MFMAs per 2 KB instead of 4; measured 5.8 TB/s with one column per step).
-        // Wave 0 owns the 2 x 2 diagonal block (tiles (k,k), (k+1,k), (k+1,k+1)): update -> factor (k,k) -> TRSM (k+1,k) ->
-        // update and factor (k+1,k+1), publishing each L^-1 as it appears.  The rows r >= k+2 (and the right-hand-side row
-        // nt) are dealt to the waves 1, 2, .., 7, 0, 1, ..: update both accumulators, L_rk = TRSM(acc0), acc1 -= L_rk L_(k+1)k^T,
-        // L_r(k+1) = TRSM(acc1).
+        // ---- tiled left-looking Cholesky, BG_C = 4 tile columns (k .. k+3) per step ----
+        // Four columns per step quarter the dominant stream: every tile L_rj fetched for the update of row r feeds the accumulators
+        // of all four columns (16 MFMAs per 2 KB).  Wave 0 owns the 4 x 4 diagonal block: factor (k,k), then row by row TRSM /
+        // update / factor, publishing each L^-1 as it appears.  The rows r >= k+4 are dealt to the workers (or taken from a counter,
+        // two-wave shape): update the four accumulators, then column by column  acc_c -= sum_{c2<c} L_r(k+c2) L_(k+c)(k+c2)^T,
+        // L_r(k+c) = TRSM(acc_c).
 #define BG_INIT_TILE(dst, r_, kc_)                                                                                   \
     do {                                                                                                             \
         if ((r_) < nt) {                                                                                             \

@@ -104,12 +104,21 @@ def stats(op, off, x0, x1, y, xs0, xs1, f_gpu, ft_gpu, sample, full_oracle=True,
     # what the exact recursion does on the patches where an fp64 implementation blew up (rounding artefact or property of the data?)
     blow_g = np.where(r_g > BLOWUP)[0]
     blow_o = o_idx[np.where(r_o > BLOWUP)[0]]
-    blow = np.array(sorted(set(blow_g.tolist()) | set(blow_o.tolist())), dtype=np.int64)[:32]
+    blow = np.array(sorted(set(blow_g.tolist()) | set(blow_o.tolist())), dtype=np.int64)
+    if len(blow) > 32:
+        # many (the basis-filling regime, where the exact recursion leaves the data range as well): the GPU's three worst and the
+        # first few -- enough to say whether the others follow it there
+        top = blow_g[np.argsort(r_g[blow_g])[::-1][:3]]
+        blow = np.array(sorted(set(top.tolist()) | set(blow[:8].tolist())), dtype=np.int64)
     blow_list = []
     if len(blow):
         f_hb = run_cpu(op, off, x0, x1, y, xs0, xs1, blow, hp=True, threads=threads)[0]
         for k, i in enumerate(blow):
-            blow_list.append({"patch": int(i), "gpu": float(r_g[i]), "oracle": float(r_o[np.where(o_idx == i)[0][0]]) if i in o_idx else None,
+            if i in pos:
+                ro_i = float(r_o[pos[int(i)]])
+            else:                                      # outside the oracle's patch set: run it on this one
+                ro_i = float(np.max(np.abs(run_cpu(op, off, x0, x1, y, xs0, xs1, [i], threads=1)[0])) / max(ymax[i], 1e-300))
+            blow_list.append({"patch": int(i), "gpu": float(r_g[i]), "oracle": ro_i,
                               "arbiter": float(np.max(np.abs(f_hb[k])) / max(ymax[i], 1e-300))})
     wg = int(np.argmax(r_g))
     wo = int(o_idx[int(np.argmax(r_o))])
