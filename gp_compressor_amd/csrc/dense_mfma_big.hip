@@ -158,6 +158,12 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
     const DenseArgs& A = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (BG_WAVES == 4) {
+        // (four-wave shape, two workgroups per CU: both chain waves would sit on SIMD 0 -- the second workgroup's chain goes to SIMD 2)
+        if (tid == 0) flag[27] = (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u);
+        __syncthreads();
+        wave ^= 2 * __builtin_amdgcn_readfirstlane(flag[27]);
+    }
     if constexpr (BG_WAVES == 2) {
         // Two-wave shape, four workgroups per CU: the dispatcher puts the first waves of two workgroups on one SIMD and their second
         // waves on the next, so with fixed roles a SIMD would host two chain waves (its MFMA pipe mostly idle) and its neighbour two
@@ -935,9 +941,11 @@ static void big_shape(const DenseArgs& a, bool irls, int* waves, int* npad, int*
     // depth plane, n <= 256: TWO waves per workgroup (the chain wave + one worker) and FOUR workgroups per CU (40 KB of LDS each)
     if (a.n_max <= 256 && a.ny == 1 && !irls && !a.v_star && !getenv("GPC_BIG_NO_W2")) { *waves = 2; *npad = 256; *per_cu = 4; }
     else if (a.n_max <= 256) { *waves = 4; *npad = 256; *per_cu = 2; }
-    // depth plane only, up to 384 points: four waves, two patches per CU (62 KB of LDS each).  Measured on the producer's own batches
-    // (273 .. 324 points): GP phase 3.29 against 3.42 ms; at n = 512 the 8-wave shape wins (13.2 against 13.4 ms on C3)
-    else if (a.n_max <= 384 && a.ny == 1 && !irls && !getenv("GPC_BIG_NO_W4")) { *waves = 4; *npad = 512; *per_cu = 2; }
+    // depth plane only, up to 512 points: four waves, two patches per CU (62 KB of LDS each).  Measured on the producer's own batches
+    // (273 .. 324 points): GP phase 3.29 against 3.42 ms.  At n = 512 (C3) the 8-wave shape used to win, 13.2 against 13.4 ms -- both
+    // chain waves sat on SIMD 0, which then idled; with the second workgroup's chain on SIMD 2 (HW_ID wave slot, see the kernel) the
+    // two-workgroup shape wins, 12.23 against 12.63 ms on the same box (round 3)
+    else if (a.n_max <= (getenv("GPC_BIG_W4_384") ? 384 : 512) && a.ny == 1 && !irls && !getenv("GPC_BIG_NO_W4")) { *waves = 4; *npad = 512; *per_cu = 2; }
     else { *waves = 8; *npad = 1024; *per_cu = 1; }
 }
 
