@@ -119,7 +119,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
     // worker from the start, wave 0 once its chain and the forward solve are done (with one worker the rows are the long pole of
     // a step and the chain wave would idle half of it at the barrier)
     constexpr bool STEAL = BG_WAVES == 2;
-    static_assert(!STEAL || BG_NPAD <= 256, "one pass counter per step in four spare flag words");
+    static_assert(!STEAL || (BG_NPAD <= 512 && !BG_IRLS), "one pass counter per step in flag words 8 .. 15 (the IRLS loop keeps its step size there)");
     static_assert(BG_NYP == 3 || (BG_NYP == 1 && !BG_IRLS), "planes of the solve vectors (the IRLS loop keeps its vectors in planes 1, 2)");
     constexpr int B_PX0 = 64, B_PX1 = B_PX0 + BG_NPAD, B_ZV = B_PX1 + BG_NPAD, B_WV = B_ZV + BG_NYP * BG_NPAD, B_AV = B_WV + BG_NYP * BG_NPAD,
                   B_RS = B_AV + BG_NYP * BG_NPAD, B_FLAG = B_RS + 32, B_LINV = B_FLAG + 16, B_LBLK = B_LINV + BG_C * 256,
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         [[maybe_unused]] unsigned long long sub_acc_[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
         unsigned long long* ext_bits = reinterpret_cast<unsigned long long*>(lds + B_FLAG + 3);   // max-norm extent, as bits
         if (tid < NDT) hflag[tid] = 0;
-        if (STEAL && tid < 4) flag[28 + tid] = 0;              // pass counters of the four steps
+        if (STEAL && tid < 8) flag[8 + tid] = 0;               // pass counters of the (up to eight) steps
         if (tid == 0) {
             flag[0] = 0;
             flag[1] = -1;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                     int np, first_row, row_stride;
                     if constexpr (STEAL) {
                         int pnum = 0;
-                        if (lane == 0) pnum = __hip_atomic_fetch_add(flag + 28 + step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (lane == 0) pnum = __hip_atomic_fetch_add(flag + 8 + step, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         pnum = __builtin_amdgcn_readfirstlane(pnum);
                         first_row = pnum * BG_RMAX;
                         if (first_row >= rows_tot) break;
@@ -941,6 +941,8 @@ static void big_shape(const DenseArgs& a, bool irls, int* waves, int* npad, int*
     // depth plane, n <= 256: TWO waves per workgroup (the chain wave + one worker) and FOUR workgroups per CU (40 KB of LDS each)
     if (a.n_max <= 256 && a.ny == 1 && !irls && !a.v_star && !getenv("GPC_BIG_NO_W2")) { *waves = 2; *npad = 256; *per_cu = 4; }
     else if (a.n_max <= 256) { *waves = 4; *npad = 256; *per_cu = 2; }
+    // (the two-wave shape at 512 points, three workgroups per CU at 50 KB of LDS: 16.0 ms on C3 against 12.2 -- six waves per CU, and
+    // one worker cannot carry a step's 28 row passes)
     // depth plane only, up to 512 points: four waves, two patches per CU (62 KB of LDS each).  Measured on the producer's own batches
     // (273 .. 324 points): GP phase 3.29 against 3.42 ms.  At n = 512 (C3) the 8-wave shape used to win, 13.2 against 13.4 ms -- both
     // chain waves sat on SIMD 0, which then idled; with the second workgroup's chain on SIMD 2 (HW_ID wave slot, see the kernel) the
