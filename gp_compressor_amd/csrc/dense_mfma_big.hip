@@ -54,6 +54,16 @@ struct BigParams {
     double* irls_fhat;            // [n_total] latent mode at the training points, or nullptr
 };
 #define BG_NPH 12
+// Diagnostic builds only (tools/r3_exp.sh; results are wrong by construction, timings tell what a phase costs under real overlap):
+//   -DBG_EXP_HOT     every j-indexed operand load reads tile column 0 (L1 hits): what the factor stream costs
+//   -DBG_EXP_NOGRAM  the Gram tiles are a constant diagonally dominant matrix (no exponentials)
+//   -DBG_EXP_NOBACK / -DBG_EXP_NOPRED  skip the backward solve / the predictive mean
+#ifdef BG_EXP_HOT
+__device__ static __forceinline__ int bg_exp_zero() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }   // (not hoistable)
+#define BG_JX(j) bg_exp_zero()
+#else
+#define BG_JX(j) (j)
+#endif
 // -DBG_SUBSTAMPS (diagnostic build, tools/stamp_big.py): the factorisation step split into 5 diagonal-block tiles, 6 update loops,
 // 7 waiting for an L^-1 (workers) or a hand-over (wave 0), 8 TRSMs (workers) or the chain (wave 0), 9 end-of-step barrier
 #ifdef BG_SUBSTAMPS
@@ -251,6 +261,11 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         // update / factor, publishing each L^-1 as it appears.  The rows r >= k+4 are dealt to the workers (or taken from a counter,
         // two-wave shape): update the four accumulators, then column by column  acc_c -= sum_{c2<c} L_r(k+c2) L_(k+c)(k+c2)^T,
         // L_r(k+c) = TRSM(acc_c).
+#ifdef BG_EXP_NOGRAM
+#define BG_GRAM_VALUE(xi0_, xi1_, pj_) ((pi_ == (pj_)) ? sf : 0.001 * sf)
+#else
+#define BG_GRAM_VALUE(xi0_, xi1_, pj_) (small_gram ? gpc_rbf_small(sf, cexp, xi0_, xi1_, px0[pj_], px1[pj_]) : gpc_rbf_neg(sf, cexp, xi0_, xi1_, px0[pj_], px1[pj_], T))
+#endif
 #define BG_INIT_TILE(dst, r_, kc_)                                                                                   \
     do {                                                                                                             \
         if ((r_) < nt) {                                                                                             \
@@ -258,8 +273,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
             const double xi0_ = px0[pi_], xi1_ = px1[pi_];                                                           \
             _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
                 const int pj_ = MF_TS * (kc_) + lg + 4 * q_;                                                         \
-                double v_ = small_gram ? gpc_rbf_small(sf, cexp, xi0_, xi1_, px0[pj_], px1[pj_])                      \
-                                       : gpc_rbf_neg(sf, cexp, xi0_, xi1_, px0[pj_], px1[pj_], T);                   \
+                double v_ = BG_GRAM_VALUE(xi0_, xi1_, pj_);                                                          \
                 if constexpr (BG_IRLS) v_ = (v_ * sv[pi_]) * sv[pj_];                                                \
                 if (pi_ == pj_) {                                                                                    \
                     if constexpr (BG_IRLS) {                                                                         \
@@ -342,8 +356,8 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         _Pragma("unroll") for (int jq_ = 0; jq_ < 4 / NPC; ++jq_) {                                                  \
             const int jj_ = min((j0) + jq_, kl);                                                                     \
             _Pragma("unroll") for (int t = 0; t < NPC; ++t) {                                                        \
-                ga[st][jq_ * NPC + t] = mf_img_load(ra[t] + (size_t)jj_ * MF_IMG, lane);                             \
-                gb[st][jq_ * NPC + t] = mf_img_load(rb[t] + (size_t)jj_ * MF_IMG, lane);                             \
+                ga[st][jq_ * NPC + t] = mf_img_load(ra[t] + (size_t)BG_JX(jj_) * MF_IMG, lane);                             \
+                gb[st][jq_ * NPC + t] = mf_img_load(rb[t] + (size_t)BG_JX(jj_) * MF_IMG, lane);                             \
             }                                                                                                        \
         }                                                                                                            \
     } while (0)
@@ -401,7 +415,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                             const int jn = min(j + h + 1, kl);
 #pragma unroll
                             for (int i = 0; i < BG_C; ++i)
-                                if (i <= i_hi) op[h ^ 1][i] = mf_img_load(rrow[i] + (size_t)jn * MF_IMG, lane);
+                                if (i <= i_hi) op[h ^ 1][i] = mf_img_load(rrow[i] + (size_t)BG_JX(jn) * MF_IMG, lane);
 #pragma unroll
                             for (int d = 0; d < NDT; ++d) {
                                 const int bi = d >= 6 ? 3 : d >= 3 ? 2 : d >= 1 ? 1 : 0, bc = d - bi * (bi + 1) / 2;
@@ -464,6 +478,9 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                 // the serial chain of the block: factor (k,k); then row by row  L_ic = (T_ic - sum_{c2<c} L_ic2 L_cc2^T) L_cc^-T,
                 // T_ii -= sum_c L_ic L_ic^T, factor -- every L^-1 published as it appears, the block's tiles left in LDS for the workers
                 bool ok = mf_diag_factor<true>(Dmine, rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol);
+#ifdef BG_EXP_HOT
+                ok = true;
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (g.export_factor) mf_img_store(LinvG + (size_t)k * MF_IMG, lane, mf_img_load(LinvC, lane));
                 if (!ok && lane == 0) flag[0] = 1;
@@ -495,6 +512,9 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
 #pragma unroll
                         for (int c = 0; c < i; ++c) Dii = bg_mfma4_neg(Lrow[c], Lrow[c], Dii);
                         ok = mf_diag_factor<true>(Dii, rsbuf, LinvC + i * 256, LinvTg + (size_t)(k + i) * MF_IMG, g.pivot_tol);
+#ifdef BG_EXP_HOT
+                        ok = true;
+#endif
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                                 if (g.export_factor) mf_img_store(LinvG + (size_t)(k + i) * MF_IMG, lane, mf_img_load(LinvC + i * 256, mf_opaque(lane)));
                         if (!ok && lane == 0) flag[0] = 1;
@@ -531,7 +551,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                         for (int h = 0; h < 2; ++h) {
                             const int jn = min(j + h + 1, k - 1);
 #pragma unroll
-                            for (int c = 0; c < BG_C; ++c) fa[h ^ 1][c] = mf_img_load(rc_[c] + (size_t)jn * MF_IMG, ln);
+                            for (int c = 0; c < BG_C; ++c) fa[h ^ 1][c] = mf_img_load(rc_[c] + (size_t)BG_JX(jn) * MF_IMG, ln);
                             if (j + h < k) {
 #pragma unroll
                                 for (int ch = 0; ch < BG_NYP; ++ch) {
@@ -630,8 +650,8 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                     const int kl = k - 1;
 #define BG_LOAD_STAGE(st, jj, NPC)                                                                                   \
     do {                                                                                                             \
-        _Pragma("unroll") for (int c = 0; c < BG_C; ++c) sa[st][c] = mf_img_load(rc_[c] + (size_t)(jj) * MF_IMG, lane); \
-        _Pragma("unroll") for (int t = 0; t < NPC; ++t) sb[st][t] = mf_img_load(rw_[t] + (size_t)(jj) * MF_IMG, lane);  \
+        _Pragma("unroll") for (int c = 0; c < BG_C; ++c) sa[st][c] = mf_img_load(rc_[c] + (size_t)BG_JX(jj) * MF_IMG, lane); \
+        _Pragma("unroll") for (int t = 0; t < NPC; ++t) sb[st][t] = mf_img_load(rw_[t] + (size_t)BG_JX(jj) * MF_IMG, lane);  \
     } while (0)
 #define BG_USE_STAGE(st, NPC)                                                                                        \
     do {                                                                                                             \
@@ -708,6 +728,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
 #endif
         __syncthreads();   // z (LDS, written by wave 0 step by step) is complete
         BG_STAMP(2);
+#ifndef BG_EXP_NOBACK
         // ---- backward solve L^T alpha = z, tile columns from the last to the first ----
         // Column k needs the tiles (i, k), i = k+1+wave+W t, and L_kk^-T: they do not depend on alpha, so the loads of
         // column k-1 are issued before the products of column k (the factor sits in HBM / Infinity Cache, ~2k cycles away).
@@ -778,6 +799,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                 lt_cur = lt_nxt;
             }
         }
+#endif
         if constexpr (!BG_IRLS) break;
         if constexpr (BG_IRLS) {
             // the solve gave u = B^-1 W^1/2 t:  a = W^1/2 u,  f_new = K a = t - W^-1 a = t - W^-1/2 u;  the step's max |f_new - f|
@@ -836,6 +858,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
         }
 
         BG_STAMP(3);
+#ifndef BG_EXP_NOPRED
         // ---- predictive mean ----
         if (A.xs0 == nullptr && A.grid_sz <= 32) {
             // separable grid: f[py][px] = sum_i Ey[py][i] * (sf alpha_i Ex[px][i]); 32-point chunks dealt to the waves
@@ -917,6 +940,7 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
                     if (c < ny) fs[(size_t)c * m + p] = s_[c];
             }
         }
+#endif
         BG_STAMP(4);
         if (timed_out && lane == 0) flag[0] = 2;
         __syncthreads();

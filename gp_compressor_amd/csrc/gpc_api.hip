@@ -299,6 +299,14 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
         // 192 < n <= 256, depth plane, mean only (BASELINE config 2): the tiled kernel in its TWO-WAVE shape -- four patches in flight
         // per CU instead of one, so that a patch's serial chain runs under the MFMAs of three others (C2: 2.15 against 2.57 ms for
         // the register-resident kernel, which keeps the colour planes, the variance export, the small sizes and 257 .. 272 points)
+        if (a.n_max > 192 && a.n_max <= 256 && a.P > 1 && dense_w1_supported(a) && !getenv("GPC_NO_W1") && !getenv("GPC_NO_W2")) {
+            // (round 3, later) ONE wave per patch, eight patches per CU: no hand-over between waves at all (dense_mfma_w1.hip)
+            int grid_w1 = 0;
+            const size_t w1_bytes = (dense_w1_ws_bytes(ctx, a, &grid_w1) + 255) & ~(size_t)255;
+            const int rcw = gpc_ws_reserve(ctx, w1_bytes);
+            if (rcw != GPC_OK) return rcw;
+            return dense_w1_launch(ctx, a, grid_w1);
+        }
         if (a.n_max > 192 && a.n_max <= 256 && a.ny == 1 && !a.v_star && a.P > 1 && !getenv("GPC_NO_W2")) {
             int grid_w2 = 0;
             const size_t w2_bytes = (dense_big_ws_bytes(ctx, a, &grid_w2) + 255) & ~(size_t)255;

@@ -143,6 +143,10 @@ int dense_variance_big_launch(gpc_ctx* ctx, const DenseArgs& a, int ntw, const d
 bool dense_big_supported(const DenseArgs& a);
 size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out);
 int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid);
+// one wave per patch, eight patches per CU: n <= 256, depth plane, mean only (see dense_mfma_w1.hip) -- the C2 headline kernel
+bool dense_w1_supported(const DenseArgs& a);
+size_t dense_w1_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out);
+int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a, int grid);
 // the same kernel inside the Newton / IRLS loop of the probit variant (BASELINE config 5; any n <= 1024, ny == 1)
 struct IrlsArgs {
     int max_iter;

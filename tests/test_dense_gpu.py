@@ -58,14 +58,14 @@ def test_dense_golden(gp, name, monkeypatch):
         _close(f2, f, 1e-12)
 
 
-@pytest.fixture(params=["dispatch", "generic", "big", "reg", "big_w4"])
+@pytest.fixture(params=["dispatch", "generic", "big", "reg", "big_w4", "w2"])
 def kernel_choice(request, monkeypatch):
     """Run a test with the normal dispatch (register-tile MFMA kernel for n <= 256 -- the two-wave shape of the tiled kernel for the
     depth plane of 193 .. 256 points -- and the tiled left-looking MFMA kernel above), with the generic global-workspace kernel
     forced, with the left-looking kernel forced for every n (its two-wave / four-workgroups-per-CU shape below 257 points for the
     depth plane), with the register-tile kernel for every n <= 256 ("reg": GPC_NO_W2), and with the tiled kernel's four-wave
     shape ("big_w4").  The environment is read at every call."""
-    for e in ("GPC_FORCE_GENERIC", "GPC_FORCE_BIG", "GPC_NO_W2", "GPC_BIG_NO_W2"):
+    for e in ("GPC_FORCE_GENERIC", "GPC_FORCE_BIG", "GPC_NO_W2", "GPC_BIG_NO_W2", "GPC_NO_W1"):
         monkeypatch.delenv(e, raising=False)
     if request.param == "generic":
         monkeypatch.setenv("GPC_FORCE_GENERIC", "1")
@@ -76,6 +76,8 @@ def kernel_choice(request, monkeypatch):
     elif request.param == "big_w4":
         monkeypatch.setenv("GPC_FORCE_BIG", "1")
         monkeypatch.setenv("GPC_BIG_NO_W2", "1")
+    elif request.param == "w2":          # the two-wave shape of the tiled kernel where the one-wave-per-patch kernel is the default
+        monkeypatch.setenv("GPC_NO_W1", "1")
     return request.param
 
 
@@ -104,10 +106,12 @@ def test_dense_vs_oracle(gp, oracle, kernel_choice, P, n, ny, ragged, seed):
     f, _, st, al = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
     fo, _, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, want_alpha=True)
     n_max = int(np.max(np.diff(off)))
-    # (192 < n <= 256, depth plane, more than one patch: the two-wave shape of the tiled kernel, four patches per CU)
+    # (192 < n <= 256, depth plane, more than one patch: one wave per patch, eight patches per CU -- dense_mfma_w1; with GPC_NO_W1 the
+    # two-wave shape of the tiled kernel, four patches per CU)
     w2 = 192 < n_max <= 256 and y.shape[0] == 1 and P > 1 and kernel_choice != "reg"
     want_kernel = {"generic": "dense_generic", "big": "dense_mfma_big", "big_w4": "dense_mfma_big"}.get(
-        kernel_choice, ("dense_mfma_nt16 + " if P > 1 else "dense_mfma_big") if n_max > 256 else ("dense_mfma_big_w2" if w2 else "dense_mfma_nt"))
+        kernel_choice, ("dense_mfma_nt16 + " if P > 1 else "dense_mfma_big") if n_max > 256
+        else (("dense_mfma_big_w2" if kernel_choice == "w2" else "dense_mfma_w1") if w2 else "dense_mfma_nt"))
     assert ctx.last_dense_kernel().startswith(want_kernel), ctx.last_dense_kernel()
     assert np.array_equal(st, so)
     _close(f, fo, FTOL)
@@ -395,7 +399,7 @@ def test_dense_full_size_properties(gp, oracle, P, n, label):
     y2 = rng.normal(0, 0.01, size=y.shape)
     p = capi.default_params_dense()
     fa, sta, ala = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz, want_alpha=True)
-    assert ctx.last_dense_kernel() == "dense_mfma_big_w2" if n <= 256 else ctx.last_dense_kernel().endswith("dense_mfma_big")
+    assert ctx.last_dense_kernel() == "dense_mfma_w1" if n <= 256 else ctx.last_dense_kernel().endswith("dense_mfma_big")
     fb, stb = ctx.dense_fit_predict_grid(p, off, x0, x1, y2, res, sz)
     fc, stc = ctx.dense_fit_predict_grid(p, off, x0, x1, y + 2.0 * y2, res, sz)
     assert np.all(sta == 0) and np.all(stb == 0) and np.all(stc == 0)
@@ -427,7 +431,7 @@ def test_dense_headline_kernel_is_bit_reproducible(gp):
     off, x0, x1, y = synth.make_patches(2048, 256, res=res, seed=77, ragged=True, n_min=200)
     p = capi.default_params_dense()
     f0, st0, al0 = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz, want_alpha=True)
-    assert ctx.last_dense_kernel() == "dense_mfma_big_w2" and np.all(st0 == 0)
+    assert ctx.last_dense_kernel() == "dense_mfma_w1" and np.all(st0 == 0)
     for _ in range(3):
         f1, st1, al1 = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz, want_alpha=True)
         assert np.array_equal(f1, f0) and np.array_equal(al1, al0) and np.array_equal(st1, st0)
