@@ -21,6 +21,7 @@
 // dense_mfma.hip), so a TRSM result is directly the operand image of L_ik.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "gpc_device.h"
 #include "gpc_internal.h"
@@ -29,6 +30,14 @@
 #define W1_NPAD 256
 #define W1_C 4          // tile columns per step
 #define W1_NDT 10       // tiles of a step's diagonal block
+// Diagnostic build -DW1_EXP_HOT (results wrong by construction): every j-indexed operand load reads tile column 0 -- what the
+// latency of the factor stream costs
+#ifdef W1_EXP_HOT
+__device__ static __forceinline__ int w1_exp_zero() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }   // (not hoistable)
+#define W1_JX(j) w1_exp_zero()
+#else
+#define W1_JX(j) (j)
+#endif
 
 struct W1Params {
     DenseArgs a;
@@ -38,7 +47,32 @@ struct W1Params {
     size_t slot;        // doubles per slot (big_slot_doubles: same layout as the tiled kernel's)
     int ntw;            // tile columns of a slot
     int export_factor;  // slot = patch (the factor of every patch stays, with the L_kk^-1 images): predictive variance
+    unsigned long long* stamps;   // diagnostic build (-DW1_STAMPS, GPC_W1_STAMPS=1): [phase] s_memtime sums over all patches
 };
+// phases: 0 load | 1 sweep: Gram tiles | 2 sweep: j loop | 3 chain | 4 forward solve | 5 pass: first loads + Gram tiles | 6 pass: j loop |
+//         7 pass: TRSMs + stores | 8 end-of-step fence | 9 backward | 10 predict | 11 (spare)
+#define W1_NPH 12
+#ifdef W1_STAMPS
+#define W1_STAMP(ph)                                                                                                 \
+    do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        const unsigned long long t_now_ = __builtin_amdgcn_s_memtime();                                              \
+        st_acc_[ph] += t_now_ - t_prev_;                                                                             \
+        t_prev_ = t_now_;                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#else
+#define W1_STAMP(ph) do { } while (0)
+#endif
+
+// One wave per workgroup: LDS instructions of a wave execute in program order, so a value written by one lane is visible to the
+// loads of every lane that follow it in the instruction stream -- all that is needed between them is that the COMPILER keeps the
+// order.  (__syncthreads() would also wait for every global load and store in flight, i.e. for the prefetches.)
+#define W1_LDS_SYNC()                                                                                                \
+    do {                                                                                                             \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                                       \
+        __builtin_amdgcn_wave_barrier();                                                                             \
+    } while (0)
 
 __device__ static __forceinline__ d4 w1_mfma4_neg(d4 a, d4 b, d4 acc)
 {
@@ -56,39 +90,44 @@ __device__ static __forceinline__ d4 w1_trsm(d4 lv, d4 src)
     return (D0 + D1) + (D2 + D3);
 }
 
-// Gram tile (tile row r, tile column c) in the transposed C/D layout: register q of lane l = K[16 r + (l & 15)][16 c + (l >> 4) + 4 q]
-// (+ the noise diagonal, identity padding beyond n).  r, c, the mode and the two special cases are wave-uniform: interior
-// off-diagonal tiles -- nine in ten -- take the bare path (distance, exponential, nothing else).
-template <bool SMALL>
-__device__ static __forceinline__ d4 w1_gram_tile(const double* px0, const double* px1, const double* T, double sf, double cexp, double noise,
-                                                  bool dbl, int n, int r, int c, int lr, int lg)
+// Gram tiles (tile row r, tile columns c0 .. c0 + CNT - 1) in the transposed C/D layout: register q of lane l of tile t =
+// K[16 r + (l & 15)][16 (c0 + t) + (l >> 4) + 4 q]  (+ the noise diagonal, identity padding beyond n).  The bare values of all CNT
+// tiles -- distance, exponential, nothing else -- come first, in ONE basic block: 4 CNT independent dependency chains for the
+// scheduler (evaluated tile by tile behind per-tile mode branches the Gram tiles ran at a fifth of the VALU rate: stamps, round 3).
+// The noise diagonal (DIAG: the row's last tile is the diagonal tile r == c0 + CNT - 1) and the padding are wave-uniform fix-ups.
+template <bool SMALL, int CNT, bool DIAG>
+__device__ static __forceinline__ void w1_gram_row(d4 (&v)[W1_C], const double* px0, const double* px1, const double* T, double sf, double cexp,
+                                                   double noise, bool dbl, int n, int r, int c0, int lr, int lg)
 {
     const int pi = MF_TS * r + lr;
     const double xi0 = px0[pi], xi1 = px1[pi];
-    d4 v;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int pj = MF_TS * c + lg + 4 * q;
-        v[q] = SMALL ? gpc_rbf_small(sf, cexp, xi0, xi1, px0[pj], px1[pj]) : gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T);
-    }
-    if (r == c) {
+    for (int t = 0; t < CNT; ++t) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int pj = MF_TS * c + lg + 4 * q;
-            if (pi == pj) {
-                v[q] += noise;               // covariance_matrix(..., training)   gaussian_process.cpp:59-61
-                if (dbl) v[q] += noise;      // C.diagonal() += sigman_sq          :21
+            const int pj = MF_TS * (c0 + t) + lg + 4 * q;
+            v[t][q] = SMALL ? gpc_rbf_small(sf, cexp, xi0, xi1, px0[pj], px1[pj]) : gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T);
+        }
+    }
+    if constexpr (DIAG) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // pi == pj on the diagonal tile: lr == lg + 4 q
+            double d = v[CNT - 1][q] + noise;            // covariance_matrix(..., training)   gaussian_process.cpp:59-61
+            if (dbl) d += noise;                         // C.diagonal() += sigman_sq          :21
+            v[CNT - 1][q] = (lr == lg + 4 * q) ? d : v[CNT - 1][q];
+        }
+    }
+    if (MF_TS * (r + 1) > n || MF_TS * (c0 + CNT) > n) {
+#pragma unroll
+        for (int t = 0; t < CNT; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pj = MF_TS * (c0 + t) + lg + 4 * q;
+                if (pi >= n || pj >= n) v[t][q] = (pi == pj) ? 1.0 : 0.0;      // identity padding
             }
         }
     }
-    if (MF_TS * (r + 1) > n || MF_TS * (c + 1) > n) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int pj = MF_TS * c + lg + 4 * q;
-            if (pi >= n || pj >= n) v[q] = (pi == pj) ? 1.0 : 0.0;      // identity padding
-        }
-    }
-    return v;
 }
 
 __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
@@ -99,35 +138,43 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
     __shared__ __attribute__((aligned(16))) double LinvC[W1_C * MF_IMG];
 
     const DenseArgs& A = g.a;
-    const int lane = threadIdx.x;
-    const int lr = lane & 15, lg = lane >> 4;
+    // The lane id goes through an empty asm at the head of every phase (W1_FRESH_LANE): hipcc hoists lane-dependent address arithmetic
+    // out of the surrounding loops -- out of the persistent patch loop too -- and keeps hundreds of such values in registers (398
+    // spilled VGPRs in the first version of this kernel); behind an opaque copy they are cheap values recomputed where they are used.
+    int lane = threadIdx.x;
+    int lr = lane & 15, lg = lane >> 4;
+#define W1_FRESH_LANE()                                                                                              \
+    do {                                                                                                             \
+        lane = mf_opaque(lane);                                                                                      \
+        lr = lane & 15;                                                                                              \
+        lg = lane >> 4;                                                                                              \
+    } while (0)
     const int m = A.m, ntw = g.ntw;
     const double sf = A.prm.sigmaf_sq, cexp = g.c_exp, noise = A.prm.noise;
     const bool dbl = A.prm.ref_double_noise != 0;
-    double* Lt = g.ws + (size_t)blockIdx.x * g.slot;              // tiles (i, j): Lt + (i * ntw + j) * 256
+    // ONE patch per workgroup and one factor slot per patch (no persistent patch loop: hipcc hoists every loop-invariant value of
+    // the body -- lane masks, addresses, grid constants -- in front of such a loop and then spills them: 350 VGPRs in that form)
+    const int patch = blockIdx.x;
+    double* Lt = g.ws + (size_t)patch * g.slot;                   // tiles (i, j): Lt + (i * ntw + j) * 256
     double* LinvTg = Lt + (size_t)(ntw + 1) * ntw * MF_IMG;       // L_kk^-T images
     double* LinvG = LinvTg + (size_t)ntw * MF_IMG;                // L_kk^-1 images (export only)
 
     gpc_exp_table_init(T);
-
-    const int n_patches = A.sel ? __builtin_amdgcn_readfirstlane(A.sel_count[0]) : A.P;
-    for (int pk = blockIdx.x; pk < n_patches; pk += gridDim.x) {
-        const int patch = A.sel ? __builtin_amdgcn_readfirstlane(A.sel[pk]) : pk;
-        if (g.export_factor) {
-            Lt = g.ws + (size_t)patch * g.slot;
-            LinvTg = Lt + (size_t)(ntw + 1) * ntw * MF_IMG;
-            LinvG = LinvTg + (size_t)ntw * MF_IMG;
-        }
+    {
         const int o = __builtin_amdgcn_readfirstlane(A.off[patch]);
         const int n = __builtin_amdgcn_readfirstlane(A.off[patch + 1]) - o;
         double* fs = A.f_star + (size_t)patch * m;
-        __syncthreads();   // (one wave: a fence -- the previous patch is done with LDS)
+        __syncthreads();   // (one wave: a fence -- the exponential table is in LDS)
         if (n <= 0 || n > MF_TS * ntw || n > W1_NPAD) {
             for (int p = lane; p < m; p += 64) fs[p] = (n == 0) ? 0.0 : __builtin_nan("");
             if (lane == 0 && A.status) A.status[patch] = (n == 0) ? GPC_STATUS_OK : GPC_STATUS_NAN;
-            continue;
+            return;
         }
         const int nt = __builtin_amdgcn_readfirstlane((n + MF_TS - 1) / MF_TS);
+#ifdef W1_STAMPS
+        unsigned long long st_acc_[W1_NPH] = {};
+        unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
 
         // ---- points into LDS; extent of the patch around its first point (max-norm) bounds every kernel argument ----
         const double xo0 = A.x0[o], xo1 = A.x1[o];
@@ -140,7 +187,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             dev = __builtin_fmax(dev, __builtin_fmax(__builtin_fabs(q0 - xo0), __builtin_fabs(q1 - xo1)));
             px0[i] = live ? q0 : 0.0;
             px1[i] = live ? q1 : 0.0;
-            zv[i] = 0.0;
+            zv[i] = live ? A.y[o + i] : 0.0;        // the right-hand side; the forward solve turns it into z column by column, in place
         }
 #pragma unroll
         for (int o_ = 32; o_ > 0; o_ >>= 1) dev = __builtin_fmax(dev, __shfl_xor(dev, o_, 64));
@@ -153,17 +200,20 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             small_gram = __builtin_amdgcn_readfirstlane((int)(-cexp * (8.0 * r * r) <= GPC_EXP_SMALL_MAX)) != 0;
             small_grid = __builtin_amdgcn_readfirstlane((int)(-cexp * (bq * bq) <= GPC_EXP_SMALL_MAX)) != 0;
         }
-        __syncthreads();
-        auto gram = [&](int r, int c) __attribute__((always_inline)) {
-            return small_gram ? w1_gram_tile<true>(px0, px1, T, sf, cexp, noise, dbl, n, r, c, lr, lg)
-                              : w1_gram_tile<false>(px0, px1, T, sf, cexp, noise, dbl, n, r, c, lr, lg);
-        };
+        W1_LDS_SYNC();
+#define W1_GRAM_ROW(v, CNT, DIAG, r, c0)                                                                              \
+    do {                                                                                                             \
+        if (small_gram) w1_gram_row<true, CNT, DIAG>(v, px0, px1, T, sf, cexp, noise, dbl, n, r, c0, lr, lg);          \
+        else w1_gram_row<false, CNT, DIAG>(v, px0, px1, T, sf, cexp, noise, dbl, n, r, c0, lr, lg);                    \
+    } while (0)
 
         bool bad = false;
+        W1_STAMP(0);
         // ---- tiled left-looking Cholesky, four tile columns (k .. k+3) per step ----
         for (int k = 0; k < nt; k += W1_C) {
             const int nc = min(W1_C, nt - k);                              // tile columns of this step
             const int kl = k - 1;
+            W1_FRESH_LANE();
             // ---- the diagonal block: T_(k+i)(k+c) = A - sum_{j<k} L_(k+i)j L_(k+c)j^T, tile d = i (i + 1) / 2 + c, one sweep over j;
             //      the forward-solve sums  part_c = sum_{j<k} L_(k+c)j z_j  from the same operands ----
             const double* rrow[W1_C];
@@ -181,17 +231,32 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                 for (int i = 0; i < W1_C; ++i) op[0][i] = mf_img_load(rrow[i], lane);
             }
 #pragma unroll
-            for (int d = 0; d < W1_NDT; ++d) {
-                const int bi = d >= 6 ? 3 : d >= 3 ? 2 : d >= 1 ? 1 : 0, bc = d - bi * (bi + 1) / 2;
-                tacc[d] = d4{0.0, 0.0, 0.0, 0.0};
-                if (bi < nc) tacc[d] = gram(k + bi, k + bc);
+            for (int d = 0; d < W1_NDT; ++d) tacc[d] = d4{0.0, 0.0, 0.0, 0.0};
+            {
+                // block row bi: tiles (k + bi, k .. k + bi), the last one the diagonal tile
+                d4 gv[W1_C];
+                W1_GRAM_ROW(gv, 1, true, k, k);
+                tacc[0] = gv[0];
+                if (nc > 1) {
+                    W1_GRAM_ROW(gv, 2, true, k + 1, k);
+                    tacc[1] = gv[0]; tacc[2] = gv[1];
+                }
+                if (nc > 2) {
+                    W1_GRAM_ROW(gv, 3, true, k + 2, k);
+                    tacc[3] = gv[0]; tacc[4] = gv[1]; tacc[5] = gv[2];
+                }
+                if (nc > 3) {
+                    W1_GRAM_ROW(gv, 4, true, k + 3, k);
+                    tacc[6] = gv[0]; tacc[7] = gv[1]; tacc[8] = gv[2]; tacc[9] = gv[3];
+                }
             }
+            W1_STAMP(1);
             for (int j = 0; j < k; j += 2) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int jn = min(j + h + 1, kl);
 #pragma unroll
-                    for (int i = 0; i < W1_C; ++i) op[h ^ 1][i] = mf_img_load(rrow[i] + (size_t)jn * MF_IMG, lane);
+                    for (int i = 0; i < W1_C; ++i) op[h ^ 1][i] = mf_img_load(rrow[i] + (size_t)W1_JX(jn) * MF_IMG, lane);
 #pragma unroll
                     for (int d = 0; d < W1_NDT; ++d) {
                         const int bi = d >= 6 ? 3 : d >= 3 ? 2 : d >= 1 ? 1 : 0, bc = d - bi * (bi + 1) / 2;
@@ -203,13 +268,15 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     for (int c = 0; c < W1_C; ++c) part[c] += (op[h][c][0] * z0 + op[h][c][1] * z1) + (op[h][c][2] * z2 + op[h][c][3] * z3);
                 }
             }
+            W1_STAMP(2);
             // ---- the chain, in registers: factor (k,k); then row by row  L_ic = (T_ic - sum_{c2<c} L_ic2 L_cc2^T) L_cc^-T,
             //      T_ii -= sum_c L_ic L_ic^T, factor.  Lb[i (i-1)/2 + c] = operand image of L_(k+i)(k+c), c < i. ----
+            W1_FRESH_LANE();
             d4 Lb[W1_C * (W1_C - 1) / 2];
 #pragma unroll
             for (int q = 0; q < W1_C * (W1_C - 1) / 2; ++q) Lb[q] = d4{0.0, 0.0, 0.0, 0.0};
-            bool ok = mf_diag_factor<true>(tacc[0], rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol);
-            __syncthreads();
+            bool ok = mf_diag_factor<true>(tacc[0], rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol, lane);
+            W1_LDS_SYNC();
             if (g.export_factor) mf_img_store(LinvG + (size_t)k * MF_IMG, lane, mf_img_load(LinvC, lane));
 #pragma unroll
             for (int i = 1; i < W1_C; ++i) {
@@ -227,12 +294,17 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     d4 Dii = tacc[i * (i + 1) / 2 + i];
 #pragma unroll
                     for (int c = 0; c < i; ++c) Dii = w1_mfma4_neg(Lb[i * (i - 1) / 2 + c], Lb[i * (i - 1) / 2 + c], Dii);
-                    ok = mf_diag_factor<true>(Dii, rsbuf, LinvC + i * MF_IMG, LinvTg + (size_t)(k + i) * MF_IMG, g.pivot_tol);
-                    __syncthreads();
+                    ok = mf_diag_factor<true>(Dii, rsbuf, LinvC + i * MF_IMG, LinvTg + (size_t)(k + i) * MF_IMG, g.pivot_tol, lane);
+                    W1_LDS_SYNC();
                     if (g.export_factor) mf_img_store(LinvG + (size_t)(k + i) * MF_IMG, lane, mf_img_load(LinvC + i * MF_IMG, mf_opaque(lane)));
                 }
             }
+#ifdef W1_EXP_HOT
+            ok = true;
+#endif
             if (!ok) { bad = true; break; }
+            W1_STAMP(3);
+            W1_FRESH_LANE();
             // ---- forward solve of the step's columns: z_(k+c) = L_cc^-1 (y_(k+c) - part_c - sum_{c2<c} L_(k+c)(k+c2) z_(k+c2)) ----
             // 16 x 16 mat-vecs on the VALU from the operand images: lane l holds M[l & 15][(l >> 4) + 4 s] -- the lane's partial sum over
             // its four columns, then the four lane groups of a row are added.
@@ -249,24 +321,29 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     }
                     pp += __shfl_xor(pp, 16, 64);
                     pp += __shfl_xor(pp, 32, 64);
-                    const double yv = (pj < n) ? A.y[o + pj] : 0.0;
+                    const double yv = zv[pj];                 // y (0 beyond n), loaded with the points
+                    W1_LDS_SYNC();
                     if (lg == 0) zv[pj] = yv - pp;            // t_c, where z_c goes next
-                    __syncthreads();
+                    W1_LDS_SYNC();
                     const d4 lv = mf_img_load(LinvC + c * MF_IMG, mf_opaque(lane));
                     const double* tq = zv + MF_TS * (k + c) + lg;
                     double zz = (lv[0] * tq[0] + lv[1] * tq[4]) + (lv[2] * tq[8] + lv[3] * tq[12]);
                     zz += __shfl_xor(zz, 16, 64);
                     zz += __shfl_xor(zz, 32, 64);
-                    __syncthreads();
+                    W1_LDS_SYNC();
                     if (lg == 0) zv[pj] = zz;
-                    __syncthreads();
+                    W1_LDS_SYNC();
                 }
             }
+            W1_STAMP(4);
+            const int rows_tot_ = nt - (k + nc);
+            if (rows_tot_ > 0) __syncthreads();     // the chain's tiles are in the workspace before the row passes read them back
             // ---- rows k + nc .. nt - 1, two per pass: update the four accumulators over j < k, then column by column
             //      T_r(k+c) -= sum_{c2<c} L_r(k+c2) L_(k+c)(k+c2)^T,  L_r(k+c) = T L_cc^-T ----
-            const int rows_tot = nt - (k + nc);
+            const int rows_tot = rows_tot_;
             for (int first_row = 0; first_row < rows_tot; first_row += 2) {
                 const int np = min(2, rows_tot - first_row);
+                W1_FRESH_LANE();
                 d4 acc[W1_C][2];
                 int rr[2];
                 const double* rw_[2];
@@ -280,8 +357,8 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                 // outstanding ones; the first stage is requested before the Gram tiles are evaluated
 #define W1_LOAD_STAGE(st, jj, NPC)                                                                                   \
     do {                                                                                                             \
-        _Pragma("unroll") for (int c = 0; c < W1_C; ++c) sa[st][c] = mf_img_load(rrow[c] + (size_t)(jj) * MF_IMG, lane); \
-        _Pragma("unroll") for (int t = 0; t < NPC; ++t) sb[st][t] = mf_img_load(rw_[t] + (size_t)(jj) * MF_IMG, lane);  \
+        _Pragma("unroll") for (int c = 0; c < W1_C; ++c) sa[st][c] = mf_img_load(rrow[c] + (size_t)W1_JX(jj) * MF_IMG, lane); \
+        _Pragma("unroll") for (int t = 0; t < NPC; ++t) sb[st][t] = mf_img_load(rw_[t] + (size_t)W1_JX(jj) * MF_IMG, lane);  \
     } while (0)
 #define W1_USE_STAGE(st, NPC)                                                                                        \
     do {                                                                                                             \
@@ -291,9 +368,22 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
 #define W1_UPDATE_LOOP(NPC)                                                                                          \
     do {                                                                                                             \
         if (k > 0) W1_LOAD_STAGE(0, 0, NPC);                                                                         \
-        _Pragma("unroll") for (int t = 0; t < NPC; ++t)                                                              \
-            _Pragma("unroll") for (int c = 0; c < W1_C; ++c)                                                         \
-                if (c < nc) acc[c][t] = gram(rr[t], k + c);                                                          \
+        _Pragma("unroll") for (int t = 0; t < NPC; ++t) {                                                            \
+            /* two tiles -- eight dependency chains -- per basic block: with four the chains' temporaries on top of the  \
+               accumulators and the operand stage in flight spill, and a spill reload waits on vmcnt, i.e. on the prefetch */ \
+            d4 gv[W1_C];                                                                                             \
+            if (nc >= 2) W1_GRAM_ROW(gv, 2, false, rr[t], k);                                                        \
+            else W1_GRAM_ROW(gv, 1, false, rr[t], k);                                                                \
+            acc[0][t] = gv[0];                                                                                       \
+            if (nc >= 2) acc[1][t] = gv[1];                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            if (nc == W1_C) W1_GRAM_ROW(gv, 2, false, rr[t], k + 2);                                                 \
+            else if (nc == 3) W1_GRAM_ROW(gv, 1, false, rr[t], k + 2);                                               \
+            if (nc >= 3) acc[2][t] = gv[0];                                                                          \
+            if (nc == W1_C) acc[3][t] = gv[1];                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+        W1_STAMP(5);                                                                                                 \
         for (int j = 0; j < k; j += 2) {                                                                             \
             W1_LOAD_STAGE(1, j + 1, NPC);                                                                            \
             W1_USE_STAGE(0, NPC);                                                                                    \
@@ -314,6 +404,17 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                 }
                 if (np == 2) W1_UPDATE_LOOP(2);
                 else W1_UPDATE_LOOP(1);
+                W1_STAMP(6);
+                W1_FRESH_LANE();
+                // the block's strictly lower tiles come back from the workspace (this wave's own stores of the chain, fenced below it;
+                // L2 / L1 hits): as registers they would be live across the whole update loop -- 48 VGPRs on top of its 160 --
+                // and the spills that causes wait on vmcnt, i.e. on the operand prefetch
+                d4 Lq[W1_C * (W1_C - 1) / 2];
+#pragma unroll
+                for (int i = 1; i < W1_C; ++i)
+#pragma unroll
+                    for (int c2 = 0; c2 < i; ++c2)
+                        Lq[i * (i - 1) / 2 + c2] = mf_img_load(Lt + ((size_t)(k + min(i, nc - 1)) * ntw + k + min(c2, max(nc - 2, 0))) * MF_IMG, lane);
 #pragma unroll
                 for (int c = 0; c < W1_C; ++c) {
                     if (c < nc) {
@@ -322,7 +423,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                         for (int t = 0; t < 2; ++t) {
                             if (t < np) {
 #pragma unroll
-                                for (int c2 = 0; c2 < c; ++c2) acc[c][t] = w1_mfma4_neg(Lb[c * (c - 1) / 2 + c2], acc[c2][t], acc[c][t]);
+                                for (int c2 = 0; c2 < c; ++c2) acc[c][t] = w1_mfma4_neg(Lq[c * (c - 1) / 2 + c2], acc[c2][t], acc[c][t]);
                                 acc[c][t] = w1_trsm(lv, acc[c][t]);
                                 mf_img_store(Lt + ((size_t)rr[t] * ntw + k + c) * MF_IMG, lane, acc[c][t]);
                             }
@@ -330,7 +431,9 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     }
                 }
             }
+            W1_STAMP(7);
             __syncthreads();   // the column block is in the workspace (this wave's own stores, read back by its next sweep)
+            W1_STAMP(8);
         }
 
         if (bad) {
@@ -338,7 +441,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             if (A.alpha_out)
                 for (int i = lane; i < n; i += 64) A.alpha_out[o + i] = __builtin_nan("");
             if (lane == 0 && A.status) A.status[patch] = GPC_STATUS_NOT_SPD;
-            continue;
+            return;
         }
 
         // ---- backward solve L^T alpha = z, tile columns from the last to the first; alpha replaces z in place ----
@@ -346,68 +449,69 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
         // cannot feed to an MFMA) with the transposing DPP row reduction, then alpha_k = L_kk^-T (z_k - w_k): four MFMAs.
         // The tiles do not depend on alpha: rows k+1 .. k+8 of column k are requested one column ahead, the rest at its start.
         {
+            W1_FRESH_LANE();
             d4 cur[8], nxt[8], lt_cur, lt_nxt;
 #pragma unroll
             for (int t = 0; t < 8; ++t) cur[t] = nxt[t] = d4{0.0, 0.0, 0.0, 0.0};
             lt_cur = mf_img_load(LinvTg + (size_t)(nt - 1) * MF_IMG, lane);
             lt_nxt = lt_cur;
-            for (int k = nt - 1; k >= 0; --k) {
-                d4 far[7];
-#pragma unroll
-                for (int t = 0; t < 7; ++t) {
-                    const int i = k + 9 + t;
-                    far[t] = d4{0.0, 0.0, 0.0, 0.0};
-                    if (i < nt) far[t] = mf_img_load(Lt + ((size_t)i * ntw + k) * MF_IMG, lane);
-                }
-                if (k > 0) {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const int i = k + t;                                  // rows of column k-1: i >= k
-                        if (i < nt) nxt[t] = mf_img_load(Lt + ((size_t)i * ntw + (k - 1)) * MF_IMG, lane);
-                    }
-                    lt_nxt = mf_img_load(LinvTg + (size_t)(k - 1) * MF_IMG, lane);
-                }
-                d4 pa = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int i = k + 1 + t;
-                    if (i < nt) pa += cur[t] * zv[MF_TS * i + lr];          // cur[t] = L_ik[l & 15][(l >> 4) + 4 s]
-                }
-#pragma unroll
-                for (int t = 0; t < 7; ++t) {
-                    const int i = k + 9 + t;
-                    if (i < nt) pa += far[t] * zv[MF_TS * i + lr];
-                }
-                d4 ub = d4{0.0, 0.0, 0.0, 0.0};
-                if (k + 1 < nt) {
-                    const double tot = mf_row_reduce4(pa, lr);               // lanes lr = 0, 4, 8, 12 hold components 0 .. 3
-                    if ((lr & 3) == 0) wsc[lg + 4 * (lr >> 2)] = tot;
-                    __syncthreads();
-                    if (lr == 0) {
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[MF_TS * k + lg + 4 * q4] - wsc[lg + 4 * q4];
-                    }
-                } else if (lr == 0) {
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[MF_TS * k + lg + 4 * q4];
-                }
-                const d4 al = w1_trsm(lt_cur, ub);                           // lanes lr = 0: alpha[16 k + (l >> 4) + 4 r]
-                __syncthreads();
-                if (lr == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) zv[MF_TS * k + lg + 4 * r] = al[r];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int t = 0; t < 8; ++t) cur[t] = nxt[t];
-                lt_cur = lt_nxt;
-            }
+            // (every load unconditional, indices clamped into the lower triangle: under runtime conditions hipcc cannot count the
+            // outstanding loads and waits for all of them, i.e. for the prefetch it has just issued)
+#define W1_BACK_COLUMN(FAR)                                                                                          \
+    do {                                                                                                             \
+        W1_FRESH_LANE();                                                                                             \
+        d4 far[7];                                                                                                   \
+        if (FAR) {                                                                                                   \
+            _Pragma("unroll") for (int t = 0; t < 7; ++t)                                                            \
+                far[t] = mf_img_load(Lt + ((size_t)min(k + 9 + t, nt - 1) * ntw + k) * MF_IMG, lane);                \
+        }                                                                                                            \
+        {                                                                                                            \
+            const int kn = max(k - 1, 0);                                                                            \
+            _Pragma("unroll") for (int t = 0; t < 8; ++t)      /* rows of column k-1: i = k + t */                   \
+                nxt[t] = mf_img_load(Lt + ((size_t)min(k + t, nt - 1) * ntw + kn) * MF_IMG, lane);                   \
+            lt_nxt = mf_img_load(LinvTg + (size_t)kn * MF_IMG, lane);                                                \
+        }                                                                                                            \
+        d4 pa = d4{0.0, 0.0, 0.0, 0.0};                                                                              \
+        _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                                              \
+            const int i = k + 1 + t;                                                                                 \
+            const double a_ = zv[MF_TS * min(i, nt - 1) + lr];                                                       \
+            pa += cur[t] * ((i < nt) ? a_ : 0.0);               /* cur[t] = L_ik[l & 15][(l >> 4) + 4 s] */          \
+        }                                                                                                            \
+        if (FAR) {                                                                                                   \
+            _Pragma("unroll") for (int t = 0; t < 7; ++t) {                                                          \
+                const int i = k + 9 + t;                                                                             \
+                const double a_ = zv[MF_TS * min(i, nt - 1) + lr];                                                   \
+                pa += far[t] * ((i < nt) ? a_ : 0.0);                                                                \
+            }                                                                                                        \
+        }                                                                                                            \
+        const double tot = mf_row_reduce4(pa, lr);               /* lanes lr = 0, 4, 8, 12 hold components 0 .. 3 */  \
+        if ((lr & 3) == 0) wsc[lg + 4 * (lr >> 2)] = tot;                                                            \
+        W1_LDS_SYNC();                                                                                               \
+        d4 ub = d4{0.0, 0.0, 0.0, 0.0};                                                                              \
+        if (lr == 0) {                                                                                               \
+            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[MF_TS * k + lg + 4 * q4] - wsc[lg + 4 * q4]; \
+        }                                                                                                            \
+        const d4 al = w1_trsm(lt_cur, ub);                       /* lanes lr = 0: alpha[16 k + (l >> 4) + 4 r] */      \
+        W1_LDS_SYNC();                                                                                               \
+        if (lr == 0) {                                                                                               \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) zv[MF_TS * k + lg + 4 * r] = al[r];                        \
+        }                                                                                                            \
+        W1_LDS_SYNC();                                                                                               \
+        _Pragma("unroll") for (int t = 0; t < 8; ++t) cur[t] = nxt[t];                                               \
+        lt_cur = lt_nxt;                                                                                             \
+    } while (0)
+            int k = nt - 1;
+            for (; k >= 0 && k + 9 >= nt; --k) W1_BACK_COLUMN(false);
+            for (; k >= 0; --k) W1_BACK_COLUMN(true);
+#undef W1_BACK_COLUMN
         }
+        W1_STAMP(9);
         double* av = zv;
         if (A.alpha_out)
             for (int i = lane; i < n; i += 64) A.alpha_out[o + i] = av[i];
 
         // ---- predictive mean ----
+        W1_FRESH_LANE();
         if (A.xs0 == nullptr && A.grid_sz <= 32) {
             // separable grid: f[py][px] = sum_i Ey[py][i] * (sf alpha_i Ex[px][i]): four 16 x 16 output tiles, no reduction across waves
             const int sz = A.grid_sz;
@@ -420,34 +524,36 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             double gq[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) gq[h] = res * (((double)(16 * h + lr) + 0.5) / (double)sz - 0.5);
-            for (int ibase = 0; ibase < n; ibase += 32) {
+            // No masks in the loop: a point beyond n contributes nothing because its weight sf alpha_i is SELECTED to zero (alpha is
+            // zero from n to 16 nt -- identity padding solves to 0 -- but never written beyond: select, do not multiply), and the
+            // grid rows / columns beyond sz are finite numbers that are never stored.  One basic block per 32 points: 32 independent
+            // exponentials for the scheduler (behind per-element masks and mode branches this phase took a sixth of the kernel).
+            auto predict_loop = [&](auto small_tag) __attribute__((always_inline)) {
+                constexpr bool SM = decltype(small_tag)::value;
+                for (int ibase = 0; ibase < n; ibase += 32) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const int i = ibase + 4 * s + lg;
-                    // alpha is zero from n to 16 nt (identity padding solves to 0) but never written beyond: select, do not multiply
-                    const int ic = min(i, W1_NPAD - 1);
-                    const double al = (i < n) ? sf * av[ic] : 0.0;
-                    const double xi0 = px0[ic], xi1 = px1[ic];
-                    double ea[2], eb[2];
+                    for (int s = 0; s < 8; ++s) {
+                        const int i = ibase + 4 * s + lg;
+                        const int ic = min(i, W1_NPAD - 1);
+                        const double al = (i < n) ? sf * av[ic] : 0.0;
+                        const double xi0 = px0[ic], xi1 = px1[ic];
+                        double ea[2], eb[2];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const bool on = (16 * h + lr < sz) && (i < n);
-                        const double dy = gq[h] - xi1, dx = gq[h] - xi0;
-                        if (small_grid) {
-                            ea[h] = on ? gpc_exp_small(cexp * (dy * dy)) : 0.0;         // Ey[py][i]
-                            eb[h] = on ? gpc_exp_small(cexp * (dx * dx)) * al : 0.0;    // Ex[px][i] * sf alpha_i
-                        } else {
-                            ea[h] = on ? gpc_exp_neg(cexp * (dy * dy), T) : 0.0;
-                            eb[h] = on ? gpc_exp_neg(cexp * (dx * dx), T) * al : 0.0;
+                        for (int h = 0; h < 2; ++h) {
+                            const double dy = gq[h] - xi1, dx = gq[h] - xi0;
+                            ea[h] = SM ? gpc_exp_small(cexp * (dy * dy)) : gpc_exp_neg(cexp * (dy * dy), T);            // Ey[py][i]
+                            eb[h] = (SM ? gpc_exp_small(cexp * (dx * dx)) : gpc_exp_neg(cexp * (dx * dx), T)) * al;     // Ex[px][i] * sf alpha_i
                         }
+#pragma unroll
+                        for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt)
+                                P[mt][nl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ea[mt], eb[nl], P[mt][nl], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int nl = 0; nl < 2; ++nl)
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-                            P[mt][nl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ea[mt], eb[nl], P[mt][nl], 0, 0, 0);
                 }
-            }
+            };
+            if (small_grid) predict_loop(std::true_type{});
+            else predict_loop(std::false_type{});
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -475,21 +581,34 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             }
         }
         if (lane == 0 && A.status) A.status[patch] = GPC_STATUS_OK;
+#ifdef W1_STAMPS
+        W1_STAMP(10);
+        if (g.stamps && lane == 0)
+            for (int q_ = 0; q_ < W1_NPH; ++q_) atomicAdd(g.stamps + q_, st_acc_[q_]);
+#endif
     }
 }
 
 bool dense_w1_supported(const DenseArgs& a)
 {
-    return a.n_max <= W1_NPAD && a.ny == 1 && !a.v_star;
+    return a.n_max <= W1_NPAD && a.ny == 1 && !a.v_star && !a.sel;
 }
 
-static int w1_per_cu() { const char* e = getenv("GPC_W1_PER_CU"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }
+// One factor slot per patch of a launch (304 KB at n = 256: 2.5 GB for the 8192 patches of BASELINE config 2 -- sized for 288 GB);
+// a larger batch goes through in launches of W1_MAX_SLOTS patches that reuse the slots.
+#define W1_MAX_SLOTS 16384
+static int w1_chunk(const DenseArgs& a)
+{
+    const char* e = getenv("GPC_W1_SLOTS");
+    const int cap = e && atoi(e) > 0 ? atoi(e) : W1_MAX_SLOTS;
+    return a.P < cap ? a.P : cap;
+}
 
 size_t dense_w1_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
 {
+    (void)ctx;
     const int ntw = (a.n_max + MF_TS - 1) / MF_TS;
-    const int cap = ctx->num_cus * w1_per_cu();
-    const int grid = a.P < cap ? a.P : cap;
+    const int grid = w1_chunk(a);
     if (grid_out) *grid_out = grid;
     return sizeof(double) * big_slot_doubles(ntw) * (size_t)grid;
 }
@@ -504,8 +623,38 @@ int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
     g.ntw = (a.n_max + MF_TS - 1) / MF_TS;
     g.slot = big_slot_doubles(g.ntw);
     g.export_factor = 0;
+    g.stamps = nullptr;
     ctx->last_dense_kernel = "dense_mfma_w1";
-    hipLaunchKernelGGL(dense_w1_kernel, dim3(grid), dim3(64), 0, ctx->stream, g);
-    GPC_HIP(ctx, hipGetLastError());
+#ifdef W1_STAMPS
+    if (getenv("GPC_W1_STAMPS")) {
+        GPC_HIP(ctx, hipMalloc(&g.stamps, sizeof(unsigned long long) * W1_NPH));
+        GPC_HIP(ctx, hipMemsetAsync(g.stamps, 0, sizeof(unsigned long long) * W1_NPH, ctx->stream));
+    }
+#endif
+    for (int base = 0; base < a.P; base += grid) {
+        // a launch works on patches base .. base + cnt - 1: the kernel's patch index is its workgroup index, `off`, f* and status
+        // are passed shifted (off[] holds absolute point offsets, so x, y and alpha stay as they are)
+        const int cnt = a.P - base < grid ? a.P - base : grid;
+        g.a.P = cnt;
+        g.a.off = a.off + base;
+        g.a.f_star = a.f_star ? a.f_star + (size_t)base * a.m : nullptr;
+        g.a.status = a.status ? a.status + base : nullptr;
+        hipLaunchKernelGGL(dense_w1_kernel, dim3(cnt), dim3(64), 0, ctx->stream, g);
+        GPC_HIP(ctx, hipGetLastError());
+    }
+#ifdef W1_STAMPS
+    if (g.stamps) {
+        unsigned long long h[W1_NPH];
+        GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GPC_HIP(ctx, hipMemcpy(h, g.stamps, sizeof(h), hipMemcpyDeviceToHost));
+        (void)hipFree(g.stamps);
+        static const char* names[W1_NPH] = {"load", "sweep gram", "sweep loop", "chain", "forward", "pass gram", "pass loop", "pass trsm",
+                                            "step fence", "backward", "predict", ""};
+        unsigned long long tot = 0;
+        for (int q = 0; q < W1_NPH; ++q) tot += h[q];
+        fprintf(stderr, "[GPC_W1_STAMPS] mean s_memtime ticks per patch (total %.0f)\n", (double)tot / a.P);
+        for (int q = 0; q < 11; ++q) fprintf(stderr, "  %-12s %9.0f  %5.1f %%\n", names[q], (double)h[q] / a.P, 100.0 * h[q] / tot);
+    }
+#endif
     return GPC_OK;
 }

@@ -113,9 +113,11 @@ __device__ static __forceinline__ void mf_img_store(double* img, int l, d4 v)
 // elimination on the VALU with v_readlane multipliers: ~650 dependent-issue instructions, 4.6k cycles per tile, on
 // the critical path of every step.)  Writes L^-1 and L^-T as operand images; false when a pivot is <= pivot_tol.
 template <bool OPAQUE = false>
-__device__ __forceinline__ static bool mf_diag_factor(d4 W, double* rsbuf, double* Linv_out, double* LinvT_out, double pivot_tol)
+__device__ __forceinline__ static bool mf_diag_factor(d4 W, double* rsbuf, double* Linv_out, double* LinvT_out, double pivot_tol, int lane_in = -1)
 {
-    const int lane = threadIdx.x & 63;
+    // (OPAQUE: the first pivot's masks too -- hoisted out of the caller's loops they are spilled and every reload waits on vmcnt)
+    // (lane_in: a caller that keeps its lane id in a register anyway passes it -- threadIdx.x itself gets spilled around these calls)
+    const int lane = OPAQUE ? mf_opaque(lane_in >= 0 ? lane_in : (int)(threadIdx.x & 63)) : (int)(threadIdx.x & 63);
     const int lr = lane & 15, lg = lane >> 4;
     double rp = mf_rcp(mf_readlane(W[0], 0));
     double rpv = (lg == 0 && lr > 0) ? rp : 0.0;

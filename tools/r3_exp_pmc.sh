@@ -18,7 +18,7 @@ for v in sorted(os.listdir(O)):
     acc=collections.defaultdict(list)
     for f in glob.glob(os.path.join(O,v,"**","*_counter_collection.csv"),recursive=True):
         for r in csv.DictReader(open(f)):
-            if "dense_big_kernel" in r["Kernel_Name"]:
+            if "dense_big_kernel" in r["Kernel_Name"] or "dense_w1_kernel" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(v, {k: round(sum(x)/len(x)/8192,1) for k,x in sorted(acc.items())})
 PY
