@@ -201,11 +201,15 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             small_grid = __builtin_amdgcn_readfirstlane((int)(-cexp * (bq * bq) <= GPC_EXP_SMALL_MAX)) != 0;
         }
         W1_LDS_SYNC();
+#ifdef W1_EXP_SMALLONLY      // diagnostic: no table-driven path at all (what the code size costs)
+#define W1_GRAM_ROW(v, CNT, DIAG, r, c0) w1_gram_row<true, CNT, DIAG>(v, px0, px1, T, sf, cexp, noise, dbl, n, r, c0, lr, lg)
+#else
 #define W1_GRAM_ROW(v, CNT, DIAG, r, c0)                                                                              \
     do {                                                                                                             \
         if (small_gram) w1_gram_row<true, CNT, DIAG>(v, px0, px1, T, sf, cexp, noise, dbl, n, r, c0, lr, lg);          \
         else w1_gram_row<false, CNT, DIAG>(v, px0, px1, T, sf, cexp, noise, dbl, n, r, c0, lr, lg);                    \
     } while (0)
+#endif
 
         bool bad = false;
         W1_STAMP(0);
@@ -409,12 +413,16 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                 // the block's strictly lower tiles come back from the workspace (this wave's own stores of the chain, fenced below it;
                 // L2 / L1 hits): as registers they would be live across the whole update loop -- 48 VGPRs on top of its 160 --
                 // and the spills that causes wait on vmcnt, i.e. on the operand prefetch
+#ifdef W1_LB_RESIDENT
+#define Lq Lb
+#else
                 d4 Lq[W1_C * (W1_C - 1) / 2];
 #pragma unroll
                 for (int i = 1; i < W1_C; ++i)
 #pragma unroll
                     for (int c2 = 0; c2 < i; ++c2)
                         Lq[i * (i - 1) / 2 + c2] = mf_img_load(Lt + ((size_t)(k + min(i, nc - 1)) * ntw + k + min(c2, max(nc - 2, 0))) * MF_IMG, lane);
+#endif
 #pragma unroll
                 for (int c = 0; c < W1_C; ++c) {
                     if (c < nc) {
@@ -430,8 +438,8 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                         }
                     }
                 }
+                W1_STAMP(7);
             }
-            W1_STAMP(7);
             __syncthreads();   // the column block is in the workspace (this wave's own stores, read back by its next sweep)
             W1_STAMP(8);
         }
