@@ -74,6 +74,25 @@ struct W1Params {
         __builtin_amdgcn_wave_barrier();                                                                             \
     } while (0)
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = A .. B-1 (ring-buffer slots and stream positions must be constants
+// for the ring to live in registers)
+template <int A, int B, typename F>
+__device__ static __forceinline__ void w1_static_for(F&& f)
+{
+    if constexpr (A < B) {
+        f(std::integral_constant<int, A>{});
+        w1_static_for<A + 1, B>(f);
+    }
+}
+// stream position -> column index from the end: the largest kk with kk (kk + 1) / 2 <= q
+__host__ __device__ constexpr int w1_stream_col(int q)
+{
+    int kk = 0;
+    while ((kk + 1) * (kk + 2) / 2 <= q) ++kk;
+    return kk;
+}
+#define W1_BW 20     // images in flight in the backward solve's ring (160 VGPRs)
+
 __device__ static __forceinline__ d4 w1_mfma4_neg(d4 a, d4 b, d4 acc)
 {
 #pragma unroll
@@ -303,7 +322,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     if (g.export_factor) mf_img_store(LinvG + (size_t)(k + i) * MF_IMG, lane, mf_img_load(LinvC + i * MF_IMG, mf_opaque(lane)));
                 }
             }
-#ifdef W1_EXP_HOT
+#if defined(W1_EXP_HOT) || defined(W1_EXP_NOPASSTRSM) || defined(W1_EXP_NOBACK)
             ok = true;
 #endif
             if (!ok) { bad = true; break; }
@@ -341,11 +360,46 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             }
             W1_STAMP(4);
             const int rows_tot_ = nt - (k + nc);
-            if (rows_tot_ > 0) __syncthreads();     // the chain's tiles are in the workspace before the row passes read them back
+            if (rows_tot_ > 0 && !(k == 0 && nc == W1_C)) __syncthreads();     // the chain's tiles are in the workspace before the row passes read them back
             // ---- rows k + nc .. nt - 1, two per pass: update the four accumulators over j < k, then column by column
             //      T_r(k+c) -= sum_{c2<c} L_r(k+c2) L_(k+c)(k+c2)^T,  L_r(k+c) = T L_cc^-T ----
             const int rows_tot = rows_tot_;
-            for (int first_row = 0; first_row < rows_tot; first_row += 2) {
+            int first_row0 = 0;
+            if (k == 0 && nc == W1_C) {
+                // Step 0 has no update loop, so its registers are free: FOUR rows per pass with the block's lower tiles resident (no
+                // reload from the workspace -- at eight patches per CU those reloads miss L2: 36 of a patch's 512 image reads) and
+                // four independent TRSM chains interleaved.
+                for (; first_row0 < rows_tot; first_row0 += 4) {
+                    const int np4 = min(4, rows_tot - first_row0);
+                    W1_FRESH_LANE();
+                    d4 a4[W1_C][4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int r_ = W1_C + first_row0 + min(t, np4 - 1);       // (t >= np4: a copy of the last row, never stored)
+                        d4 gv[W1_C];
+                        W1_GRAM_ROW(gv, 2, false, r_, 0);
+                        a4[0][t] = gv[0]; a4[1][t] = gv[1];
+                        __builtin_amdgcn_sched_barrier(0);
+                        W1_GRAM_ROW(gv, 2, false, r_, 2);
+                        a4[2][t] = gv[0]; a4[3][t] = gv[1];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    W1_STAMP(5);
+#pragma unroll
+                    for (int c = 0; c < W1_C; ++c) {
+                        const d4 lv = mf_img_load(LinvC + c * MF_IMG, mf_opaque(lane));
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                            for (int c2 = 0; c2 < c; ++c2) a4[c][t] = w1_mfma4_neg(Lb[c * (c - 1) / 2 + c2], a4[c2][t], a4[c][t]);
+                            a4[c][t] = w1_trsm(lv, a4[c][t]);
+                            if (t < np4) mf_img_store(Lt + ((size_t)(W1_C + first_row0 + t) * ntw + c) * MF_IMG, lane, a4[c][t]);
+                        }
+                    }
+                    W1_STAMP(7);
+                }
+            }
+            for (int first_row = first_row0; first_row < rows_tot; first_row += 2) {
                 const int np = min(2, rows_tot - first_row);
                 W1_FRESH_LANE();
                 d4 acc[W1_C][2];
@@ -430,9 +484,11 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             if (t < np) {
+#ifndef W1_EXP_NOPASSTRSM      // (diagnostic: what the TRSM chains of the row passes cost -- stores only)
 #pragma unroll
                                 for (int c2 = 0; c2 < c; ++c2) acc[c][t] = w1_mfma4_neg(Lq[c * (c - 1) / 2 + c2], acc[c2][t], acc[c][t]);
                                 acc[c][t] = w1_trsm(lv, acc[c][t]);
+#endif
                                 mf_img_store(Lt + ((size_t)rr[t] * ntw + k + c) * MF_IMG, lane, acc[c][t]);
                             }
                         }
@@ -452,72 +508,79 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             return;
         }
 
+#ifndef W1_EXP_NOBACK
         // ---- backward solve L^T alpha = z, tile columns from the last to the first; alpha replaces z in place ----
         // Column k: w_k = sum_{i>k} L_ik^T alpha_i on the VALU (the products contract over the ROW index, which the image layout
         // cannot feed to an MFMA) with the transposing DPP row reduction, then alpha_k = L_kk^-T (z_k - w_k): four MFMAs.
-        // The tiles do not depend on alpha: rows k+1 .. k+8 of column k are requested one column ahead, the rest at its start.
+        // The tiles do not depend on alpha, and the factor of the 2048 patches in flight (620 MB) is in HBM: the solve is ONE STREAM
+        // of nt (nt + 1) / 2 images -- column by column, each column's tiles and then its L_kk^-T -- consumed in order through a ring
+        // of W1_BW registers images that keeps W1_BW requests in flight (with one column of look-ahead this phase took 12 % of the
+        // kernel for 2 % of its arithmetic: every column waited out an HBM round trip).  Everything is unrolled over the stream
+        // positions of a 16-column factor, aligned at its last column: column kk from the end (k = nt-1-kk) has kk tiles, rows
+        // k+1+t; positions of columns a smaller factor does not have are skipped, their requests clamped to the slot's first image.
         {
             W1_FRESH_LANE();
-            d4 cur[8], nxt[8], lt_cur, lt_nxt;
+            constexpr int NP = W1_NPAD / MF_TS;                     // 16
+            constexpr int SLEN = NP * (NP + 1) / 2;                 // 136 stream positions
+            d4 win[W1_BW];
+            auto stream_addr = [&](auto P) __attribute__((always_inline)) -> const double* {
+                constexpr int q = decltype(P)::value;
+                constexpr int kk = w1_stream_col(q), t = q - kk * (kk + 1) / 2;
+                const int kq = nt - 1 - kk;                          // (negative for a column this factor does not have)
+                const double* ad = (t < kk) ? Lt + ((size_t)(kq + 1 + t) * ntw + kq) * MF_IMG : LinvTg + (size_t)kq * MF_IMG;
+                return kk < nt ? ad : Lt;
+            };
+            w1_static_for<0, W1_BW>([&](auto P) __attribute__((always_inline)) {
+                constexpr int q = decltype(P)::value;
+                win[q % W1_BW] = mf_img_load(stream_addr(P), lane);
+            });
+            d4 pa = d4{0.0, 0.0, 0.0, 0.0};
+            w1_static_for<0, SLEN>([&](auto P) __attribute__((always_inline)) {
+                constexpr int q = decltype(P)::value;
+                constexpr int kk = w1_stream_col(q), t = q - kk * (kk + 1) / 2;
+                if (kk < nt) {
+                    const int k = nt - 1 - kk;
+                    if constexpr (t < kk) {
+                        const double a_ = zv[MF_TS * (k + 1 + t) + lr];
+                        pa += win[q % W1_BW] * a_;                       // the image of L_ik: [l & 15][(l >> 4) + 4 s]
+                    } else {
+                        d4 ub = d4{0.0, 0.0, 0.0, 0.0};
+                        if constexpr (kk > 0) {
+                            const double tot = mf_row_reduce4(pa, lr);   // lanes lr = 0, 4, 8, 12 hold components 0 .. 3
+                            if ((lr & 3) == 0) wsc[lg + 4 * (lr >> 2)] = tot;
+                            W1_LDS_SYNC();
+                            if (lr == 0) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) cur[t] = nxt[t] = d4{0.0, 0.0, 0.0, 0.0};
-            lt_cur = mf_img_load(LinvTg + (size_t)(nt - 1) * MF_IMG, lane);
-            lt_nxt = lt_cur;
-            // (every load unconditional, indices clamped into the lower triangle: under runtime conditions hipcc cannot count the
-            // outstanding loads and waits for all of them, i.e. for the prefetch it has just issued)
-#define W1_BACK_COLUMN(FAR)                                                                                          \
-    do {                                                                                                             \
-        W1_FRESH_LANE();                                                                                             \
-        d4 far[7];                                                                                                   \
-        if (FAR) {                                                                                                   \
-            _Pragma("unroll") for (int t = 0; t < 7; ++t)                                                            \
-                far[t] = mf_img_load(Lt + ((size_t)min(k + 9 + t, nt - 1) * ntw + k) * MF_IMG, lane);                \
-        }                                                                                                            \
-        {                                                                                                            \
-            const int kn = max(k - 1, 0);                                                                            \
-            _Pragma("unroll") for (int t = 0; t < 8; ++t)      /* rows of column k-1: i = k + t */                   \
-                nxt[t] = mf_img_load(Lt + ((size_t)min(k + t, nt - 1) * ntw + kn) * MF_IMG, lane);                   \
-            lt_nxt = mf_img_load(LinvTg + (size_t)kn * MF_IMG, lane);                                                \
-        }                                                                                                            \
-        d4 pa = d4{0.0, 0.0, 0.0, 0.0};                                                                              \
-        _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                                              \
-            const int i = k + 1 + t;                                                                                 \
-            const double a_ = zv[MF_TS * min(i, nt - 1) + lr];                                                       \
-            pa += cur[t] * ((i < nt) ? a_ : 0.0);               /* cur[t] = L_ik[l & 15][(l >> 4) + 4 s] */          \
-        }                                                                                                            \
-        if (FAR) {                                                                                                   \
-            _Pragma("unroll") for (int t = 0; t < 7; ++t) {                                                          \
-                const int i = k + 9 + t;                                                                             \
-                const double a_ = zv[MF_TS * min(i, nt - 1) + lr];                                                   \
-                pa += far[t] * ((i < nt) ? a_ : 0.0);                                                                \
-            }                                                                                                        \
-        }                                                                                                            \
-        const double tot = mf_row_reduce4(pa, lr);               /* lanes lr = 0, 4, 8, 12 hold components 0 .. 3 */  \
-        if ((lr & 3) == 0) wsc[lg + 4 * (lr >> 2)] = tot;                                                            \
-        W1_LDS_SYNC();                                                                                               \
-        d4 ub = d4{0.0, 0.0, 0.0, 0.0};                                                                              \
-        if (lr == 0) {                                                                                               \
-            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[MF_TS * k + lg + 4 * q4] - wsc[lg + 4 * q4]; \
-        }                                                                                                            \
-        const d4 al = w1_trsm(lt_cur, ub);                       /* lanes lr = 0: alpha[16 k + (l >> 4) + 4 r] */      \
-        W1_LDS_SYNC();                                                                                               \
-        if (lr == 0) {                                                                                               \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) zv[MF_TS * k + lg + 4 * r] = al[r];                        \
-        }                                                                                                            \
-        W1_LDS_SYNC();                                                                                               \
-        _Pragma("unroll") for (int t = 0; t < 8; ++t) cur[t] = nxt[t];                                               \
-        lt_cur = lt_nxt;                                                                                             \
-    } while (0)
-            int k = nt - 1;
-            for (; k >= 0 && k + 9 >= nt; --k) W1_BACK_COLUMN(false);
-            for (; k >= 0; --k) W1_BACK_COLUMN(true);
-#undef W1_BACK_COLUMN
+                                for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[MF_TS * k + lg + 4 * q4] - wsc[lg + 4 * q4];
+                            }
+                        } else {
+                            if (lr == 0) {
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[MF_TS * k + lg + 4 * q4];
+                            }
+                        }
+                        const d4 al = w1_trsm(win[q % W1_BW], ub);       // lanes lr = 0: alpha[16 k + (l >> 4) + 4 r]
+                        W1_LDS_SYNC();
+                        if (lr == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) zv[MF_TS * k + lg + 4 * r] = al[r];
+                        }
+                        W1_LDS_SYNC();
+                        pa = d4{0.0, 0.0, 0.0, 0.0};
+                    }
+                }
+                if constexpr (q + W1_BW < SLEN) {
+                    win[q % W1_BW] = mf_img_load(stream_addr(std::integral_constant<int, q + W1_BW>{}), lane);
+                }
+            });
         }
+#endif
         W1_STAMP(9);
         double* av = zv;
         if (A.alpha_out)
             for (int i = lane; i < n; i += 64) A.alpha_out[o + i] = av[i];
 
+#ifndef W1_EXP_NOPRED
         // ---- predictive mean ----
         W1_FRESH_LANE();
         if (A.xs0 == nullptr && A.grid_sz <= 32) {
@@ -588,6 +651,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                 fs[p] = s_;
             }
         }
+#endif
         if (lane == 0 && A.status) A.status[patch] = GPC_STATUS_OK;
 #ifdef W1_STAMPS
         W1_STAMP(10);
@@ -647,7 +711,10 @@ int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
         g.a.off = a.off + base;
         g.a.f_star = a.f_star ? a.f_star + (size_t)base * a.m : nullptr;
         g.a.status = a.status ? a.status + base : nullptr;
-        hipLaunchKernelGGL(dense_w1_kernel, dim3(cnt), dim3(64), 0, ctx->stream, g);
+        // (diagnostic: GPC_W1_LDS_PAD bytes of unused dynamic LDS per workgroup cap the workgroups resident on a CU)
+        const char* pad_e = getenv("GPC_W1_LDS_PAD");
+        const size_t pad = pad_e ? (size_t)atoi(pad_e) : 0;
+        hipLaunchKernelGGL(dense_w1_kernel, dim3(cnt), dim3(64), pad, ctx->stream, g);
         GPC_HIP(ctx, hipGetLastError());
     }
 #ifdef W1_STAMPS

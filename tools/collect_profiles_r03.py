@@ -21,7 +21,7 @@ DST = os.path.join(ROOT, "profiles")
 # workload -> (substring of the dominant kernel's name, warm-up dispatches per kernel name in the profiled command, dispatches
 #              per kernel name that make up ONE bench launch / pass, traffic.json key)
 WORK = {
-    "c2": ("dense_big_kernel<2, 256, 2, 2, false, 4, 1>", 2, 1, "dense_mfma_big_w2"),
+    "c2": ("dense_w1_kernel", 2, 1, "dense_mfma_w1"),
     "c2var": ("dense_variance_kernel<16,", 1, 1, "dense_variance@C2"),
     "c3": ("dense_big_kernel<8, 1024, 2, 2, false, 4, 3>", 1, 1, "dense_mfma_big@n512"),
     "c4fill": ("sparse_add_", 4, 4, "sparse_add@C4_fill"),          # one pass = 4 add calls, each a small-basis + a regular kernel
