@@ -30,6 +30,10 @@
 #define W1_NPAD 256
 #define W1_C 4          // tile columns per step
 #define W1_NDT 10       // tiles of a step's diagonal block
+#define W1_NT (W1_NPAD / 16)                 // tile rows of a slot
+#define W1_TRI (W1_NT * (W1_NT + 1) / 2)     // images of a slot
+// offset (doubles) of tile (i, j), j <= i, in a slot
+#define W1_TILE(i, j) (((size_t)(i) * (size_t)((i) + 1) / 2 + (size_t)(j)) * MF_IMG)
 // Diagnostic build -DW1_EXP_HOT (results wrong by construction): every j-indexed operand load reads tile column 0 -- what the
 // latency of the factor stream costs
 #ifdef W1_EXP_HOT
@@ -43,10 +47,10 @@ struct W1Params {
     DenseArgs a;
     double c_exp;
     double pivot_tol;
-    double* ws;
-    size_t slot;        // doubles per slot (big_slot_doubles: same layout as the tiled kernel's)
-    int ntw;            // tile columns of a slot
-    int export_factor;  // slot = patch (the factor of every patch stays, with the L_kk^-1 images): predictive variance
+    double* ws;         // factor slots, one per patch of the launch: W1_TRI images, the lower triangle packed row-major -- tile (i, j) at
+                        // (i (i + 1) / 2 + j) * 256 -- which is the layout dense_variance_kernel<16> reads (dense_variance.hip)
+    double* linvt;      // the L_kk^-T images: [patch][16][256]
+    int export_factor;  // predictive variance: the L_kk^-1 images go to the diagonal positions of the slot
     unsigned long long* stamps;   // diagnostic build (-DW1_STAMPS, GPC_W1_STAMPS=1): [phase] s_memtime sums over all patches
 };
 // phases: 0 load | 1 sweep: Gram tiles | 2 sweep: j loop | 3 chain | 4 forward solve | 5 pass: first loads + Gram tiles | 6 pass: j loop |
@@ -168,15 +172,14 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
         lr = lane & 15;                                                                                              \
         lg = lane >> 4;                                                                                              \
     } while (0)
-    const int m = A.m, ntw = g.ntw;
+    const int m = A.m;
     const double sf = A.prm.sigmaf_sq, cexp = g.c_exp, noise = A.prm.noise;
     const bool dbl = A.prm.ref_double_noise != 0;
     // ONE patch per workgroup and one factor slot per patch (no persistent patch loop: hipcc hoists every loop-invariant value of
     // the body -- lane masks, addresses, grid constants -- in front of such a loop and then spills them: 350 VGPRs in that form)
     const int patch = blockIdx.x;
-    double* Lt = g.ws + (size_t)patch * g.slot;                   // tiles (i, j): Lt + (i * ntw + j) * 256
-    double* LinvTg = Lt + (size_t)(ntw + 1) * ntw * MF_IMG;       // L_kk^-T images
-    double* LinvG = LinvTg + (size_t)ntw * MF_IMG;                // L_kk^-1 images (export only)
+    double* Lt = g.ws + (size_t)patch * W1_TRI * MF_IMG;          // tiles (i, j): Lt + W1_TILE(i, j)
+    double* LinvTg = g.linvt + (size_t)patch * W1_NT * MF_IMG;    // L_kk^-T images
 
     gpc_exp_table_init(T);
     {
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
         const int n = __builtin_amdgcn_readfirstlane(A.off[patch + 1]) - o;
         double* fs = A.f_star + (size_t)patch * m;
         __syncthreads();   // (one wave: a fence -- the exponential table is in LDS)
-        if (n <= 0 || n > MF_TS * ntw || n > W1_NPAD) {
+        if (n <= 0 || n > W1_NPAD) {
             for (int p = lane; p < m; p += 64) fs[p] = (n == 0) ? 0.0 : __builtin_nan("");
             if (lane == 0 && A.status) A.status[patch] = (n == 0) ? GPC_STATUS_OK : GPC_STATUS_NAN;
             return;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             //      the forward-solve sums  part_c = sum_{j<k} L_(k+c)j z_j  from the same operands ----
             const double* rrow[W1_C];
 #pragma unroll
-            for (int i = 0; i < W1_C; ++i) rrow[i] = Lt + ((size_t)(k + min(i, nc - 1)) * ntw) * MF_IMG;
+            for (int i = 0; i < W1_C; ++i) rrow[i] = Lt + W1_TILE(k + min(i, nc - 1), 0);
             d4 op[2][W1_C], tacc[W1_NDT];
             double part[W1_C];
 #pragma unroll
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             for (int q = 0; q < W1_C * (W1_C - 1) / 2; ++q) Lb[q] = d4{0.0, 0.0, 0.0, 0.0};
             bool ok = mf_diag_factor<true>(tacc[0], rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol, lane);
             W1_LDS_SYNC();
-            if (g.export_factor) mf_img_store(LinvG + (size_t)k * MF_IMG, lane, mf_img_load(LinvC, lane));
+            if (g.export_factor) mf_img_store(Lt + W1_TILE(k, k), lane, mf_img_load(LinvC, lane));
 #pragma unroll
             for (int i = 1; i < W1_C; ++i) {
                 if (ok && i < nc) {
@@ -312,14 +315,14 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                         const d4 lvc = mf_img_load(LinvC + c * MF_IMG, mf_opaque(lane));
                         const d4 L = w1_trsm(lvc, Tt);                     // operand image of L_(k+i)(k+c)
                         Lb[i * (i - 1) / 2 + c] = L;
-                        mf_img_store(Lt + ((size_t)(k + i) * ntw + k + c) * MF_IMG, lane, L);
+                        mf_img_store(Lt + W1_TILE(k + i, k + c), lane, L);
                     }
                     d4 Dii = tacc[i * (i + 1) / 2 + i];
 #pragma unroll
                     for (int c = 0; c < i; ++c) Dii = w1_mfma4_neg(Lb[i * (i - 1) / 2 + c], Lb[i * (i - 1) / 2 + c], Dii);
                     ok = mf_diag_factor<true>(Dii, rsbuf, LinvC + i * MF_IMG, LinvTg + (size_t)(k + i) * MF_IMG, g.pivot_tol, lane);
                     W1_LDS_SYNC();
-                    if (g.export_factor) mf_img_store(LinvG + (size_t)(k + i) * MF_IMG, lane, mf_img_load(LinvC + i * MF_IMG, mf_opaque(lane)));
+                    if (g.export_factor) mf_img_store(Lt + W1_TILE(k + i, k + i), lane, mf_img_load(LinvC + i * MF_IMG, mf_opaque(lane)));
                 }
             }
 #if defined(W1_EXP_HOT) || defined(W1_EXP_NOPASSTRSM) || defined(W1_EXP_NOBACK)
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
 #pragma unroll
                             for (int c2 = 0; c2 < c; ++c2) a4[c][t] = w1_mfma4_neg(Lb[c * (c - 1) / 2 + c2], a4[c2][t], a4[c][t]);
                             a4[c][t] = w1_trsm(lv, a4[c][t]);
-                            if (t < np4) mf_img_store(Lt + ((size_t)(W1_C + first_row0 + t) * ntw + c) * MF_IMG, lane, a4[c][t]);
+                            if (t < np4) mf_img_store(Lt + W1_TILE(W1_C + first_row0 + t, c), lane, a4[c][t]);
                         }
                     }
                     W1_STAMP(7);
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     rr[t] = k + nc + first_row + min(t, np - 1);           // (t >= np: a copy of the last row, never stored)
-                    rw_[t] = Lt + ((size_t)rr[t] * ntw) * MF_IMG;
+                    rw_[t] = Lt + W1_TILE(rr[t], 0);
                 }
                 d4 sa[2][W1_C], sb[2][2];
                 // two operand stages; the loads are UNCONDITIONAL (indices clamped: redundant re-reads) so that hipcc can count the
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                 for (int i = 1; i < W1_C; ++i)
 #pragma unroll
                     for (int c2 = 0; c2 < i; ++c2)
-                        Lq[i * (i - 1) / 2 + c2] = mf_img_load(Lt + ((size_t)(k + min(i, nc - 1)) * ntw + k + min(c2, max(nc - 2, 0))) * MF_IMG, lane);
+                        Lq[i * (i - 1) / 2 + c2] = mf_img_load(Lt + W1_TILE(k + min(i, nc - 1), k + min(c2, max(nc - 2, 0))), lane);
 #endif
 #pragma unroll
                 for (int c = 0; c < W1_C; ++c) {
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                                 for (int c2 = 0; c2 < c; ++c2) acc[c][t] = w1_mfma4_neg(Lq[c * (c - 1) / 2 + c2], acc[c2][t], acc[c][t]);
                                 acc[c][t] = w1_trsm(lv, acc[c][t]);
 #endif
-                                mf_img_store(Lt + ((size_t)rr[t] * ntw + k + c) * MF_IMG, lane, acc[c][t]);
+                                mf_img_store(Lt + W1_TILE(rr[t], k + c), lane, acc[c][t]);
                             }
                         }
                     }
@@ -526,8 +529,8 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             auto stream_addr = [&](auto P) __attribute__((always_inline)) -> const double* {
                 constexpr int q = decltype(P)::value;
                 constexpr int kk = w1_stream_col(q), t = q - kk * (kk + 1) / 2;
-                const int kq = nt - 1 - kk;                          // (negative for a column this factor does not have)
-                const double* ad = (t < kk) ? Lt + ((size_t)(kq + 1 + t) * ntw + kq) * MF_IMG : LinvTg + (size_t)kq * MF_IMG;
+                const int kq = max(nt - 1 - kk, 0);                  // (clamped for a column this factor does not have)
+                const double* ad = (t < kk) ? Lt + W1_TILE(kq + 1 + t, kq) : LinvTg + (size_t)kq * MF_IMG;
                 return kk < nt ? ad : Lt;
             };
             w1_static_for<0, W1_BW>([&](auto P) __attribute__((always_inline)) {
@@ -583,7 +586,9 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
 #ifndef W1_EXP_NOPRED
         // ---- predictive mean ----
         W1_FRESH_LANE();
-        if (A.xs0 == nullptr && A.grid_sz <= 32) {
+        if (m <= 0) {
+            // (the variance solve forms the mean from its own K* tiles: the fit predicts nothing)
+        } else if (A.xs0 == nullptr && A.grid_sz <= 32) {
             // separable grid: f[py][px] = sum_i Ey[py][i] * (sf alpha_i Ex[px][i]): four 16 x 16 output tiles, no reduction across waves
             const int sz = A.grid_sz;
             const double res = A.grid_res;
@@ -663,11 +668,12 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
 
 bool dense_w1_supported(const DenseArgs& a)
 {
-    return a.n_max <= W1_NPAD && a.ny == 1 && !a.v_star && !a.sel;
+    // (with the variance: point-wise X* only -- the variance entry has no grid form)
+    return a.n_max <= W1_NPAD && a.ny == 1 && !a.sel && (a.v_star == nullptr || a.xs0 != nullptr);
 }
 
-// One factor slot per patch of a launch (304 KB at n = 256: 2.5 GB for the 8192 patches of BASELINE config 2 -- sized for 288 GB);
-// a larger batch goes through in launches of W1_MAX_SLOTS patches that reuse the slots.
+// One factor slot per patch of a launch (304 KB: 2.5 GB for the 8192 patches of BASELINE config 2 -- sized for 288 GB); a larger
+// batch goes through in launches of W1_MAX_SLOTS patches that reuse the slots.
 #define W1_MAX_SLOTS 16384
 static int w1_chunk(const DenseArgs& a)
 {
@@ -679,43 +685,57 @@ static int w1_chunk(const DenseArgs& a)
 size_t dense_w1_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
 {
     (void)ctx;
-    const int ntw = (a.n_max + MF_TS - 1) / MF_TS;
     const int grid = w1_chunk(a);
     if (grid_out) *grid_out = grid;
-    return sizeof(double) * big_slot_doubles(ntw) * (size_t)grid;
+    // factor slots | L_kk^-T images | (variance without alpha_out: the weights the variance kernel forms the mean from)
+    return sizeof(double) * ((size_t)(W1_TRI + W1_NT) * MF_IMG * (size_t)grid + (a.v_star ? (size_t)a.n_total : 0));
 }
 
-int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
+int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
 {
+    DenseArgs a = a_in;
+    double* v_star = a.v_star;
+    a.v_star = nullptr;
     W1Params g;
-    g.a = a;
     g.c_exp = (double)(-0.5f) / a.prm.l_sq;
     g.pivot_tol = GPC_PIVOT_RTOL * (a.prm.sigmaf_sq + a.prm.noise);
     g.ws = static_cast<double*>(ctx->ws);
-    g.ntw = (a.n_max + MF_TS - 1) / MF_TS;
-    g.slot = big_slot_doubles(g.ntw);
-    g.export_factor = 0;
+    g.linvt = g.ws + (size_t)W1_TRI * MF_IMG * (size_t)grid;
+    g.export_factor = v_star ? 1 : 0;
     g.stamps = nullptr;
-    ctx->last_dense_kernel = "dense_mfma_w1";
+    if (v_star) {
+        // Predictive variance (gaussian_process::predict_measurements, /root/reference/src/gaussian_process.cpp:35-43): the slots are the
+        // factor export dense_variance_kernel<16> reads, the fit predicts nothing (the solve forms the mean from the same K* tiles)
+        a.m = 0;
+        if (!a.alpha_out) a.alpha_out = g.linvt + (size_t)W1_NT * MF_IMG * (size_t)grid;
+    }
+    ctx->last_dense_kernel = v_star ? "dense_mfma_w1 + dense_variance" : "dense_mfma_w1";
 #ifdef W1_STAMPS
     if (getenv("GPC_W1_STAMPS")) {
         GPC_HIP(ctx, hipMalloc(&g.stamps, sizeof(unsigned long long) * W1_NPH));
         GPC_HIP(ctx, hipMemsetAsync(g.stamps, 0, sizeof(unsigned long long) * W1_NPH, ctx->stream));
     }
 #endif
+    // (diagnostic: GPC_W1_LDS_PAD bytes of unused dynamic LDS per workgroup cap the workgroups resident on a CU)
+    const char* pad_e = getenv("GPC_W1_LDS_PAD");
+    const size_t pad = pad_e ? (size_t)atoi(pad_e) : 0;
     for (int base = 0; base < a.P; base += grid) {
-        // a launch works on patches base .. base + cnt - 1: the kernel's patch index is its workgroup index, `off`, f* and status
+        // a launch works on patches base .. base + cnt - 1: the kernel's patch index is its workgroup index; `off`, f*, V* and status
         // are passed shifted (off[] holds absolute point offsets, so x, y and alpha stay as they are)
         const int cnt = a.P - base < grid ? a.P - base : grid;
+        g.a = a;
         g.a.P = cnt;
         g.a.off = a.off + base;
-        g.a.f_star = a.f_star ? a.f_star + (size_t)base * a.m : nullptr;
+        g.a.f_star = a.f_star ? a.f_star + (size_t)base * a.ny * a_in.m : nullptr;
         g.a.status = a.status ? a.status + base : nullptr;
-        // (diagnostic: GPC_W1_LDS_PAD bytes of unused dynamic LDS per workgroup cap the workgroups resident on a CU)
-        const char* pad_e = getenv("GPC_W1_LDS_PAD");
-        const size_t pad = pad_e ? (size_t)atoi(pad_e) : 0;
         hipLaunchKernelGGL(dense_w1_kernel, dim3(cnt), dim3(64), pad, ctx->stream, g);
         GPC_HIP(ctx, hipGetLastError());
+        if (v_star) {
+            DenseArgs av = g.a;
+            av.m = a_in.m;
+            const int rc = dense_variance_launch(ctx, av, W1_NT, g.ws, a.alpha_out, v_star + (size_t)base * a_in.m);
+            if (rc != GPC_OK) return rc;
+        }
     }
 #ifdef W1_STAMPS
     if (g.stamps) {

@@ -75,11 +75,39 @@ __global__ __launch_bounds__(64 * WV, 2) void dense_variance_kernel(VarParams g)
         return;
     }
     const int nt = __builtin_amdgcn_readfirstlane((n + MF_TS - 1) / MF_TS);
+    // Small-argument regime (dense_mfma.hip): when |c| d^2 <= 2^-5 for every (training point, prediction point) pair of the patch the
+    // K* tiles take the degree-7 polynomial instead of the table-driven exponential -- half the VALU work of a block's 64 evaluations
+    // per lane, on the pipe the MFMAs need.  Bound: max-norm distances of the points and of X* from the patch's first point.
+    __shared__ unsigned long long ext_bits[2];
+    if (tid < 2) ext_bits[tid] = 0ull;
+    __syncthreads();
+    const double xo0 = A.x0[o], xo1 = A.x1[o];
+    double dev_p = 0.0, dev_q = 0.0;
     for (int i = tid; i < NT * MF_TS; i += DVT) {
-        px0[i] = (i < n) ? A.x0[o + i] : 0.0;
-        px1[i] = (i < n) ? A.x1[o + i] : 0.0;
+        const bool live = i < n;
+        const double q0 = live ? A.x0[o + i] : xo0, q1 = live ? A.x1[o + i] : xo1;
+        dev_p = __builtin_fmax(dev_p, __builtin_fmax(__builtin_fabs(q0 - xo0), __builtin_fabs(q1 - xo1)));
+        px0[i] = live ? q0 : 0.0;
+        px1[i] = live ? q1 : 0.0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) al[c][i] = (c < ny && i < n) ? g.alpha[(size_t)c * A.n_total + o + i] : 0.0;
+    }
+    for (int p = tid; p < m; p += DVT)
+        dev_q = __builtin_fmax(dev_q, __builtin_fmax(__builtin_fabs(A.xs0[p] - xo0), __builtin_fabs(A.xs1[p] - xo1)));
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) {
+        dev_p = __builtin_fmax(dev_p, __shfl_xor(dev_p, o_, 64));
+        dev_q = __builtin_fmax(dev_q, __shfl_xor(dev_q, o_, 64));
+    }
+    if (lane == 0) {     // non-negative doubles order like their bits; a NaN extent fails the test below
+        atomicMax(&ext_bits[0], (unsigned long long)__double_as_longlong(dev_p));
+        atomicMax(&ext_bits[1], (unsigned long long)__double_as_longlong(dev_q));
+    }
+    __syncthreads();
+    bool small_k;
+    {
+        const double r = __longlong_as_double((long long)ext_bits[0]) + __longlong_as_double((long long)ext_bits[1]);
+        small_k = __builtin_amdgcn_readfirstlane((int)(-cexp * (2.0 * r * r) <= GPC_EXP_SMALL_MAX)) != 0 && !(dev_p != dev_p) && !(dev_q != dev_q);
     }
     const double* F = g.factor + (size_t)patch * NTILES * MF_IMG;
     // this thread's 32 bytes of a chunk: chunk c = images [c DV_CH, (c + 1) DV_CH) = 2048 doubles, 4 per thread
@@ -129,10 +157,25 @@ __global__ __launch_bounds__(64 * WV, 2) void dense_variance_kernel(VarParams g)
             if (i < nt) {
                 // B_i: K*(rows 16 i + lg + 4 r, column q), straight into the accumulator; rows beyond n are padding -> 0
                 d4 acc;
+                // (evaluated for every lane -- padded points and columns are finite numbers -- and SELECTED: a mask around the
+                // exponential becomes a branch per element)
+                if (small_k) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int p = MF_TS * i + lg + 4 * r;
+                        acc[r] = gpc_rbf_small(sf, cexp, px0[p], px1[p], gx0, gx1);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int p = MF_TS * i + lg + 4 * r;
+                        acc[r] = gpc_rbf_neg(sf, cexp, px0[p], px1[p], gx0, gx1, T);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int p = MF_TS * i + lg + 4 * r;
-                    acc[r] = (qv && p < n) ? gpc_rbf_neg(sf, cexp, px0[p], px1[p], gx0, gx1, T) : 0.0;
+                    acc[r] = (qv && p < n) ? acc[r] : 0.0;
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
                         if (c < ny) fm[c] = __builtin_fma(acc[r], al[c][p], fm[c]);      // f* = K*^T alpha (:32), same tile
@@ -157,12 +200,12 @@ __global__ __launch_bounds__(64 * WV, 2) void dense_variance_kernel(VarParams g)
                         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(img[s], V[k][s], acc, 0, 0, 1);
                     } else {
                         // V_i = L_ii^-1 acc: four independent products, tree sum
-                        const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
-                        const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[0], acc[0], z4, 0, 0, 0);
-                        const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[1], acc[1], z4, 0, 0, 0);
-                        const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[2], acc[2], z4, 0, 0, 0);
-                        const d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(img[3], acc[3], z4, 0, 0, 0);
-                        V[i] = (D0 + D1) + (D2 + D3);
+                        // V_i = L_ii^-1 acc: accumulator-chained (no VALU add tree behind the MFMA -> VALU hazard, 24 registers less)
+                        d4 D = __builtin_amdgcn_mfma_f64_16x16x4f64(img[0], acc[0], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+                        D = __builtin_amdgcn_mfma_f64_16x16x4f64(img[1], acc[1], D, 0, 0, 0);
+                        D = __builtin_amdgcn_mfma_f64_16x16x4f64(img[2], acc[2], D, 0, 0, 0);
+                        D = __builtin_amdgcn_mfma_f64_16x16x4f64(img[3], acc[3], D, 0, 0, 0);
+                        V[i] = D;
                         nrm += (V[i][0] * V[i][0] + V[i][1] * V[i][1]) + (V[i][2] * V[i][2] + V[i][3] * V[i][3]);
                     }
                 }
