@@ -402,99 +402,80 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     W1_STAMP(7);
                 }
             }
-            for (int first_row = first_row0; first_row < rows_tot; first_row += 2) {
-                const int np = min(2, rows_tot - first_row);
+            // k > 0 (rows beyond the block exist only when the block has all four columns): FOUR rows per pass -- 16 accumulators; the four
+            // column operands L_(k+c)j double-buffered, the four row operands L_rj single-buffered and re-requested for j + 1 as soon as
+            // their four products of j are issued (twelve products of lead).  Eight images per 16 products: the two-row passes of the
+            // first version fetched six per eight, and at eight patches per CU every one of them is an L2 miss (the kernel moves
+            // 10.7 GB per launch at 6 TB/s: it runs at the HBM bandwidth the part delivers).
+            for (int first_row = first_row0; first_row < rows_tot; first_row += 4) {
+                const int np4 = min(4, rows_tot - first_row);
                 W1_FRESH_LANE();
-                d4 acc[W1_C][2];
-                int rr[2];
-                const double* rw_[2];
+                int rr[4];
+                const double* rw_[4];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    rr[t] = k + nc + first_row + min(t, np - 1);           // (t >= np: a copy of the last row, never stored)
+                for (int t = 0; t < 4; ++t) {
+                    rr[t] = k + W1_C + first_row + min(t, np4 - 1);        // (t >= np4: a copy of the last row, never stored)
                     rw_[t] = Lt + W1_TILE(rr[t], 0);
                 }
-                d4 sa[2][W1_C], sb[2][2];
-                // two operand stages; the loads are UNCONDITIONAL (indices clamped: redundant re-reads) so that hipcc can count the
-                // outstanding ones; the first stage is requested before the Gram tiles are evaluated
-#define W1_LOAD_STAGE(st, jj, NPC)                                                                                   \
-    do {                                                                                                             \
-        _Pragma("unroll") for (int c = 0; c < W1_C; ++c) sa[st][c] = mf_img_load(rrow[c] + (size_t)W1_JX(jj) * MF_IMG, lane); \
-        _Pragma("unroll") for (int t = 0; t < NPC; ++t) sb[st][t] = mf_img_load(rw_[t] + (size_t)W1_JX(jj) * MF_IMG, lane);  \
-    } while (0)
-#define W1_USE_STAGE(st, NPC)                                                                                        \
-    do {                                                                                                             \
-        _Pragma("unroll") for (int t = 0; t < NPC; ++t)                                                              \
-            _Pragma("unroll") for (int c = 0; c < W1_C; ++c) acc[c][t] = w1_mfma4_neg(sa[st][c], sb[st][t], acc[c][t]); \
-    } while (0)
-#define W1_UPDATE_LOOP(NPC)                                                                                          \
-    do {                                                                                                             \
-        if (k > 0) W1_LOAD_STAGE(0, 0, NPC);                                                                         \
-        _Pragma("unroll") for (int t = 0; t < NPC; ++t) {                                                            \
-            /* two tiles -- eight dependency chains -- per basic block: with four the chains' temporaries on top of the  \
-               accumulators and the operand stage in flight spill, and a spill reload waits on vmcnt, i.e. on the prefetch */ \
-            d4 gv[W1_C];                                                                                             \
-            if (nc >= 2) W1_GRAM_ROW(gv, 2, false, rr[t], k);                                                        \
-            else W1_GRAM_ROW(gv, 1, false, rr[t], k);                                                                \
-            acc[0][t] = gv[0];                                                                                       \
-            if (nc >= 2) acc[1][t] = gv[1];                                                                          \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
-            if (nc == W1_C) W1_GRAM_ROW(gv, 2, false, rr[t], k + 2);                                                 \
-            else if (nc == 3) W1_GRAM_ROW(gv, 1, false, rr[t], k + 2);                                               \
-            if (nc >= 3) acc[2][t] = gv[0];                                                                          \
-            if (nc == W1_C) acc[3][t] = gv[1];                                                                       \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
-        }                                                                                                            \
-        W1_STAMP(5);                                                                                                 \
-        for (int j = 0; j < k; j += 2) {                                                                             \
-            W1_LOAD_STAGE(1, j + 1, NPC);                                                                            \
-            W1_USE_STAGE(0, NPC);                                                                                    \
-            W1_LOAD_STAGE(0, min(j + 2, kl), NPC);                                                                   \
-            W1_USE_STAGE(1, NPC);                                                                                    \
-        }                                                                                                            \
-    } while (0)
+                d4 acc[W1_C][4], A2[2][W1_C], B[4];
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int c = 0; c < W1_C; ++c) A2[0][c] = mf_img_load(rrow[c], lane);
 #pragma unroll
-                    for (int c = 0; c < W1_C; ++c) acc[c][t] = d4{0.0, 0.0, 0.0, 0.0};
+                for (int t = 0; t < 4; ++t) B[t] = mf_img_load(rw_[t], lane);
 #pragma unroll
-                for (int st = 0; st < 2; ++st) {
-#pragma unroll
-                    for (int c = 0; c < W1_C; ++c) sa[st][c] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) sb[st][t] = d4{0.0, 0.0, 0.0, 0.0};
+                for (int t = 0; t < 4; ++t) {
+                    d4 gv[W1_C];
+                    W1_GRAM_ROW(gv, 2, false, rr[t], k);
+                    acc[0][t] = gv[0]; acc[1][t] = gv[1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    W1_GRAM_ROW(gv, 2, false, rr[t], k + 2);
+                    acc[2][t] = gv[0]; acc[3][t] = gv[1];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (np == 2) W1_UPDATE_LOOP(2);
-                else W1_UPDATE_LOOP(1);
+                W1_STAMP(5);
+                // one j: request the column operands of jn into the other stage, then row by row the four products and the row's next request
+#define W1_PASS_J(st, jn, PREFETCH)                                                                                  \
+    do {                                                                                                             \
+        /* (the scheduling barriers pin the requests where they are written: left alone, hipcc sinks every one of them to its  \
+           first use -- request, s_waitcnt vmcnt(0), MFMA -- and the prefetch is gone) */                              \
+        if (PREFETCH) {                                                                                              \
+            _Pragma("unroll") for (int c = 0; c < W1_C; ++c) A2[(st) ^ 1][c] = mf_img_load(rrow[c] + (size_t)W1_JX(jn) * MF_IMG, lane); \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                              \
+            _Pragma("unroll") for (int c = 0; c < W1_C; ++c) acc[c][t] = w1_mfma4_neg(A2[st][c], B[t], acc[c][t]);    \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            if (PREFETCH) B[t] = mf_img_load(rw_[t] + (size_t)W1_JX(jn) * MF_IMG, lane);                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+    } while (0)
+                for (int j = 0; j + 2 < k; j += 2) {
+                    W1_PASS_J(0, j + 1, true);
+                    W1_PASS_J(1, j + 2, true);
+                }
+                W1_PASS_J(0, kl, true);                 // (k is a multiple of four: the last pair of j; its second half requests nothing)
+                W1_PASS_J(1, kl, false);
+#undef W1_PASS_J
                 W1_STAMP(6);
                 W1_FRESH_LANE();
-                // the block's strictly lower tiles come back from the workspace (this wave's own stores of the chain, fenced below it;
-                // L2 / L1 hits): as registers they would be live across the whole update loop -- 48 VGPRs on top of its 160 --
-                // and the spills that causes wait on vmcnt, i.e. on the operand prefetch
-#ifdef W1_LB_RESIDENT
-#define Lq Lb
-#else
+                // the block's strictly lower tiles come back from the workspace (this wave's own stores of the chain, fenced below it):
+                // as registers they would be live across the update loop -- 48 VGPRs on top of its 224
                 d4 Lq[W1_C * (W1_C - 1) / 2];
 #pragma unroll
                 for (int i = 1; i < W1_C; ++i)
 #pragma unroll
-                    for (int c2 = 0; c2 < i; ++c2)
-                        Lq[i * (i - 1) / 2 + c2] = mf_img_load(Lt + W1_TILE(k + min(i, nc - 1), k + min(c2, max(nc - 2, 0))), lane);
-#endif
+                    for (int c2 = 0; c2 < i; ++c2) Lq[i * (i - 1) / 2 + c2] = mf_img_load(Lt + W1_TILE(k + i, k + c2), lane);
 #pragma unroll
                 for (int c = 0; c < W1_C; ++c) {
-                    if (c < nc) {
-                        const d4 lv = mf_img_load(LinvC + c * MF_IMG, mf_opaque(lane));
+                    const d4 lv = mf_img_load(LinvC + c * MF_IMG, mf_opaque(lane));
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            if (t < np) {
+                    for (int t = 0; t < 4; ++t) {
 #ifndef W1_EXP_NOPASSTRSM      // (diagnostic: what the TRSM chains of the row passes cost -- stores only)
 #pragma unroll
-                                for (int c2 = 0; c2 < c; ++c2) acc[c][t] = w1_mfma4_neg(Lq[c * (c - 1) / 2 + c2], acc[c2][t], acc[c][t]);
-                                acc[c][t] = w1_trsm(lv, acc[c][t]);
+                        for (int c2 = 0; c2 < c; ++c2) acc[c][t] = w1_mfma4_neg(Lq[c * (c - 1) / 2 + c2], acc[c2][t], acc[c][t]);
+                        acc[c][t] = w1_trsm(lv, acc[c][t]);
 #endif
-                                mf_img_store(Lt + W1_TILE(rr[t], k + c), lane, acc[c][t]);
-                            }
-                        }
+                        if (t < np4) mf_img_store(Lt + W1_TILE(rr[t], k + c), lane, acc[c][t]);
                     }
                 }
                 W1_STAMP(7);
