@@ -433,6 +433,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 W1_STAMP(5);
+                d4 Lq[W1_C * (W1_C - 1) / 2];      // images of L_(k+i)(k+c2), c2 < i, at i (i - 1) / 2 + c2
                 // one j: request the column operands of jn into the other stage, then row by row the four products and the row's next request
 #define W1_PASS_J(st, jn, PREFETCH)                                                                                  \
     do {                                                                                                             \
@@ -446,6 +447,12 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             _Pragma("unroll") for (int c = 0; c < W1_C; ++c) acc[c][t] = w1_mfma4_neg(A2[st][c], B[t], acc[c][t]);    \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
             if (PREFETCH) B[t] = mf_img_load(rw_[t] + (size_t)W1_JX(jn) * MF_IMG, lane);                             \
+            else {     /* the last j: the block's lower tiles for the TRSMs take the place of the operands that are done */ \
+                if (t < 3) Lq[t] = mf_img_load(Lt + W1_TILE(k + (t == 0 ? 1 : 2), k + (t == 2 ? 1 : 0)), lane);      \
+                else {                                                                                               \
+                    _Pragma("unroll") for (int c2 = 0; c2 < 3; ++c2) Lq[3 + c2] = mf_img_load(Lt + W1_TILE(k + 3, k + c2), lane); \
+                }                                                                                                    \
+            }                                                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
     } while (0)
@@ -458,13 +465,8 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
 #undef W1_PASS_J
                 W1_STAMP(6);
                 W1_FRESH_LANE();
-                // the block's strictly lower tiles come back from the workspace (this wave's own stores of the chain, fenced below it):
-                // as registers they would be live across the update loop -- 48 VGPRs on top of its 224
-                d4 Lq[W1_C * (W1_C - 1) / 2];
-#pragma unroll
-                for (int i = 1; i < W1_C; ++i)
-#pragma unroll
-                    for (int c2 = 0; c2 < i; ++c2) Lq[i * (i - 1) / 2 + c2] = mf_img_load(Lt + W1_TILE(k + i, k + c2), lane);
+                // (the block's strictly lower tiles Lq came back from the workspace during the last j -- this wave's own stores of the
+                // chain, fenced below it: as registers they would be live across the update loop, 48 VGPRs on top of its 224)
 #pragma unroll
                 for (int c = 0; c < W1_C; ++c) {
                     const d4 lv = mf_img_load(LinvC + c * MF_IMG, mf_opaque(lane));

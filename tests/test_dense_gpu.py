@@ -185,6 +185,93 @@ def test_dense_edge_cases(gp, oracle):
     assert np.all(np.isnan(f[0])) and np.all(np.isnan(al[0, :3])) and np.all(np.isfinite(f[1]))
 
 
+def _mixed_batch(sizes, seed, res=0.15):
+    """A batch with exactly the given point counts (zeros allowed), surfaces as synth.make_patches draws them."""
+    rng = np.random.default_rng(seed)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    N = int(off[-1])
+    x0, x1 = rng.uniform(-res / 2, res / 2, N), rng.uniform(-res / 2, res / 2, N)
+    y = np.zeros((1, N))
+    for i, n in enumerate(sizes):
+        sl = slice(off[i], off[i + 1])
+        d = 0.01 * np.sin(rng.uniform(5, 30) * x0[sl] + rng.uniform(0, 6)) * np.cos(rng.uniform(5, 30) * x1[sl]) + rng.normal(0, 0.003, n)
+        y[0, sl] = d - (d.mean() if n else 0.0)
+    return off, x0, x1, y
+
+
+@pytest.mark.parametrize("want_var", [0, 1])
+def test_dense_one_wave_kernel_edge_cases(gp, oracle, monkeypatch, want_var):
+    """The one-wave-per-patch kernel (dense_mfma_w1.hip: the depth plane of a batch whose largest patch has 193 .. 256 points) on a
+    batch that mixes every tile count 1 .. 16 with sizes on and next to tile boundaries, empty patches, a single point, and a patch
+    that is not SPD (duplicated point under zero noise: the failing pivot sits in the third tile column, the patches around it must
+    not notice); mean-only and with the predictive variance (factor export + dense_variance_kernel)."""
+    capi, ctx = gp
+    res, sz = 0.15, 12
+    sizes = [256, 0, 1, 15, 16, 17, 31, 33, 48, 64, 65, 80, 100, 112, 128, 129, 150, 176, 192, 193, 200, 208, 224, 239, 240, 241, 255, 256, 0, 7]
+    off, x0, x1, y = _mixed_batch(sizes, seed=5)
+    xs0, xs1 = oracle.grid(res, sz)
+    p = capi.default_params_dense(want_variance=want_var)
+    f, v, st, al = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
+    assert ctx.last_dense_kernel() == ("dense_mfma_w1 + dense_variance" if want_var else "dense_mfma_w1")
+    fo, vo, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, variance=bool(want_var), want_alpha=True)
+    assert np.array_equal(st, so) and np.all(st == 0)
+    _close(f, fo, FTOL)
+    _close(al, ao, ATOL)
+    if want_var:
+        assert np.max(np.abs(v - vo)) <= VTOL
+    # the grid entry (separable predictive mean) on the same batch
+    if not want_var:
+        fg, stg = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz)
+        assert ctx.last_dense_kernel() == "dense_mfma_w1" and np.all(stg == 0)
+        _close(fg, fo, FTOL)
+    # launches of 7 patches that reuse the factor slots (GPC_W1_SLOTS; production: 16384) give the same bits
+    monkeypatch.setenv("GPC_W1_SLOTS", "7")
+    f2, v2, st2, al2 = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
+    monkeypatch.delenv("GPC_W1_SLOTS")
+    assert np.array_equal(f2, f) and np.array_equal(al2, al) and np.array_equal(st2, st)
+    if want_var:
+        assert np.array_equal(v2, v)
+    # not SPD in the middle of the batch: a duplicated point under zero noise (short length scale, so that the neighbours -- and the
+    # rest of this patch's Gram matrix -- stay well conditioned without a noise term); the failing pivot is in the third tile column
+    kw0 = dict(sigmaf_sq=1.0, l_sq=0.01 ** 2, noise=0.0)
+    p0 = capi.default_params_dense(want_variance=want_var, **kw0)
+    off3, x03, x13, y3 = _mixed_batch([200, 250, 256], seed=6)
+    x03[off3[1] + 40] = x03[off3[1] + 35]
+    x13[off3[1] + 40] = x13[off3[1] + 35]
+    f3, v3, st3, al3 = ctx.dense_fit_predict(p0, off3, x03, x13, y3, xs0, xs1, want_alpha=True)
+    fo3, vo3, so3 = oracle.dense_fit_predict_batch(oracle.dense_params(kw0["sigmaf_sq"], kw0["l_sq"], 0.0), off3, x03, x13, y3, xs0, xs1,
+                                                   variance=bool(want_var))
+    assert ctx.last_dense_kernel().startswith("dense_mfma_w1")
+    assert st3.tolist() == so3.tolist() == [0, 1, 0]
+    assert np.all(np.isnan(f3[1])) and np.all(np.isnan(al3[0, off3[1]:off3[2]])) and np.all(np.isfinite(f3[[0, 2]]))
+    if want_var:
+        assert np.all(np.isnan(v3[1])) and np.all(np.isfinite(v3[[0, 2]]))
+    _close(f3[[0, 2]], fo3[[0, 2]], 1e-7)          # (zero noise: conditioned by the closest pairs of points)
+
+
+@pytest.mark.parametrize("l_sq,shift,tol", [(0.05 ** 2, 0.0, 1e-8), (0.5 ** 2, 0.0, FTOL), (9.0, 0.4, FTOL), (9.0, 30.0, FTOL)])
+def test_dense_one_wave_kernel_exp_regimes(gp, oracle, l_sq, shift, tol):
+    """The exponential regimes of test_dense_mfma_exp_regimes on the one-wave kernel (patches of up to 256 points): table-driven
+    Gram tiles and grid factors, polynomial Gram with table-driven grid, polynomial everywhere -- and the variance kernel's own
+    small-argument test on the same patches."""
+    capi, ctx = gp
+    res, sz = 0.15, 20
+    off, x0, x1, y = synth.make_patches(6, 256, seed=34, ragged=True, n_min=150)
+    x0, x1 = x0 + shift, x1 - shift
+    kw = dict(sigmaf_sq=0.5, l_sq=l_sq, noise=1e-3)
+    po = oracle.dense_params(kw["sigmaf_sq"], kw["l_sq"], kw["noise"])
+    xs0, xs1 = oracle.grid(res, sz)
+    f1, st1 = ctx.dense_fit_predict_grid(capi.default_params_dense(**kw), off, x0, x1, y, res, sz)
+    assert ctx.last_dense_kernel() == "dense_mfma_w1"
+    f2, v2, st2 = ctx.dense_fit_predict(capi.default_params_dense(want_variance=1, **kw), off, x0, x1, y, xs0, xs1)
+    assert ctx.last_dense_kernel() == "dense_mfma_w1 + dense_variance"
+    fo, vo, so = oracle.dense_fit_predict_batch(po, off, x0, x1, y, xs0, xs1, variance=True)
+    assert np.all(st1 == 0) and np.all(st2 == 0) and np.all(so == 0)
+    _close(f1, fo, tol)
+    _close(f2, fo, tol)
+    assert np.max(np.abs(v2 - vo)) <= (1e-9 if tol > FTOL else 1e-10)
+
+
 def test_dense_big_kernel_edge_cases(gp, oracle, monkeypatch):
     """The tiled left-looking kernel (n_max > 256; GPC_NO_SPLIT keeps the whole batch on it) on a batch that mixes an empty patch, a tiny patch, a patch that is not
     SPD (duplicated point, zero noise: the failing pivot sits in a late tile column) and full-size patches; grid and

@@ -23,7 +23,7 @@ DST = os.path.join(ROOT, "profiles")
 WORK = {
     "c2": ("dense_w1_kernel", 2, 1, "dense_mfma_w1"),
     "c2var": ("dense_variance_kernel<16,", 1, 1, "dense_variance@C2"),
-    "c3": ("dense_big_kernel<8, 1024, 2, 2, false, 4, 3>", 1, 1, "dense_mfma_big@n512"),
+    "c3": ("dense_big_kernel<4, 512, 2, 2, false, 4, 1>", 1, 1, "dense_mfma_big@n512"),
     "c4fill": ("sparse_add_", 4, 4, "sparse_add@C4_fill"),          # one pass = 4 add calls, each a small-basis + a regular kernel
     "c4defaults": ("sparse_add_", 4, 4, "sparse_add@C4_defaults"),        # + the rows phase (sparse_add_rows_kernel), same family
     "c4defaults3": ("sparse_add_", 4, 4, "sparse_add@C4_defaults_ny3"),
