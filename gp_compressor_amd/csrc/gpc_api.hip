@@ -296,18 +296,24 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
     const bool ny_ok = a.ny == 1 || a.ny == 3;
     if (!force_generic && !force_big && ny_ok) {
         const bool no_split = a.P == 1 || getenv("GPC_NO_SPLIT");
-        // 192 < n <= 256, depth plane, mean only (BASELINE config 2): the tiled kernel in its TWO-WAVE shape -- four patches in flight
-        // per CU instead of one, so that a patch's serial chain runs under the MFMAs of three others (C2: 2.15 against 2.57 ms for
-        // the register-resident kernel, which keeps the colour planes, the variance export, the small sizes and 257 .. 272 points)
-        if (a.n_max > 192 && a.n_max <= 256 && a.P > 1 && dense_w1_supported(a) && !getenv("GPC_NO_W1") && !getenv("GPC_NO_W2")) {
-            // (round 3, later) ONE wave per patch, eight patches per CU: no hand-over between waves at all (dense_mfma_w1.hip)
-            int grid_w1 = 0;
-            const size_t w1_bytes = (dense_w1_ws_bytes(ctx, a, &grid_w1) + 255) & ~(size_t)255;
-            const int rcw = gpc_ws_reserve(ctx, w1_bytes);
-            if (rcw != GPC_OK) return rcw;
-            return dense_w1_launch(ctx, a, grid_w1);
+        // Depth plane, n <= 256, a batch large enough to fill the chip: ONE wave per patch, eight patches per CU (dense_mfma_w1.hip) --
+        // no hand-over between waves at all.  Measured against the register-resident kernel at 8192 patches: 256 points 1.72 against
+        // 2.57 ms, 192: 0.98 / 1.70, 128: 0.48 / 1.06, 64: 0.20 / 0.62; at 512 patches the two are level, below that the register kernel's
+        // eight waves per patch win on latency (64 patches x 192 points: 0.066 against 0.134 ms) -- hence the batch-size rule
+        // (GPC_W1_MIN_P overrides it; the variance goes this way for 193 .. 256 points, where its solve kernel is the <16> shape).
+        {
+            const char* mp = getenv("GPC_W1_MIN_P");
+            const int min_p = mp ? atoi(mp) : 4 * ctx->num_cus;
+            if (a.n_max <= 256 && a.P >= min_p && a.P > 1 && (a.n_max > 192 || !a.v_star) && dense_w1_supported(a) && !getenv("GPC_NO_W1")) {
+                int grid_w1 = 0;
+                const size_t w1_bytes = (dense_w1_ws_bytes(ctx, a, &grid_w1) + 255) & ~(size_t)255;
+                const int rcw = gpc_ws_reserve(ctx, w1_bytes);
+                if (rcw != GPC_OK) return rcw;
+                return dense_w1_launch(ctx, a, grid_w1);
+            }
         }
-        if (a.n_max > 192 && a.n_max <= 256 && a.ny == 1 && !a.v_star && a.P > 1 && !getenv("GPC_NO_W2")) {
+        // (GPC_W2=1: the two-wave shape of the tiled kernel, round 3's first headline kernel, kept as a cross-check)
+        if (a.n_max > 192 && a.n_max <= 256 && a.ny == 1 && !a.v_star && a.P > 1 && getenv("GPC_W2")) {
             int grid_w2 = 0;
             const size_t w2_bytes = (dense_big_ws_bytes(ctx, a, &grid_w2) + 255) & ~(size_t)255;
             const int rcw = gpc_ws_reserve(ctx, w2_bytes);
@@ -571,7 +577,8 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     const bool want_v = !grid && params->want_variance && v_star;
     const size_t N = (size_t)n_total;
-    const int C = (P >= 2048 && !getenv("GPC_HOST_NO_PIPELINE")) ? 4 : 1;
+    // (chunks of at least 1024 patches: below four patches per CU the dense dispatch leaves the one-wave-per-patch kernel)
+    const int C = getenv("GPC_HOST_NO_PIPELINE") ? 1 : P >= 4096 ? 4 : P >= 2048 ? 2 : 1;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         if ((rc = gpc_aux_streams(ctx))) return rc;

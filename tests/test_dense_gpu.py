@@ -60,24 +60,28 @@ def test_dense_golden(gp, name, monkeypatch):
 
 @pytest.fixture(params=["dispatch", "generic", "big", "reg", "big_w4", "w2"])
 def kernel_choice(request, monkeypatch):
-    """Run a test with the normal dispatch (register-tile MFMA kernel for n <= 256 -- the two-wave shape of the tiled kernel for the
-    depth plane of 193 .. 256 points -- and the tiled left-looking MFMA kernel above), with the generic global-workspace kernel
-    forced, with the left-looking kernel forced for every n (its two-wave / four-workgroups-per-CU shape below 257 points for the
-    depth plane), with the register-tile kernel for every n <= 256 ("reg": GPC_NO_W2), and with the tiled kernel's four-wave
-    shape ("big_w4").  The environment is read at every call."""
-    for e in ("GPC_FORCE_GENERIC", "GPC_FORCE_BIG", "GPC_NO_W2", "GPC_BIG_NO_W2", "GPC_NO_W1"):
+    """Run a test with the normal dispatch -- the one-wave-per-patch kernel for the depth plane of n <= 256 (at every batch size here:
+    GPC_W1_MIN_P=2; in production from 4 patches per CU up), the register-tile MFMA kernel for colour planes, the tiled left-looking
+    MFMA kernel above 256 points --, with the generic global-workspace kernel forced, with the left-looking kernel forced for every n
+    (its two-wave / four-workgroups-per-CU shape below 257 points for the depth plane), with the register-tile kernel for every
+    n <= 256 ("reg": GPC_NO_W1), with the tiled kernel's four-wave shape ("big_w4"), and with the two-wave shape where round 3's first
+    headline ran it ("w2": GPC_W2, depth plane of 193 .. 256 points).  The environment is read at every call."""
+    for e in ("GPC_FORCE_GENERIC", "GPC_FORCE_BIG", "GPC_NO_W2", "GPC_BIG_NO_W2", "GPC_NO_W1", "GPC_W2", "GPC_W1_MIN_P"):
         monkeypatch.delenv(e, raising=False)
-    if request.param == "generic":
+    if request.param == "dispatch":
+        monkeypatch.setenv("GPC_W1_MIN_P", "2")
+    elif request.param == "generic":
         monkeypatch.setenv("GPC_FORCE_GENERIC", "1")
     elif request.param == "big":
         monkeypatch.setenv("GPC_FORCE_BIG", "1")
     elif request.param == "reg":
-        monkeypatch.setenv("GPC_NO_W2", "1")
+        monkeypatch.setenv("GPC_NO_W1", "1")
     elif request.param == "big_w4":
         monkeypatch.setenv("GPC_FORCE_BIG", "1")
         monkeypatch.setenv("GPC_BIG_NO_W2", "1")
-    elif request.param == "w2":          # the two-wave shape of the tiled kernel where the one-wave-per-patch kernel is the default
+    elif request.param == "w2":
         monkeypatch.setenv("GPC_NO_W1", "1")
+        monkeypatch.setenv("GPC_W2", "1")
     return request.param
 
 
@@ -106,12 +110,13 @@ def test_dense_vs_oracle(gp, oracle, kernel_choice, P, n, ny, ragged, seed):
     f, _, st, al = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
     fo, _, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, want_alpha=True)
     n_max = int(np.max(np.diff(off)))
-    # (192 < n <= 256, depth plane, more than one patch: one wave per patch, eight patches per CU -- dense_mfma_w1; with GPC_NO_W1 the
-    # two-wave shape of the tiled kernel, four patches per CU)
-    w2 = 192 < n_max <= 256 and y.shape[0] == 1 and P > 1 and kernel_choice != "reg"
+    # depth plane, n <= 256, more than one patch: one wave per patch (dense_mfma_w1); "w2": the two-wave shape of the tiled kernel for
+    # 193 .. 256 points; otherwise the register-tile kernel
+    small1 = n_max <= 256 and y.shape[0] == 1 and P > 1
+    want_small = "dense_mfma_w1" if (small1 and kernel_choice == "dispatch") else \
+                 "dense_mfma_big_w2" if (small1 and n_max > 192 and kernel_choice == "w2") else "dense_mfma_nt"
     want_kernel = {"generic": "dense_generic", "big": "dense_mfma_big", "big_w4": "dense_mfma_big"}.get(
-        kernel_choice, ("dense_mfma_nt16 + " if P > 1 else "dense_mfma_big") if n_max > 256
-        else (("dense_mfma_big_w2" if kernel_choice == "w2" else "dense_mfma_w1") if w2 else "dense_mfma_nt"))
+        kernel_choice, ("dense_mfma_nt16 + " if P > 1 else "dense_mfma_big") if n_max > 256 else want_small)
     assert ctx.last_dense_kernel().startswith(want_kernel), ctx.last_dense_kernel()
     assert np.array_equal(st, so)
     _close(f, fo, FTOL)
@@ -206,6 +211,7 @@ def test_dense_one_wave_kernel_edge_cases(gp, oracle, monkeypatch, want_var):
     that is not SPD (duplicated point under zero noise: the failing pivot sits in the third tile column, the patches around it must
     not notice); mean-only and with the predictive variance (factor export + dense_variance_kernel)."""
     capi, ctx = gp
+    monkeypatch.setenv("GPC_W1_MIN_P", "2")           # (production: batches of at least four patches per CU)
     res, sz = 0.15, 12
     sizes = [256, 0, 1, 15, 16, 17, 31, 33, 48, 64, 65, 80, 100, 112, 128, 129, 150, 176, 192, 193, 200, 208, 224, 239, 240, 241, 255, 256, 0, 7]
     off, x0, x1, y = _mixed_batch(sizes, seed=5)
@@ -250,11 +256,12 @@ def test_dense_one_wave_kernel_edge_cases(gp, oracle, monkeypatch, want_var):
 
 
 @pytest.mark.parametrize("l_sq,shift,tol", [(0.05 ** 2, 0.0, 1e-8), (0.5 ** 2, 0.0, FTOL), (9.0, 0.4, FTOL), (9.0, 30.0, FTOL)])
-def test_dense_one_wave_kernel_exp_regimes(gp, oracle, l_sq, shift, tol):
+def test_dense_one_wave_kernel_exp_regimes(gp, oracle, monkeypatch, l_sq, shift, tol):
     """The exponential regimes of test_dense_mfma_exp_regimes on the one-wave kernel (patches of up to 256 points): table-driven
     Gram tiles and grid factors, polynomial Gram with table-driven grid, polynomial everywhere -- and the variance kernel's own
     small-argument test on the same patches."""
     capi, ctx = gp
+    monkeypatch.setenv("GPC_W1_MIN_P", "2")
     res, sz = 0.15, 20
     off, x0, x1, y = synth.make_patches(6, 256, seed=34, ragged=True, n_min=150)
     x0, x1 = x0 + shift, x1 - shift
@@ -270,6 +277,26 @@ def test_dense_one_wave_kernel_exp_regimes(gp, oracle, l_sq, shift, tol):
     _close(f1, fo, tol)
     _close(f2, fo, tol)
     assert np.max(np.abs(v2 - vo)) <= (1e-9 if tol > FTOL else 1e-10)
+
+
+def test_dense_batch_size_rule(gp, oracle, monkeypatch):
+    """Depth plane, n <= 256: batches of at least four patches per CU go to the one-wave-per-patch kernel, smaller ones to the
+    register-tile kernel (eight waves per patch: the better latency when the chip is not full); both agree with the oracle."""
+    capi, ctx = gp
+    for e in ("GPC_W1_MIN_P", "GPC_NO_W1", "GPC_W2", "GPC_FORCE_BIG", "GPC_FORCE_GENERIC"):
+        monkeypatch.delenv(e, raising=False)
+    res, sz = 0.15, 8
+    xs0, xs1 = oracle.grid(res, sz)
+    for P, n, want in ((1100, 96, "dense_mfma_w1"), (40, 96, "dense_mfma_nt8"), (1030, 20, "dense_mfma_w1")):
+        off, x0, x1, y = synth.make_patches(P, n, seed=P, ragged=True)
+        f, st = ctx.dense_fit_predict_grid(capi.default_params_dense(), off, x0, x1, y, res, sz)
+        assert ctx.last_dense_kernel() == want, ctx.last_dense_kernel()
+        pick = np.arange(0, P, max(1, P // 24))
+        sub = np.concatenate([[0], np.cumsum(np.diff(off)[pick])]).astype(np.int32)
+        idx = np.concatenate([np.arange(off[i], off[i + 1]) for i in pick])
+        fo, _, so = oracle.dense_fit_predict_batch(oracle.dense_params(), sub, x0[idx], x1[idx], y[:, idx], xs0, xs1)
+        assert np.all(st == 0)
+        _close(f[pick], fo, FTOL)
 
 
 def test_dense_big_kernel_edge_cases(gp, oracle, monkeypatch):
