@@ -343,12 +343,18 @@ def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s, ny=1):
     g.predict_dev(M, d_xs0, d_xs1, f)
     torch.cuda.synchronize()
     # B_add = 32 b^2 bytes per point (C and Q read once, written once), b interpolated linearly between the
-    # measured basis sizes at the chunk boundaries
+    # measured basis sizes at the chunk boundaries.  Round 3: a patch that arrives at an add call with >= 32 basis vectors runs that
+    # call on the LOWER TRIANGLES of C and Q (csrc/sparse.hip, sp_tri_pass; capacity > 100, Gaussian noise): 16 b^2 bytes per
+    # point + one mirror pass (16 b^2) when it leaves the kernel -- the bytes the path has to move, which is what `achieved` counts.
+    tri_on = cap > 100 and os.environ.get("GPC_SPARSE_FULL") is None
+    tri_min = int(os.environ.get("GPC_SPARSE_TRI_MIN", "32"))
     bytes_total = 0.0
     frac = (np.arange(cn) + 0.5) / cn
     for c in range(chunks):
         b = sizes[c][:, None] + (sizes[c + 1] - sizes[c])[:, None] * frac[None, :]
-        bytes_total += float(np.sum(32.0 * b * b))
+        tri = (sizes[c] >= tri_min) & tri_on
+        per_b2 = np.where(tri, 16.0, 32.0)[:, None]
+        bytes_total += float(np.sum(per_b2 * b * b)) + float(np.sum(np.where(tri, 16.0, 0.0) * sizes[c + 1] ** 2))
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(chunks)] for _ in range(steps)]
     t_tot = 0.0
     for k in range(steps):
@@ -376,12 +382,14 @@ def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s, ny=1):
            "config": {"workload": f"C4 {what} online ({regime}): {P} patches x {n} pts streamed in {chunks} add calls, capacity {cap}, "
                                   f"then predictive mean on the {SZ}x{SZ} grid" + hyp,
                       "patches_per_gpu": P, "points_per_patch": n, "capacity": cap, "channels": ny, "bv_mean": float(bv.mean()), "bv_max": int(bv.max()),
-                      "kernel": "sparse_add_kernel<true, false> (small-basis phase) + sparse_add_kernel<false, false> + sparse_predict_kernel",
+                      "kernel": "sparse_add_rows_kernel<16> (rows phase) + sparse_add_kernel<true, false> (small-basis phase) + "
+                                + ("sparse_add_kernel<false, false, true> (triangular passes from 32 basis vectors on)" if tri_on
+                                   else "sparse_add_kernel<false, false>") + " + sparse_predict_kernel",
                       "results_ok": ok},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                         "traffic": _traffic(f"sparse_add@C4_{regime}" + ("" if ny == 1 else "_ny3")), "kernel_ms": add_ms, "bytes_per_patch": bytes_total / P,
-                        "what": "the add calls of one pass (small-basis phase + regular kernel): sum over points of 32 b_t^2 bytes / "
-                                "their HIP-event time"
+                        "what": "the add calls of one pass (rows phase + small-basis phase + regular kernel): sum over points of 32 b_t^2 bytes "
+                                "(16 b_t^2 where the regular kernel works on the lower triangles of C and Q, + its mirror pass) / their HIP-event time"
                                 + ("" if regime == "fill" else "; with ~13 basis vectors the pass is latency-bound, not stream-bound")}}
     if budget_s > 0:
         O = _oracle()

@@ -251,21 +251,171 @@ __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int l
     }
 }
 
-// delete_bv(loc): sparse_gp.hpp:252-295 / sparse_gp_field.hpp:219-263.  b is workgroup-uniform; returns b-1.
-template <int RB>
-__device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_bug, double* Cstar, double* Qstar,
-                                   double* Crep, double* Qrep)
+// ---- TRIANGULAR passes (the four-wave regular kernel, capacity > 100: SpAddParams::tri) ----------------------------------------
+// C and Q are symmetric, and with a large basis the add path is bound by their stream: one read + one write of both per point
+// (32 b^2 bytes).  In this mode the kernel works on the LOWER triangles only -- element (i, j), i >= j, at [i + j ld]; the upper
+// triangle is ignored on entry and mirrored from the lower one when the patch leaves the kernel, so every other kernel still sees
+// full matrices -- 16 b^2 bytes per point.  The element updates are the ones of the full passes, applied to the lower elements
+// (same operations, same bits per element from the same inputs); what changes is that a mat-vec takes C_ji for C_ij above the
+// diagonal (the full matrices differ from their transposes by a rounding of the rank-one terms) and sums a row in a different
+// order: row part (j <= i, in the lane that owns row i) + column part (rows below the diagonal, summed over the lanes).  The
+// results are therefore NOT the bits of the full mode (GPC_SPARSE_FULL=1 keeps it: the bit-identity tests between kernel shapes
+// run there); they are gated like every other summation order by the parity statistics of tests/sparse_parity.py.
+#define SP_TB 8     // columns per block of a triangular pass (8 C + 8 Q column sums = one 16-value wave reduction)
+__device__ static __forceinline__ size_t sp_tri_at(int i, int j, int ld)
 {
+    return i >= j ? (size_t)i + (size_t)j * ld : (size_t)j + (size_t)i * ld;
+}
+// first column of wave q's share (of 4): equal areas of the lower triangle, 1 - sqrt(1 - q / 4), in multiples of SP_TB
+__device__ static __forceinline__ int sp_tri_bound(int nb, int q)
+{
+    if (q <= 0) return 0;
+    if (q >= 4) return nb;
+    const double f = q == 1 ? 0.1339746 : q == 2 ? 0.2928932 : 0.5;
+    const int c = ((int)(f * nb + 0.5 * SP_TB)) & ~(SP_TB - 1);
+    return c < nb ? c : nb;
+}
+// Sums the four components of x over the 16 lanes of a DPP row: after the xor-8 and half-mirror rounds a lane keeps ONE component,
+// sel = 2 (l >> 3 & 1) + (l >> 2 & 1), which the two quad rounds finish; lanes l & 15 = 0, 4, 8, 12 hold the totals of x0 .. x3.
+__device__ static __forceinline__ double sp_row_reduce4(double x0, double x1, double x2, double x3, int r)
+{
+    const bool hi8 = (r & 8) != 0, hi4 = (r & 4) != 0;
+    double k0 = hi8 ? x2 : x0, k1 = hi8 ? x3 : x1;
+    const double s0 = hi8 ? x0 : x2, s1 = hi8 ? x1 : x3;
+    k0 += sp_dpp<0x128>(s0);            // row_ror:8  (l <-> l ^ 8)
+    k1 += sp_dpp<0x128>(s1);
+    double k = hi4 ? k1 : k0;
+    const double sd = hi4 ? k0 : k1;
+    k += sp_dpp<0x141>(sd);             // row_half_mirror
+    k += sp_dpp<0xB1>(k);               // quad_perm [1,0,3,2]
+    k += sp_dpp<0x4E>(k);               // quad_perm [2,3,0,1]
+    return k;
+}
+// One pass over the lower triangles (256 threads).  Wave w owns the columns [bound(w), bound(w + 1)); a wave instruction covers
+// 16 rows x 4 columns -- lane l: row r = l & 15 of a 16-row group, column g = l >> 4 (and g + 4) of an SP_TB-column block -- so every
+// 16-lane segment is one aligned cache line of one column, the diagonal and the last row group waste at most 15 rows each (with 64
+// rows per instruction they wasted half of the lanes: 584 instruction slots per pass at b = 200 against 362 here, 314 ideal), and the
+// column sums of a block finish inside the DPP rows (no cross-row step).  Rows OUTSIDE, in quads of row groups, columns inside: the
+// row parts of a quad are four register pairs whatever the basis size (with the columns outside they were 2 x 16 accumulators across
+// an unrolled body: 110-145 spilled VGPRs), the column parts are reduced per (quad, block) and added up in LDS by the lane that owns
+// the column -- the same lane every time, in program order: deterministic.  All 8 + 8 loads of a trip come first.
+// MODE bits: 1 apply f(i, j, c, q) and store C | 2 store Q too | 4 mat-vecs with kv: row parts to prow [4][2][lv], column parts
+// to pcol [2][lv] | 8 Q is neither read nor written.
+template <int MODE, class F>
+__device__ static inline void sp_tri_pass(double* C, double* Q, int ld, int lv, int nb, const double* kv, double* prow, double* pcol, F f)
+{
+    constexpr bool UPD = (MODE & 1) != 0, WQ = (MODE & 2) != 0, MV = (MODE & 4) != 0, NOQ = (MODE & 8) != 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int jlo = sp_tri_bound(nb, w), jhi = sp_tri_bound(nb, w + 1);
+    if (MV) {
+        for (int j = jlo + lane; j < jhi; j += 64) pcol[j] = pcol[lv + j] = 0.0;
+    }
+    for (int Rq = 0; 16 * Rq < nb; Rq += 4) {
+        double rc[4] = {0.0, 0.0, 0.0, 0.0}, rq[4] = {0.0, 0.0, 0.0, 0.0};     // row parts: rows 16 (Rq + t) + r over this lane's columns
+        int ic[4];
+        double kiv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 16 * (Rq + t) + r;
+            ic[t] = i < nb ? i : nb - 1;
+            if (MV) kiv[t] = kv[ic[t]];
+        }
+        const int jend = jhi < 16 * (Rq + 4) ? jhi : 16 * (Rq + 4);
+        for (int j0 = jlo; j0 < jend; j0 += SP_TB) {
+            const int ja = j0 + g, jb = j0 + g + 4;
+            const bool oka = ja < jhi, okb = jb < jhi;
+            const int jac = oka ? ja : jhi - 1, jbc = okb ? jb : jhi - 1;      // clamped: the loads are unconditional
+            double ka = 0.0, kb = 0.0;
+            if (MV) {
+                ka = kv[jac];
+                kb = kv[jbc];
+            }
+            double c[8], q[8];
+            int at[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    const int jc = s_ ? jbc : jac;
+                    at[2 * t + s_] = (ic[t] < jc ? jc : ic[t]) + jc * ld;
+                    c[2 * t + s_] = C[at[2 * t + s_]];
+                    q[2 * t + s_] = NOQ ? 0.0 : Q[at[2 * t + s_]];
+                }
+            }
+            double cs0 = 0.0, cs1 = 0.0, cq0 = 0.0, cq1 = 0.0;                 // column parts of columns ja, jb: this lane's rows of the quad
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i = 16 * (Rq + t) + r;
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    const int e = 2 * t + s_, j = s_ ? jb : ja;
+                    if ((s_ ? okb : oka) && i >= j && i < nb) {
+                        if (UPD) {
+                            f(i, j, c[e], q[e]);
+                            C[at[e]] = c[e];
+                            if (WQ) Q[at[e]] = q[e];
+                        }
+                        if (MV) {
+                            const double kj = s_ ? kb : ka;
+                            rc[t] += c[e] * kj;
+                            rq[t] += q[e] * kj;
+                            if (i > j) {
+                                if (s_) { cs1 += c[e] * kiv[t]; cq1 += q[e] * kiv[t]; }
+                                else { cs0 += c[e] * kiv[t]; cq0 += q[e] * kiv[t]; }
+                            }
+                        }
+                    }
+                }
+            }
+            if (MV) {
+                const double tot = sp_row_reduce4(cs0, cs1, cq0, cq1, r);      // r = 0, 4, 8, 12: C of ja, C of jb, Q of ja, Q of jb
+                const int comp = r >> 2, j = (comp & 1) ? jb : ja;
+                if ((r & 3) == 0 && j < jhi) pcol[(comp >> 1) * lv + j] += tot;
+            }
+        }
+        if (MV) {
+            // a row's four column groups
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                double vc = rc[t], vq = rq[t];
+                vc += __shfl_xor(vc, 16, 64);
+                vq += __shfl_xor(vq, 16, 64);
+                vc += __shfl_xor(vc, 32, 64);
+                vq += __shfl_xor(vq, 32, 64);
+                const int i = 16 * (Rq + t) + r;
+                if (g == 0 && i < nb) {
+                    prow[(w * 2 + 0) * lv + i] = vc;
+                    prow[(w * 2 + 1) * lv + i] = vq;
+                }
+            }
+        }
+    }
+}
+
+// delete_bv(loc): sparse_gp.hpp:252-295 / sparse_gp_field.hpp:219-263.  b is workgroup-uniform; returns b-1.
+template <int RB, bool TRI = false>
+__device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_bug, double* Cstar, double* Qstar,
+                                   double* Crep, double* Qrep, bool tri_p = false)
+{
+    const bool tri = TRI && tri_p;      // (this patch runs in the triangular mode)
     const int tid = threadIdx.x, ld = S.ld, ldm = S.ldm, last = b - 1, ny = S.ny;
     double alphastar[3];
     for (int c = 0; c < ny; ++c) alphastar[c] = S.alpha[c * ld + loc];
     const double cstar = S.C[loc + (size_t)loc * ldm];
     const double qstar = S.Q[loc + (size_t)loc * ldm];
     for (int i = tid; i < b; i += SP_NTH) {
-        Cstar[i] = S.C[i + (size_t)loc * ldm];
-        Qstar[i] = S.Q[i + (size_t)loc * ldm];
-        Crep[i] = S.C[i + (size_t)last * ldm];
-        Qrep[i] = S.Q[i + (size_t)last * ldm];
+        if (tri) {                                   // columns of the symmetric matrices out of their lower triangles
+            const size_t al = sp_tri_at(i, loc, ldm), aa = sp_tri_at(last, i, ldm);
+            Cstar[i] = S.C[al];
+            Qstar[i] = S.Q[al];
+            Crep[i] = S.C[aa];
+            Qrep[i] = S.Q[aa];
+        } else {
+            Cstar[i] = S.C[i + (size_t)loc * ldm];
+            Qstar[i] = S.Q[i + (size_t)loc * ldm];
+            Crep[i] = S.C[i + (size_t)last * ldm];
+            Qrep[i] = S.Q[i + (size_t)last * ldm];
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -277,10 +427,16 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
     __syncthreads();
     for (int i = tid; i < b; i += SP_NTH) {
         const double cr = Crep[i], qr = Qrep[i];
-        S.C[loc + (size_t)i * ldm] = cr;   // C.row(loc) = Crep^T
-        S.C[i + (size_t)loc * ldm] = cr;   // C.col(loc) = Crep
-        S.Q[loc + (size_t)i * ldm] = qr;
-        S.Q[i + (size_t)loc * ldm] = qr;
+        if (tri) {
+            const size_t al = sp_tri_at(i, loc, ldm);
+            S.C[al] = cr;
+            S.Q[al] = qr;
+        } else {
+            S.C[loc + (size_t)i * ldm] = cr;   // C.row(loc) = Crep^T
+            S.C[i + (size_t)loc * ldm] = cr;   // C.col(loc) = Crep
+            S.Q[loc + (size_t)i * ldm] = qr;
+            S.Q[i + (size_t)loc * ldm] = qr;
+        }
     }
     if (tid < ny) S.alpha[tid * ld + loc] = S.alpha[tid * ld + last];     // alpha(loc) = alpha(last)  (:257)
     if (tid == 32) {
@@ -299,12 +455,14 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
         }
     }
     // C += Qs Qs^T / qstar - (Qs+Cs)(Qs+Cs)^T / (qstar+cstar);  Q -= Qs Qs^T / qstar   (:286-288)
-    sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, [&](int i, int j, double& c, double& q) {
+    auto downdate = [&](int i, int j, double& c, double& q) {
         const double qq = (Qstar[i] * Qstar[j]) / qstar;
         const double cc = ((Qstar[i] + Cstar[i]) * (Qstar[j] + Cstar[j])) / qc_den;
         c += qq - cc;
         q -= qq;
-    });
+    };
+    if (tri) sp_tri_pass<1 | 2>(S.C, S.Q, ldm, ld, nb, nullptr, nullptr, nullptr, downdate);
+    else sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, downdate);
     __syncthreads();
     return nb;
 }
@@ -318,12 +476,14 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
 // in the same order as the two-pass form, so the result is the same to the last bit; only the intermediate (b+1) x (b+1)
 // matrices never reach memory.  b == capacity on entry and on return.
 // When the coordinates of the NEXT point are known (nxt != nullptr) the pass also forms that point's mat-vecs (sp_rmw_cq_next).
-template <int RB>
+template <int RB, bool TRI = false>
 __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, double gamma, const double* qv, double px0, double px1,
                                             int field_bug, const double* ck, double* eh, double* sv, double* Cstar, double* Qstar,
                                             double* Crep, double* Qrep, double* anew, double* sval, int* sidx,
-                                            const double* nxt, double* kvn, double* pnext, double sf, double c_exp, const double* T)
+                                            const double* nxt, double* kvn, double* pnext, double sf, double c_exp, const double* T,
+                                            double* pnext_col = nullptr, bool tri_p = false)
 {
+    const bool tri = TRI && tri_p;
     const int tid = threadIdx.x, ld = S.ld, ldm = S.ldm, ny = S.ny, last = b;
     const double ig = (double)1.0f / gamma;
     for (int i = tid; i <= b; i += SP_NTH) {
@@ -354,7 +514,8 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
     // columns loc and last of the updated matrices (delete_bv :259-278)
     for (int i = tid; i <= b; i += SP_NTH) {
         const bool old = (i < b) && (loc < b);
-        const double c0 = old ? S.C[i + (size_t)loc * ldm] : 0.0, q0 = old ? S.Q[i + (size_t)loc * ldm] : 0.0;
+        const size_t al = tri ? sp_tri_at(old ? i : 0, old ? loc : 0, ldm) : (size_t)i + (size_t)loc * ldm;
+        const double c0 = old ? S.C[al] : 0.0, q0 = old ? S.Q[al] : 0.0;
         Cstar[i] = c0 + (rr * sv[i]) * sv[loc];
         Qstar[i] = q0 + (ig * eh[i]) * eh[loc];
         Crep[i] = 0.0 + (rr * sv[i]) * sv[b];
@@ -406,9 +567,11 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
         const double n0 = nxt[0], n1 = nxt[1];
         for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
         __syncthreads();
-        sp_rmw_cq_next<true, RB>(S.C, S.Q, ldm, ld, nb, kvn, pnext, element);
+        if (tri) sp_tri_pass<1 | 2 | 4>(S.C, S.Q, ldm, ld, nb, kvn, pnext, pnext_col, element);
+        else sp_rmw_cq_next<true, RB>(S.C, S.Q, ldm, ld, nb, kvn, pnext, element);
     } else {
-        sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, element);
+        if (tri) sp_tri_pass<1 | 2>(S.C, S.Q, ldm, ld, nb, nullptr, nullptr, nullptr, element);
+        else sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, element);
     }
     __syncthreads();
     return nb;
@@ -433,6 +596,7 @@ struct SpAddParams {
     int32_t* list;             // [P] patch ids (nullptr: static shares)
     int32_t* list_n;           // [0] entries in `list`, [1], [3] ticket counters of the small-basis and the regular launch
     int ticket_slot;           // which counter this launch draws from
+    int tri_min;               // triangular mode (sparse_add_kernel<false, ., true>): for patches that arrive with at least this many basis vectors
 };
 
 // Small-basis phase.  With the reference's default hyper-parameters the basis stays at a dozen vectors whatever the capacity,
@@ -444,7 +608,8 @@ struct SpAddParams {
 
 // PROBIT: the probit functor (sqrt, erf, exp: ~450 instructions and their constants) is compiled in only where it is used -- in the
 // Gaussian instantiation, the reference's production path, its registers go to the point loop
-template <bool SMALL, bool PROBIT = false>
+// TRI: the triangular mode of the four-wave shape (see sp_tri_pass)
+template <bool SMALL, bool PROBIT = false, bool TRI = false>
 __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse_add_kernel(SpAddParams A)   // <= 256 VGPRs (128 for the small-basis phase)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -472,6 +637,8 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
     double* BVL = alphaL + 3 * ld;                 // point, so they live here between the first and the last point of the call
     double* Cl = BVL + 2 * ld;                     // SMALL: C, Q [SP_BMAX][SP_BMAX]
     double* Ql = Cl + SP_BMAX * SP_BMAX;
+    double* part_col = BVL + 2 * ld;               // TRI: column parts of the mat-vecs [2][ld], this point's and the next one's
+    double* pnext_col = part_col + 2 * ld;
     gpc_exp_table_init(T);
 
     const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, eps_tol = A.prm.eps_tol;
@@ -503,6 +670,9 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
         S.BV = BVL;
         int b = A.b[patch];
         int st = A.stat[patch];
+        // the triangular passes pay from a mid-sized basis on (their per-block reductions and the uneven shares of the four waves cost
+        // more than half a stream of a small matrix saves): decided per patch and call from the basis it arrives with
+        [[maybe_unused]] const bool tri = TRI && b >= A.tri_min;
         const int it0 = A.start_it ? A.start_it[patch] : 0;     // an earlier phase (rows / small-basis) already took these
         __syncthreads();
         if (SMALL && (b > SP_BMAX || n == 0)) {          // too large from the start (or nothing to do): all of it is the regular kernel's
@@ -580,7 +750,10 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
 
             // C k and e_hat = Q k (:140,:160,:171): wave w covers columns j in its quarter, lanes cover rows
             const double* pp = from_prev ? pnext : part;
-            if (!from_prev && SMALL && b <= 32) {
+            [[maybe_unused]] const double* pc = from_prev ? pnext_col : part_col;
+            if (TRI && tri && !from_prev) {
+                sp_tri_pass<4>(S.C, S.Q, ldm, ld, b, kv, part, part_col, [](int, int, double&, double&) {});
+            } else if (!from_prev && SMALL && b <= 32) {
                 // one wave, small basis: the four quarters side by side (see sp_rmw_cq_next)
                 const int shift = b <= 16 ? 4 : 5;
                 const int i = lane & ((1 << shift) - 1), G = 64 >> shift;
@@ -616,8 +789,12 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
             double sums[4] = {0.0, 0.0, 0.0, 0.0};   // m[0..2] partial, (kCk, ke) handled in a second pass
             double dots[4] = {0.0, 0.0, 0.0, 0.0};
             for (int i = tid; i < b; i += SP_NTH) {
-                const double c_ = pp[0 * ld + i] + pp[2 * ld + i] + pp[4 * ld + i] + pp[6 * ld + i];
-                const double q_ = pp[1 * ld + i] + pp[3 * ld + i] + pp[5 * ld + i] + pp[7 * ld + i];
+                double c_ = pp[0 * ld + i] + pp[2 * ld + i] + pp[4 * ld + i] + pp[6 * ld + i];
+                double q_ = pp[1 * ld + i] + pp[3 * ld + i] + pp[5 * ld + i] + pp[7 * ld + i];
+                if (TRI && tri) {                            // + the column part: rows below the diagonal
+                    c_ += pc[i];
+                    q_ += pc[ld + i];
+                }
                 ck[i] = c_;
                 eh[i] = q_;
                 const double ki = kv[i];
@@ -657,8 +834,12 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     const double n0 = nx0, n1 = nx1;
                     for (int i = tid; i < b; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
-                    sp_rmw_cq_next<false, RB>(S.C, S.Q, ldm, ld, b, kvn, pnext, [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; });
+                    auto proj = [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; };
+                    if (TRI && tri) sp_tri_pass<1 | 4>(S.C, S.Q, ldm, ld, b, kvn, pnext, pnext_col, proj);
+                    else sp_rmw_cq_next<false, RB>(S.C, S.Q, ldm, ld, b, kvn, pnext, proj);
                     have_next = true;
+                } else if (TRI && tri) {
+                    sp_tri_pass<1 | 8>(S.C, S.Q, ldm, ld, b, nullptr, nullptr, nullptr, [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; });
                 } else {
                     const int nn = b * b;
                     for (int e0 = tid; e0 < nn; e0 += SP_NTH * RB) {     // loads first, see sp_rmw_cq
@@ -690,8 +871,8 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     nx[0] = nx0;
                     nx[1] = nx1;
                 }
-                b = sp_full_update_delete<RB>(S, b, rr, gamma, qv, px0, px1, A.prm.ref_field_delete_bug, ck, eh, sv, Cstar, Qstar, Crep,
-                                          Qrep, part + 4 * ld, sval, sidx, more ? nx : nullptr, kvn, pnext, sf, A.c_exp, T);
+                b = sp_full_update_delete<RB, TRI>(S, b, rr, gamma, qv, px0, px1, A.prm.ref_field_delete_bug, ck, eh, sv, Cstar, Qstar, Crep,
+                                               Qrep, part + 4 * ld, sval, sidx, more ? nx : nullptr, kvn, pnext, sf, A.c_exp, T, pnext_col, tri);
                 have_next = more;
                 dec = 1 | 2;
             } else {
@@ -723,10 +904,12 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     const double n0 = nx0, n1 = nx1;
                     for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
-                    sp_rmw_cq_next<true, RB>(S.C, S.Q, ldm, ld, nb, kvn, pnext, grow);
+                    if (TRI && tri) sp_tri_pass<1 | 2 | 4>(S.C, S.Q, ldm, ld, nb, kvn, pnext, pnext_col, grow);
+                    else sp_rmw_cq_next<true, RB>(S.C, S.Q, ldm, ld, nb, kvn, pnext, grow);
                     have_next = true;
                 } else {
-                    sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, grow);
+                    if (TRI && tri) sp_tri_pass<1 | 2>(S.C, S.Q, ldm, ld, nb, nullptr, nullptr, nullptr, grow);
+                    else sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, grow);
                 }
                 b = nb;
                 __syncthreads();
@@ -746,7 +929,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                 if (!have) best = __builtin_inf();
                 sp_block_argmin(best, loc, sval, sidx);
                 if (loc < 0 || loc >= b) loc = 0;          // all-NaN scores: the reference keeps minloc = 0
-                b = sp_delete_bv<RB>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
+                b = sp_delete_bv<RB, TRI>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep, tri);
                 have_next = false;
                 if (((dec >> 1) & 7) < 7) dec += 2;
             }
@@ -769,7 +952,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     if (loc < 0 || loc >= b) loc = 0;
                     minscore = best;
                     if (minscore < (double)1e-9f) {
-                        b = sp_delete_bv<RB>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep);
+                        b = sp_delete_bv<RB, TRI>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep, tri);
                         have_next = false;              // the matrices and the basis changed after the pass
                         if (((dec >> 4) & 7) < 7) dec += 16;
                     }
@@ -796,6 +979,22 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                 Qg[i + (size_t)j * ldg] = Ql[i + j * SP_BMAX];
             }
             if (tid == 0) A.done_it[patch] = it_end;
+        }
+        if (TRI && tri) {
+            // the upper triangles from the lower ones: every other kernel (and the full mode) reads full matrices.  16 x 16 tiles, one
+            // per 16 lanes and trip, read along their columns (once per call: 16 b^2 bytes against 16 b^2 per POINT)
+            const int nt_ = (b + 15) >> 4, sub = tid >> 4, r = tid & 15;
+            for (int tl = sub; tl < nt_ * nt_; tl += SP_NTH >> 4) {
+                const int ti = tl % nt_, tj = tl / nt_;
+                if (ti < tj) continue;
+                for (int c = 0; c < 16; ++c) {
+                    const int i = 16 * ti + r, j = 16 * tj + c;
+                    if (i < b && j < b && i > j) {
+                        Cg[j + (size_t)i * ldg] = Cg[i + (size_t)j * ldg];
+                        Qg[j + (size_t)i * ldg] = Qg[i + (size_t)j * ldg];
+                    }
+                }
+            }
         }
         if (tid == 0) {
             A.b[patch] = b;
@@ -1544,7 +1743,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_train_kernel(SpTrainParams 
 // ------------------------------------------------------------------------------------------------ host side
 
 static size_t sp_add_lds_small() { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (SP_BMAX + 2) + 22 * (SP_BMAX + 1) + 2 * SP_BMAX * SP_BMAX); }
-static size_t sp_add_lds(int ld) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (ld + 1) + 8 * ld + 9 * ld + 5 * ld); }
+static size_t sp_add_lds(int ld, bool tri = false) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (ld + 1) + 8 * ld + 9 * ld + 5 * ld + (tri ? 4 * ld : 0)); }
 static size_t sp_lik_lds(int ld, bool fast)
 {
     return sizeof(double) * (size_t)(64 + 5 * ld + SP_NQ * 8 * SP_PC + (size_t)ld * SP_PC * (fast ? 2 : 1));
@@ -1673,7 +1872,7 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     A.b = g->b; A.count = g->count; A.stat = g->stat; A.status_out = status;
     A.fuse_next = getenv("GPC_SPARSE_NO_FUSE") ? 0 : 1;
     A.trace = g->trace;
-    const size_t lds = sp_add_lds(g->ld);
+
     // capacity <= 64: one wave per patch (every row of the basis fits a lane; no cross-wave barriers, four times the patches
     // in flight); capacity <= 100 (the reference's default): two waves, twice the patches in flight; otherwise four waves per
     // patch.  While a thread owns at most one basis row the shapes give the same results, bit for bit (GPC_SPARSE_WIDE forces
@@ -1681,6 +1880,11 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     // with a full basis; at capacity 128 two waves lose (49 k vs 54 k).
     const int cap_ = g->prm.capacity;
     const int nth = (cap_ <= 0 || getenv("GPC_SPARSE_WIDE")) ? SP_THREADS : cap_ <= 64 ? 64 : cap_ <= 100 ? 128 : SP_THREADS;
+    // four waves per patch: the triangular mode (sp_tri_pass) -- half the stream of C and Q; GPC_SPARSE_FULL=1 keeps the full passes
+    const bool tri = nth == SP_THREADS && A.prm.noise_model == GPC_NOISE_GAUSSIAN && !getenv("GPC_SPARSE_FULL");
+    const size_t lds = sp_add_lds(g->ld, tri);
+    A.tri_min = 32;   // (measured at the C4 size: 32 -> 62.0 k patches/s, 96 -> 59.0 k, 160 -> 51.1 k; full passes 42.0 k; the defaults regime is level)
+    if (const char* e = getenv("GPC_SPARSE_TRI_MIN")) A.tri_min = atoi(e);      // (diagnostic: where the triangular passes start to pay)
     int per_cu = (int)((160u * 1024u) / lds);
     const int per_cu_max = 2 * SP_THREADS / nth;
     per_cu = per_cu > per_cu_max ? per_cu_max : (per_cu < 1 ? 1 : per_cu);
@@ -1728,6 +1932,7 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
         A.done_it = nullptr;
     }
     if (!gauss) hipLaunchKernelGGL((sparse_add_kernel<false, true>), dim3(grid), dim3(nth), lds, ctx->stream, A);
+    else if (tri) hipLaunchKernelGGL((sparse_add_kernel<false, false, true>), dim3(grid), dim3(nth), lds, ctx->stream, A);
     else hipLaunchKernelGGL((sparse_add_kernel<false, false>), dim3(grid), dim3(nth), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;

@@ -529,6 +529,7 @@ def test_sparse_one_wave_per_patch_is_bit_identical(gp, ny, cap, kernel, monkeyp
     """capacity <= 64: the add kernel runs one wave per patch (every basis row has its lane; no cross-wave barriers, four times
     as many patches in flight); capacity <= 100: two waves per patch.  The reductions and the quarter-wise mat-vec sums keep
     the layout of the four-wave shape (GPC_SPARSE_WIDE selects it): identical states, bit for bit, in every update regime."""
+    monkeypatch.setenv("GPC_SPARSE_FULL", "1")     # the kernel SHAPES are compared in the full mode (the triangular passes of the four-wave shape sum a row in another order)
     capi, ctx = gp
     res, P, n = 0.15, 37, 200
     off, x0, x1, y = synth.make_patches(P, n, res=res, seed=3 + cap, ragged=True, ny=ny)
@@ -569,6 +570,7 @@ def test_sparse_small_basis_phase_is_bit_identical(gp, ny, cap, kernel, monkeypa
     with and without the first phase (GPC_SPARSE_NO_SMALL) the states, the basis sizes, the per-patch status and the point
     counts are identical -- patches that stay small, patches that cross over in the middle of a call, online growth over
     several calls, empty patches, capacities below and above the block size."""
+    monkeypatch.setenv("GPC_SPARSE_FULL", "1")     # the kernel SHAPES are compared in the full mode (the triangular passes of the four-wave shape sum a row in another order)
     capi, ctx = gp
     res, P, n = 0.15, 29, 180
     off, x0, x1, y = synth.make_patches(P, n, res=res, seed=11 + cap, ragged=True, ny=ny)
@@ -620,6 +622,7 @@ def test_sparse_rows_phase_is_bit_identical(gp, ny, cap, kernel, P, n, monkeypat
     words, point counts and the per-point decision bytes are identical: patches that never leave the rows phase (the
     reference's default hyper-parameters), patches handed over in the middle of a call (basis > 16, a geometric deletion due,
     the capacity reached), online growth over two calls, ragged and empty patches, a patch count that is not a multiple of 4."""
+    monkeypatch.setenv("GPC_SPARSE_FULL", "1")     # the kernel SHAPES are compared in the full mode (the triangular passes of the four-wave shape sum a row in another order)
     capi, ctx = gp
     res = 0.15
     off, x0, x1, y = synth.make_patches(P, n, res=res, seed=23 + cap + P, ragged=True, ny=ny, n_min=1)
@@ -664,6 +667,82 @@ def test_sparse_rows_phase_is_bit_identical(gp, ny, cap, kernel, P, n, monkeypat
             assert np.array_equal(Q0[i][:nb, :nb], Q1[i][:nb, :nb], equal_nan=True), i
             assert np.array_equal(BV0[i][:nb], BV1[i][:nb], equal_nan=True), i
 
+
+@pytest.mark.parametrize("ny,cap,kernel", [(1, 200, "fill"), (3, 200, "mixed"), (1, 150, "mixed"), (1, 200, "geo"), (1, 255, "fill"), (1, 200, "default")])
+def test_sparse_triangular_mode(gp, oracle, ny, cap, kernel, monkeypatch):
+    """The four-wave regular kernel (capacity > 100) works on the LOWER triangles of C and Q -- half the stream of a point -- and
+    mirrors them when a patch leaves it (sp_tri_pass).  Against the full passes (GPC_SPARSE_FULL=1): the matrices that come back are
+    exactly symmetric; in regimes where the recursion is well conditioned the branch decisions, basis sizes and status words are
+    the same and the triangular mode is as close to the CPU oracle as the full mode is (both are summation orders of the same
+    recursion: the two modes differ by which of C_ij / C_ji a mat-vec reads and by the order a row is summed in -- bound written
+    before the first run: twice the full mode's distance from the oracle + 1e-12, and below 1e-6); in the ill-conditioned regimes (basis-filling kernel, the reference defaults) the modes are two summation
+    orders like any others and are held by the parity statistics (tests/sparse_parity.py, test_sparse_full_size_c4,
+    test_sparse_c4_defaults_full_size_parity), here only by a loose bound."""
+    capi, ctx = gp
+    res, P, n = 0.15, 20, (300 if cap in (255, -1) else 256)
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=31 + cap, ragged=True, ny=ny, n_min=(280 if cap in (255, -1) else None))
+    perm = synth.sattolo_perms(off, seed=5)
+    kw = dict(capacity=cap)
+    if kernel == "fill":
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 8) ** 2, noise=1e-4)
+    if kernel == "geo":            # geometric deletions on bases that reach the four-wave kernel (a shorter length scale than the other geo cases)
+        kw.update(sigmaf_sq=1.0, l_sq=(res * 0.6) ** 2, noise=1e-6, eps_tol=1e-14)
+    if kernel == "mixed":          # well conditioned: noise 1e-2 on a unit-amplitude kernel
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 6) ** 2, noise=1e-2 if ny == 1 else 1.0, eps_tol=1e-3)
+    p = capi.default_params_sparse(ny, **kw)
+    xs0, xs1 = synth.grid(res, 20)
+    out = []
+    # (the mode is chosen per patch and call from the basis it arrives with, >= 96 vectors by default: here every patch the four-wave
+    # kernel takes runs it)
+    monkeypatch.setenv("GPC_SPARSE_TRI_MIN", "0")
+    for full in (False, True):
+        if full:
+            monkeypatch.setenv("GPC_SPARSE_FULL", "1")
+        g = capi.Sparse(ctx, p, P, ny)
+        st1, tr1 = g.add(off, x0, x1, y, perm, trace=True)
+        st2, tr2 = g.add(off, x0, x1, y, trace=True)
+        f = g.predict(xs0, xs1)[0]
+        out.append((st1, st2, tr1, tr2, g.sizes(), f, *g.state()))
+        g.close()
+    t, u = out
+    nbs = t[4]
+    if kernel not in ("default", "geo"):
+        assert nbs.max() > 24                          # beyond the small-basis kernel: the four-wave shape took these patches
+    for i in range(P):
+        nb = int(nbs[i])
+        C, Q = t[7][i][:nb, :nb], t[8][i][:nb, :nb]
+        if nb > 24:                                    # (a smaller basis never left the rows / small-basis kernels, whose matrices are full)
+            assert np.array_equal(C, C.T, equal_nan=True) and np.array_equal(Q, Q.T, equal_nan=True), i
+    fin = np.isfinite(u[5])                            # (capacity -1: a patch that ran into GPC_MAX_BV predicts NaN in both modes)
+    assert np.array_equal(fin, np.isfinite(t[5]))
+    scale = max(1e-300, float(np.sqrt(np.mean(u[5][fin] ** 2))))
+    err = float(np.sqrt(np.mean((t[5][fin] - u[5][fin]) ** 2))) / scale
+    # both modes against the CPU oracle (same two calls, same insertion orders): the triangular mode must be as close to it as the full
+    # mode is -- 2 x + 1e-12 where the recursion is well conditioned (and below 1e-6 there), 3 x + 1e-9 elsewhere (in the geo regime,
+    # eps_tol = 1e-14 with |Q| up to 1e9, every summation order keeps a different basis and e_full itself is O(1))
+    okw = dict(p0=kw.get("sigmaf_sq", 100.0), p1=kw.get("l_sq", 1.0), capacity=cap)
+    if "noise" in kw:
+        okw["s20"] = kw["noise"]
+    if "eps_tol" in kw:
+        okw["eps_tol"] = kw["eps_tol"]
+    op = oracle.sparse_params(ny, **okw)
+    fo = np.zeros_like(t[5])
+    for i in range(P):
+        sl = slice(off[i], off[i + 1])
+        h = oracle.Sparse(op, (cap + 2) if cap > 0 else 2 * n + 2)
+        h.add_measurements(x0[sl], x1[sl], y[:, sl], perm[sl])
+        h.add_measurements(x0[sl], x1[sl], y[:, sl], None)
+        fo[i] = h.predict(xs0, xs1)[0]
+    fin &= np.isfinite(fo)
+    e_tri = float(np.sqrt(np.mean((t[5][fin] - fo[fin]) ** 2))) / scale
+    e_full = float(np.sqrt(np.mean((u[5][fin] - fo[fin]) ** 2))) / scale
+    print(f"triangular mode [{ny}-{cap}-{kernel}]: rms vs oracle tri {e_tri:.3e} full {e_full:.3e}; tri vs full {err:.3e}; bv max {nbs.max()}")
+    if kernel == "mixed" and cap > 0:
+        assert np.array_equal(t[0], u[0]) and np.array_equal(t[1], u[1]) and np.array_equal(t[4], u[4])
+        assert np.mean(t[2] != u[2]) < 2e-3 and np.mean(t[3] != u[3]) < 2e-3     # (a gamma within rounding of eps_tol may fall either way)
+        assert e_tri <= 2.0 * e_full + 1e-12 and e_tri < 1e-6, (e_tri, e_full, err)
+    else:
+        assert e_tri <= 3.0 * e_full + 1e-9, (e_tri, e_full, err)
 
 # ------------------------------------------------------------------ the tolerances, stated against the exact recursion
 
