@@ -266,12 +266,12 @@ __device__ static __forceinline__ size_t sp_tri_at(int i, int j, int ld)
 {
     return i >= j ? (size_t)i + (size_t)j * ld : (size_t)j + (size_t)i * ld;
 }
-// first column of wave q's share (of 4): equal areas of the lower triangle, 1 - sqrt(1 - q / 4), in multiples of SP_TB
-__device__ static __forceinline__ int sp_tri_bound(int nb, int q)
+// first column of wave q's share (of nw = 4, 2 or 1 waves): equal areas of the lower triangle, 1 - sqrt(1 - q / nw), in multiples of SP_TB
+__device__ static __forceinline__ int sp_tri_bound(int nb, int q, int nw)
 {
     if (q <= 0) return 0;
-    if (q >= 4) return nb;
-    const double f = q == 1 ? 0.1339746 : q == 2 ? 0.2928932 : 0.5;
+    if (q >= nw) return nb;
+    const double f = nw == 2 ? 0.2928932 : q == 1 ? 0.1339746 : q == 2 ? 0.2928932 : 0.5;
     const int c = ((int)(f * nb + 0.5 * SP_TB)) & ~(SP_TB - 1);
     return c < nb ? c : nb;
 }
@@ -291,7 +291,7 @@ __device__ static __forceinline__ double sp_row_reduce4(double x0, double x1, do
     k += sp_dpp<0x4E>(k);               // quad_perm [2,3,0,1]
     return k;
 }
-// One pass over the lower triangles (256 threads).  Wave w owns the columns [bound(w), bound(w + 1)); a wave instruction covers
+// One pass over the lower triangles (256 or 128 threads).  Wave w owns the columns [bound(w), bound(w + 1)); a wave instruction covers
 // 16 rows x 4 columns -- lane l: row r = l & 15 of a 16-row group, column g = l >> 4 (and g + 4) of an SP_TB-column block -- so every
 // 16-lane segment is one aligned cache line of one column, the diagonal and the last row group waste at most 15 rows each (with 64
 // rows per instruction they wasted half of the lanes: 584 instruction slots per pass at b = 200 against 362 here, 314 ideal), and the
@@ -306,9 +306,14 @@ __device__ static inline void sp_tri_pass(double* C, double* Q, int ld, int lv, 
 {
     constexpr bool UPD = (MODE & 1) != 0, WQ = (MODE & 2) != 0, MV = (MODE & 4) != 0, NOQ = (MODE & 8) != 0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-    const int jlo = sp_tri_bound(nb, w), jhi = sp_tri_bound(nb, w + 1);
+    const int nw = SP_NTH >> 6;
+    const int jlo = sp_tri_bound(nb, w, nw), jhi = sp_tri_bound(nb, w + 1, nw);
     if (MV) {
         for (int j = jlo + lane; j < jhi; j += 64) pcol[j] = pcol[lv + j] = 0.0;
+        if (nw < 4 && w == 0) {                        // two-wave shape: the row parts of the absent waves (the consumer adds four)
+            for (int w2 = nw; w2 < 4; ++w2)
+                for (int i = lane; i < nb; i += 64) prow[(w2 * 2 + 0) * lv + i] = prow[(w2 * 2 + 1) * lv + i] = 0.0;
+        }
     }
     for (int Rq = 0; 16 * Rq < nb; Rq += 4) {
         double rc[4] = {0.0, 0.0, 0.0, 0.0}, rq[4] = {0.0, 0.0, 0.0, 0.0};     // row parts: rows 16 (Rq + t) + r over this lane's columns
@@ -1885,8 +1890,8 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     // with a full basis; at capacity 128 two waves lose (49 k vs 54 k).
     const int cap_ = g->prm.capacity;
     const int nth = (cap_ <= 0 || getenv("GPC_SPARSE_WIDE")) ? SP_THREADS : cap_ <= 64 ? 64 : cap_ <= 100 ? 128 : SP_THREADS;
-    // four waves per patch: the triangular mode (sp_tri_pass) -- half the stream of C and Q; GPC_SPARSE_FULL=1 keeps the full passes
-    const bool tri = nth == SP_THREADS && A.prm.noise_model == GPC_NOISE_GAUSSIAN && !getenv("GPC_SPARSE_FULL");
+    // four or two waves per patch (capacity > 64): the triangular mode (sp_tri_pass) -- half the stream of C and Q; GPC_SPARSE_FULL=1 keeps the full passes
+    const bool tri = nth >= 128 && A.prm.noise_model == GPC_NOISE_GAUSSIAN && !getenv("GPC_SPARSE_FULL");
     const size_t lds = sp_add_lds(g->ld, tri);
     A.tri_min = 32;   // (measured at the C4 size: 32 -> 62.0 k patches/s, 96 -> 59.0 k, 160 -> 51.1 k; full passes 42.0 k; the defaults regime is level)
     if (const char* e = getenv("GPC_SPARSE_TRI_MIN")) A.tri_min = atoi(e);      // (diagnostic: where the triangular passes start to pay)

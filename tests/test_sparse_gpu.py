@@ -668,7 +668,8 @@ def test_sparse_rows_phase_is_bit_identical(gp, ny, cap, kernel, P, n, monkeypat
             assert np.array_equal(BV0[i][:nb], BV1[i][:nb], equal_nan=True), i
 
 
-@pytest.mark.parametrize("ny,cap,kernel", [(1, 200, "fill"), (3, 200, "mixed"), (1, 150, "mixed"), (1, 200, "geo"), (1, 255, "fill"), (1, 200, "default")])
+@pytest.mark.parametrize("ny,cap,kernel", [(1, 200, "fill"), (3, 200, "mixed"), (1, 150, "mixed"), (1, 200, "geo"), (1, 255, "fill"), (1, 200, "default"),
+                                           (1, 100, "fill"), (1, 80, "mixed")])     # (capacity <= 100: the two-wave shape; 80 < the 92 vectors the mixed kernel asks for)
 def test_sparse_triangular_mode(gp, oracle, ny, cap, kernel, monkeypatch):
     """The four-wave regular kernel (capacity > 100) works on the LOWER triangles of C and Q -- half the stream of a point -- and
     mirrors them when a patch leaves it (sp_tri_pass).  Against the full passes (GPC_SPARSE_FULL=1): the matrices that come back are
@@ -737,7 +738,7 @@ def test_sparse_triangular_mode(gp, oracle, ny, cap, kernel, monkeypatch):
     e_tri = float(np.sqrt(np.mean((t[5][fin] - fo[fin]) ** 2))) / scale
     e_full = float(np.sqrt(np.mean((u[5][fin] - fo[fin]) ** 2))) / scale
     print(f"triangular mode [{ny}-{cap}-{kernel}]: rms vs oracle tri {e_tri:.3e} full {e_full:.3e}; tri vs full {err:.3e}; bv max {nbs.max()}")
-    if kernel == "mixed" and cap > 0:
+    if kernel == "mixed" and nbs.max() < cap:          # (no capacity deletions: with them, near-ties of the scores choose different vectors)
         assert np.array_equal(t[0], u[0]) and np.array_equal(t[1], u[1]) and np.array_equal(t[4], u[4])
         assert np.mean(t[2] != u[2]) < 2e-3 and np.mean(t[3] != u[3]) < 2e-3     # (a gamma within rounding of eps_tol may fall either way)
         assert e_tri <= 2.0 * e_full + 1e-12 and e_tri < 1e-6, (e_tri, e_full, err)
