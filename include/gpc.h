@@ -229,7 +229,10 @@ int gpc_sparse_likelihood_dev(gpc_sparse* g, const int32_t* off, int n_total, co
 /* size() of every patch GP (src/sparse_gp.hpp:35-39) -- host pointer */
 int gpc_sparse_sizes(gpc_sparse* g, int32_t* bv_count);
 /* state read-back for tests (host pointers; each may be NULL): alpha [P][ny][cap1], C,Q [P][cap1][cap1] column-major,
- * BV [P][cap1][2], with cap1 = gpc_sparse_ld(g) */
+ * BV [P][cap1][2], with cap1 = gpc_sparse_ld(g).  C and Q are symmetric matrices stored in full; the add kernels may work on
+ * one triangle and mirror it (a state that went through them at capacity > 64 comes back exactly symmetric, a smaller one
+ * carries the rounding of its rank-one updates in both triangles): a state handed to gpc_sparse_set_state must be symmetric
+ * to rounding, as every state of the recursion is. */
 int gpc_sparse_get_state(gpc_sparse* g, double* alpha, double* C, double* Q, double* BV);
 int gpc_sparse_ld(const gpc_sparse* g);
 /* inverse of gpc_sparse_get_state, for loading a stored model (row f3; the reference's save_compressed writes nothing,
