@@ -262,12 +262,22 @@ static int dense_check(gpc_ctx* ctx, const gpc_params* prm, int P, const void* o
 __global__ void dense_classify_kernel(int P, const int32_t* off, int bound0, int bound1, int32_t* sel0, int32_t* sel1, int32_t* sel2,
                                       int32_t* counts)
 {
+    // one atomic per wave and class (a counter takes ~11 ns per atomic device-wide: with one per patch the 8192 patches of a
+    // single-class batch spent 95 us here, 0.8 % of a C3 launch and 5 % of a C2-sized one)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const int n = off[i + 1] - off[i];
-    if (n <= bound0) sel0[atomicAdd(&counts[0], 1)] = i;
-    else if (n <= bound1) sel1[atomicAdd(&counts[1], 1)] = i;
-    else sel2[atomicAdd(&counts[2], 1)] = i;
+    const int lane = threadIdx.x & 63;
+    const int n = i < P ? off[i + 1] - off[i] : 0;
+    const int cls = i >= P ? -1 : n <= bound0 ? 0 : n <= bound1 ? 1 : 2;
+    int32_t* const sel[3] = {sel0, sel1, sel2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(&counts[c], __builtin_popcountll(m));
+        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(m));
+        if (cls == c) sel[c][base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+    }
 }
 
 // the context's two auxiliary streams and its events (also used by the host-pointer pipeline), created on first use
