@@ -332,7 +332,10 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
         }
         if (a.n_max <= 256 || (no_split && dense_mfma_supported(a) && !getenv("GPC_NO_NT17")))
             return dense_mfma_launch(ctx, a);                                                               // one shape for the whole batch
-        if (!a.v_star && a.n_max <= GPC_MAX_POINTS && !no_split) {
+        // (a batch whose patches all have n_max points -- P n_max == n_total: every n_i <= n_max and they add up to n_total -- has one
+        // size class and the host knows it: no classification, no empty class launches waiting for a CU beside the tiled kernel)
+        const bool uniform = (long long)a.P * a.n_max == (long long)a.n_total && !getenv("GPC_NO_UNIFORM");
+        if (!a.v_star && a.n_max <= GPC_MAX_POINTS && !no_split && !(uniform && a.n_max > 17 * 16)) {
             const bool nt17 = a.ny == 1 && !getenv("GPC_NO_NT17");
             const bool need_big = !(nt17 && a.n_max <= 17 * 16);
             int grid_b = 0;
