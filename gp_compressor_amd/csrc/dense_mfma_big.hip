@@ -44,6 +44,9 @@ struct BigParams {
     size_t slot;   // doubles per workgroup slot
     int ntw;       // tile columns of a slot = ceil(n_max / 16)
     unsigned long long* stamps;   // diagnostic (GPC_BIG_STAMPS=1): [phase][wave] cycle sums over all patches, else nullptr
+    int32_t* ticket;              // patches beyond a workgroup's first one are taken from this counter (nullptr: blockIdx.x + k gridDim.x).  The
+                                  // Newton loop takes 5 .. 11 solves per patch: with 16 patches per workgroup dealt in advance the slowest
+                                  // workgroup of a C5 launch carried 11 % more solves than the average
     int export_factor;            // predictive variance (dense_variance.hip): the factor of EVERY patch stays in the workspace (slot =
                                   // patch, not workgroup) together with the L_kk^-1 images
     // IRLS instantiation only (BASELINE config 5, gpc_dense_irls_fit_predict): the Newton loop around the factorisation
@@ -194,7 +197,17 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
     gpc_exp_table_init(T);
 
     const int n_patches = A.sel ? __builtin_amdgcn_readfirstlane(A.sel_count[0]) : A.P;   // size-class dispatch: sel[0 .. count)
-    for (int pk = blockIdx.x; pk < n_patches; pk += gridDim.x) {
+    int* const s_next_patch = flag + 30;      // (a free word of the flag block: static LDS on top of the 160 KB dynamic carve does not launch)
+    auto next_patch = [&](int pk) {
+        // (the Newton-loop instantiations only: in the others every patch of a class costs the same within a factor the static deal
+        // averages out, and the two live values of the dynamic form spill in the 512-point shape)
+        if (!BG_IRLS || !g.ticket) return pk + (int)gridDim.x;
+        __syncthreads();
+        if (tid == 0) *s_next_patch = (int)gridDim.x + atomicAdd(g.ticket, 1);
+        __syncthreads();
+        return __builtin_amdgcn_readfirstlane(*s_next_patch);
+    };
+    for (int pk = blockIdx.x; pk < n_patches; pk = next_patch(pk)) {
         const int patch = A.sel ? __builtin_amdgcn_readfirstlane(A.sel[pk]) : pk;
         if (g.export_factor) {
             Lt = g.ws + (size_t)patch * g.slot;
@@ -1021,6 +1034,9 @@ int dense_irls_launch(gpc_ctx* ctx, const DenseArgs& a, const IrlsArgs& ir, int 
     g.irls_f_init = ir.f_init;
     g.irls_iters = ir.iters;
     g.irls_fhat = ir.fhat;
+    if (!ctx->tickets) GPC_HIP(ctx, hipMalloc(&ctx->tickets, 64 * sizeof(int32_t)));
+    GPC_HIP(ctx, hipMemsetAsync(ctx->tickets, 0, sizeof(int32_t), ctx->stream));
+    g.ticket = getenv("GPC_BIG_STATIC") ? nullptr : ctx->tickets;
     int waves, npad, per_cu;
     big_shape(a, true, &waves, &npad, &per_cu);
     if (waves == 4) {
@@ -1056,6 +1072,7 @@ int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
     big_shape(a, false, &waves, &npad, &per_cu);
     g.stamps = nullptr;
     g.irls_model = 0; g.irls_max_iter = 0; g.irls_tol = 0.0; g.irls_f_init = 0.0; g.irls_iters = nullptr; g.irls_fhat = nullptr;
+    g.ticket = nullptr;
     struct StampDump {
         gpc_ctx* ctx; unsigned long long* d; int P, waves;
         ~StampDump()

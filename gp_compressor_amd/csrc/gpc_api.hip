@@ -182,6 +182,8 @@ void gpc_ctx_destroy(gpc_ctx* ctx)
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->ws) (void)hipFree(ctx->ws);
         ctx->ws = nullptr;
+        if (ctx->tickets) (void)hipFree(ctx->tickets);
+        ctx->tickets = nullptr;
         ctx->ws_bytes = 0;
         if (ctx->s_in) {
             (void)hipStreamSynchronize(ctx->s_in);

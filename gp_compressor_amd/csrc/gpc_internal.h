@@ -28,6 +28,7 @@ struct gpc_ctx {
     // grow-only device workspace (K / L factors of the generic dense kernel, variance scratch, grid tables)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    int32_t* tickets = nullptr;        // 64 counters (allocated on first use): patches handed out one at a time where their cost varies (dense_mfma_big.hip)
     // host-pointer entries (gpc_api.hip, dense_host): a grow-only device arena for the batch, pinned staging buffers for
     // pageable caller memory, and two copy streams so that the upload of chunk c+1 and the download of chunk c-1 run on the
     // SDMA engines while the kernel works on chunk c
