@@ -56,6 +56,13 @@ struct BigParams {
     int32_t* irls_iters;          // [P] solves performed, or nullptr
     double* irls_fhat;            // [n_total] latent mode at the training points, or nullptr
 };
+// BG_HINT bit 1: the backward solve reads the factor once -- its loads carry the non-temporal hint, so that they do not push the block rows
+// a step reads several times out of L2 (the one-wave kernel: 1.738 -> 1.680 ms with the same hint, dense_mfma_w1.hip)
+// (C3 11.91 -> 11.78 ms, C5 299 -> 298 ms same box)
+#ifndef BG_HINT
+#define BG_HINT 1
+#endif
+#define BG_LOAD_BACK(p, l) ((BG_HINT & 1) ? mf_img_load_nt(p, l) : mf_img_load(p, l))
 #define BG_NPH 12
 // Diagnostic builds only (tools/r3_exp.sh; results are wrong by construction, timings tell what a phase costs under real overlap):
 //   -DBG_EXP_HOT     every j-indexed operand load reads tile column 0 (L1 hits): what the factor stream costs
@@ -750,15 +757,15 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
             d4 cur[BT], nxt[BT], lt_cur = d4{0.0, 0.0, 0.0, 0.0}, lt_nxt = lt_cur;
 #pragma unroll
             for (int t = 0; t < BT; ++t) cur[t] = nxt[t] = d4{0.0, 0.0, 0.0, 0.0};
-            if (wave == 0) lt_cur = mf_img_load(LinvTg + (size_t)(nt - 1) * MF_IMG, lane);
+            if (wave == 0) lt_cur = BG_LOAD_BACK(LinvTg + (size_t)(nt - 1) * MF_IMG, lane);
             for (int k = nt - 1; k >= 0; --k) {
                 if (k > 0) {
 #pragma unroll
                     for (int t = 0; t < BT; ++t) {
                         const int i = k + wave + BG_WAVES * t;               // rows of column k-1: i >= k
-                        if (i < nt) nxt[t] = mf_img_load(Lt + ((size_t)i * ntw + (k - 1)) * MF_IMG, lane);
+                        if (i < nt) nxt[t] = BG_LOAD_BACK(Lt + ((size_t)i * ntw + (k - 1)) * MF_IMG, lane);
                     }
-                    if (wave == 0) lt_nxt = mf_img_load(LinvTg + (size_t)(k - 1) * MF_IMG, lane);
+                    if (wave == 0) lt_nxt = BG_LOAD_BACK(LinvTg + (size_t)(k - 1) * MF_IMG, lane);
                 }
                 d4 pa[3];
 #pragma unroll

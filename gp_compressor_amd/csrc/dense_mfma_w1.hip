@@ -43,6 +43,21 @@ __device__ static __forceinline__ int w1_exp_zero() { int z; asm volatile("s_mov
 #define W1_JX(j) (j)
 #endif
 
+// Non-temporal hints on the streams that are used once (-DW1_HINT=mask: 1 the backward solve's loads, 2 the row operands of the passes,
+// 4 the stores of the factor tiles), so that the block rows a step reads three times (sweep, column operands of two passes) have a better
+// chance to stay in L2.  Measured on one box, C2: none 1.738 ms, backward loads 1.680 (-3.4 %), row operands 1.755 (they ARE read again,
+// one step later), stores 1.742, all three 1.727: the backward solve's loads carry the hint.
+#ifndef W1_HINT
+#define W1_HINT 1
+#endif
+#define W1_LOAD_BACK(p, l) ((W1_HINT & 1) ? mf_img_load_nt(p, l) : mf_img_load(p, l))
+#define W1_LOAD_ROWOP(p, l) ((W1_HINT & 2) ? mf_img_load_nt(p, l) : mf_img_load(p, l))
+#define W1_STORE_TILE(p, l, v)                                                                                        \
+    do {                                                                                                             \
+        if (W1_HINT & 4) mf_img_store_nt(p, l, v);                                                                     \
+        else mf_img_store(p, l, v);                                                                                  \
+    } while (0)
+
 struct W1Params {
     DenseArgs a;
     double c_exp;
@@ -315,7 +330,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                         const d4 lvc = mf_img_load(LinvC + c * MF_IMG, mf_opaque(lane));
                         const d4 L = w1_trsm(lvc, Tt);                     // operand image of L_(k+i)(k+c)
                         Lb[i * (i - 1) / 2 + c] = L;
-                        mf_img_store(Lt + W1_TILE(k + i, k + c), lane, L);
+                        W1_STORE_TILE(Lt + W1_TILE(k + i, k + c), lane, L);
                     }
                     d4 Dii = tacc[i * (i + 1) / 2 + i];
 #pragma unroll
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
 #pragma unroll
                             for (int c2 = 0; c2 < c; ++c2) a4[c][t] = w1_mfma4_neg(Lb[c * (c - 1) / 2 + c2], a4[c2][t], a4[c][t]);
                             a4[c][t] = w1_trsm(lv, a4[c][t]);
-                            if (t < np4) mf_img_store(Lt + W1_TILE(W1_C + first_row0 + t, c), lane, a4[c][t]);
+                            if (t < np4) W1_STORE_TILE(Lt + W1_TILE(W1_C + first_row0 + t, c), lane, a4[c][t]);
                         }
                     }
                     W1_STAMP(7);
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
 #pragma unroll
                 for (int c = 0; c < W1_C; ++c) A2[0][c] = mf_img_load(rrow[c], lane);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) B[t] = mf_img_load(rw_[t], lane);
+                for (int t = 0; t < 4; ++t) B[t] = W1_LOAD_ROWOP(rw_[t], lane);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     d4 gv[W1_C];
@@ -446,7 +461,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                              \
             _Pragma("unroll") for (int c = 0; c < W1_C; ++c) acc[c][t] = w1_mfma4_neg(A2[st][c], B[t], acc[c][t]);    \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
-            if (PREFETCH) B[t] = mf_img_load(rw_[t] + (size_t)W1_JX(jn) * MF_IMG, lane);                             \
+            if (PREFETCH) B[t] = W1_LOAD_ROWOP(rw_[t] + (size_t)W1_JX(jn) * MF_IMG, lane);                           \
             else {     /* the last j: the block's lower tiles for the TRSMs take the place of the operands that are done */ \
                 if (t < 3) Lq[t] = mf_img_load(Lt + W1_TILE(k + (t == 0 ? 1 : 2), k + (t == 2 ? 1 : 0)), lane);      \
                 else {                                                                                               \
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                         for (int c2 = 0; c2 < c; ++c2) acc[c][t] = w1_mfma4_neg(Lq[c * (c - 1) / 2 + c2], acc[c2][t], acc[c][t]);
                         acc[c][t] = w1_trsm(lv, acc[c][t]);
 #endif
-                        if (t < np4) mf_img_store(Lt + W1_TILE(rr[t], k + c), lane, acc[c][t]);
+                        if (t < np4) W1_STORE_TILE(Lt + W1_TILE(rr[t], k + c), lane, acc[c][t]);
                     }
                 }
                 W1_STAMP(7);
@@ -518,7 +533,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             };
             w1_static_for<0, W1_BW>([&](auto P) __attribute__((always_inline)) {
                 constexpr int q = decltype(P)::value;
-                win[q % W1_BW] = mf_img_load(stream_addr(P), lane);
+                win[q % W1_BW] = W1_LOAD_BACK(stream_addr(P), lane);
             });
             d4 pa = d4{0.0, 0.0, 0.0, 0.0};
             w1_static_for<0, SLEN>([&](auto P) __attribute__((always_inline)) {
@@ -556,7 +571,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     }
                 }
                 if constexpr (q + W1_BW < SLEN) {
-                    win[q % W1_BW] = mf_img_load(stream_addr(std::integral_constant<int, q + W1_BW>{}), lane);
+                    win[q % W1_BW] = W1_LOAD_BACK(stream_addr(std::integral_constant<int, q + W1_BW>{}), lane);
                 }
             });
         }

@@ -100,6 +100,19 @@ __device__ static __forceinline__ void mf_img_store(double* img, int l, d4 v)
     *reinterpret_cast<d2*>(img + 128 + l * 2) = d2{v[2], v[3]};
 }
 
+// ... with the non-temporal hint (a stream that is read or written once should not push re-used lines out of L2)
+__device__ static __forceinline__ d4 mf_img_load_nt(const double* img, int l)
+{
+    const d2 a = __builtin_nontemporal_load(reinterpret_cast<const d2*>(img + l * 2));
+    const d2 b = __builtin_nontemporal_load(reinterpret_cast<const d2*>(img + 128 + l * 2));
+    return d4{a[0], a[1], b[0], b[1]};
+}
+__device__ static __forceinline__ void mf_img_store_nt(double* img, int l, d4 v)
+{
+    __builtin_nontemporal_store(d2{v[0], v[1]}, reinterpret_cast<d2*>(img + l * 2));
+    __builtin_nontemporal_store(d2{v[2], v[3]}, reinterpret_cast<d2*>(img + 128 + l * 2));
+}
+
 // Inverse Cholesky factor of a 16 x 16 SPD tile, on the MFMA pipe.  `W` holds the tile in C/D register layout
 // (lane l, register r: A[(l>>4) + 4 r][l & 15]; the diagonal tile is symmetric, so the workers' transposed storage is
 // the same thing).  Square-root-free Gauss-Jordan elimination IN PLACE: pivot c is ONE rank-1 v_mfma_f64_16x16x4
