@@ -293,9 +293,10 @@ __device__ static __forceinline__ double sp_row_reduce4(double x0, double x1, do
 }
 // One pass over the lower triangles (256 or 128 threads).  Wave w owns the columns [bound(w), bound(w + 1)); a wave instruction covers
 // 16 rows x 4 columns -- lane l: row r = l & 15 of a 16-row group, column g = l >> 4 (and g + 4) of an SP_TB-column block -- so every
-// 16-lane segment is one aligned cache line of one column, the diagonal and the last row group waste at most 15 rows each (with 64
-// rows per instruction they wasted half of the lanes: 584 instruction slots per pass at b = 200 against 362 here, 314 ideal), and the
-// column sums of a block finish inside the DPP rows (no cross-row step).  Rows OUTSIDE, in quads of row groups, columns inside: the
+// 16-lane segment is one aligned cache line of one column, and the column sums of a block finish inside the DPP rows (no cross-row
+// step: 45 instructions per block against 130 for the 16-value wave reduction of the first form, 64 rows x 1 column per instruction).
+// A quad's row groups above the diagonal or beyond the basis are issued masked (584 instruction slots per pass at b = 200 for 314
+// slots' worth of elements; skipping them behind wave-uniform guards was measured and not kept: the guards end the batch of loads).  Rows OUTSIDE, in quads of row groups, columns inside: the
 // row parts of a quad are four register pairs whatever the basis size (with the columns outside they were 2 x 16 accumulators across
 // an unrolled body: 110-145 spilled VGPRs), the column parts are reduced per (quad, block) and added up in LDS by the lane that owns
 // the column -- the same lane every time, in program order: deterministic.  All 8 + 8 loads of a trip come first.
