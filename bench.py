@@ -70,13 +70,22 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("GPC_CPU_THREADS", "16"))))
 
 
-def _traffic(key):
+def _traffic(key, field="hbm_bytes_per_launch"):
     """HBM bytes per launch from the PMC passes (profiles/traffic.json, collected and corrected as the microarch guide
-    prescribes; tools/collect_profiles.py) or None"""
+    prescribes; tools/collect_profiles_r04.py) or None.  Other fields of the same record: the rocprofv3 kernel time of the
+    timed launches, the counted wave-instructions of a pass."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get("hbm_bytes_per_launch")
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get(field)
     except Exception:
         return None
+
+
+def _kstats(ms):
+    """median / mean / min / max of per-step kernel times (HIP events on the launch stream)"""
+    a = np.asarray(ms, dtype=np.float64)
+    if a.size == 0:
+        return {"median": float("nan"), "mean": float("nan"), "min": float("nan"), "max": float("nan"), "steps": 0}
+    return {"median": float(np.median(a)), "mean": float(np.mean(a)), "min": float(np.min(a)), "max": float(np.max(a)), "steps": int(a.size)}
 
 
 def _oracle():
@@ -205,7 +214,8 @@ def bench_dense(env, P, n, steps, warmup, seed=2):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    kt = _kstats([a.elapsed_time(b) for a, b in events])
+    kern_ms = kt["median"]                       # the roofline uses the MEDIAN of the per-step HIP-event times; mean / min / max beside it
     last = (steps - 1) & 1 if use_dist and steps > 0 else 0
     st = status.cpu().numpy()
     f_host = f_bufs[last].cpu().numpy()
@@ -224,7 +234,7 @@ def bench_dense(env, P, n, steps, warmup, seed=2):
             if hasattr(g_, "close"):
                 g_.close()
     del d_off, d_x0, d_x1, d_y, f_bufs, gathers
-    return {"value": world * P * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kern_ms": kern_ms, "ok": ok,
+    return {"value": world * P * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "kern_ms": kern_ms, "kern_stats": kt, "ok": ok,
             "kernel": kernel, "achieved": achieved, "exchange": exchange, "host": (off, x0, x1, y, f_host) if not use_dist else None}
 
 
@@ -241,7 +251,11 @@ def dense_record(name, r, P, n, world, steps, warmup):
                        "results_ok": r["ok"], **({"exchange": r["exchange"]} if r.get("exchange") else {})},
             "roofline": {"bound": "mfma", "achieved": r["achieved"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": r["achieved"] / FP64_PEAK_TFLOPS, "traffic": _traffic(tkey), "kernel_ms": r["kern_ms"],
-                         "flops_per_patch": algorithmic_flops(n, M)}}
+                         "kernel_ms_stats": r["kern_stats"], "kernel_ms_rocprof": _traffic(tkey, "kernel_ms_timed_rocprof"),
+                         "flops_per_patch": algorithmic_flops(n, M),
+                         "what": "F(n, m) x patches / MEDIAN of the per-step HIP-event times of the launch (kernel_ms_stats: mean, min, max, "
+                                 "steps); kernel_ms_rocprof: the timed median of the same command under rocprofv3 --kernel-trace "
+                                 "(profiles/, collected by tools/profile_r04.sh)"}}
 
 
 def bench_dense_variance(env, P, n, steps, budget_s):
@@ -273,7 +287,8 @@ def bench_dense_variance(env, P, n, steps, budget_s):
         step(ev[k])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kt = _kstats([a.elapsed_time(b) for a, b in ev])
+    kern_ms = kt["median"]
     v_host, st = d_v.cpu().numpy(), d_st.cpu().numpy()
     ok = bool(np.all(st == 0)) and bool(np.all(np.isfinite(v_host))) and bool(np.all(v_host > -1e-12))
     fl = algorithmic_flops(n, M) + float(n) * n * M + 2.0 * n * M
@@ -284,7 +299,7 @@ def bench_dense_variance(env, P, n, steps, budget_s):
                                   f"(V* = k** - |L^-1 k*|^2, what gaussian_process::predict_measurements computes)",
                       "patches_per_gpu": P, "points_per_patch": n, "grid_points": M, "kernel": ctx.last_dense_kernel(), "results_ok": ok},
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                        "traffic": _traffic("dense_variance@C2"), "kernel_ms": kern_ms, "flops_per_patch": fl,
+                        "traffic": _traffic("dense_variance@C2"), "kernel_ms": kern_ms, "kernel_ms_stats": kt, "flops_per_patch": fl,
                         "what": "F(n, m) + n^2 m + 2 n m flops per patch / HIP-event time of fit + variance kernels"}}
     if budget_s > 0:
         O = _oracle()
@@ -308,12 +323,67 @@ def bench_dense_variance(env, P, n, steps, budget_s):
 
 # ------------------------------------------------------------------------------------------------ C4: sparse online GP
 
-def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s, ny=1):
+ISSUE_PEAK_GINST = 256 * 4 * 2.4     # wave-instructions / ns the part can issue: one per SIMD and cycle, 1024 SIMDs, 2.4 GHz
+
+
+def sparse_add_bytes(sizes, cn, cap):
+    """Algorithmic bytes of the add calls of one pass.  B_add = 32 b^2 bytes per point (C and Q read once, written once),
+    b interpolated linearly between the measured basis sizes at the chunk boundaries (`sizes`: chunks + 1 arrays over the patches).
+    A patch that arrives at an add call with >= 32 basis vectors runs that call on the LOWER TRIANGLES of C and Q (csrc/sparse.hip,
+    sp_tri_pass: the regular kernel's two- and four-wave shapes, i.e. capacity > 64, Gaussian noise, GPC_SPARSE_FULL unset):
+    16 b^2 bytes per point + one mirror pass (16 b^2) when it leaves the kernel -- the bytes the path has to move."""
+    tri_on = cap > 64 and os.environ.get("GPC_SPARSE_FULL") is None
+    tri_min = int(os.environ.get("GPC_SPARSE_TRI_MIN", "32"))
+    total = 0.0
+    frac = (np.arange(cn) + 0.5) / cn
+    for c in range(len(sizes) - 1):
+        b = sizes[c][:, None] + (sizes[c + 1] - sizes[c])[:, None] * frac[None, :]
+        tri = (sizes[c] >= tri_min) & tri_on
+        per_b2 = np.where(tri, 16.0, 32.0)[:, None]
+        total += float(np.sum(per_b2 * b * b)) + float(np.sum(np.where(tri, 16.0, 0.0) * sizes[c + 1] ** 2))
+    return total, tri_on
+
+
+def sparse_add_roofline(regime, ny, bytes_total, add_stats, P, point_updates):
+    """The roofline object of a sparse record's add calls.
+    fill: the basis reaches the capacity and the pass streams C and Q -- bound = HBM, achieved = algorithmic bytes / time.
+    defaults (the reference's hyper-parameters: ~13 basis vectors, the blocks live in LDS): the pass moves ~1 GB and is bound by
+    INSTRUCTION ISSUE -- achieved = wave-instructions the add kernels issue per pass (SQ_INSTS_* of the PMC passes,
+    profiles/traffic.json, scaled by this record's point updates) / time, peak = one instruction per SIMD and cycle.  The byte
+    figure stays beside it as `hbm_algorithmic_GBps`: Sigma 32 b^2 over blocks that never leave LDS is NOT what the kernels move."""
+    add_ms = add_stats["median"]
+    tkey = f"sparse_add@C4_{regime}" + ("" if ny == 1 else "_ny3")
+    gbps = bytes_total / (add_ms * 1e-3) / 1e9
+    if regime == "fill":
+        return {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                "traffic": _traffic(tkey), "kernel_ms": add_ms, "kernel_ms_stats": add_stats, "bytes_per_patch": bytes_total / P,
+                "what": "the add calls of one pass (rows phase + small-basis phase + regular kernel): sum over points of 32 b_t^2 bytes "
+                        "(16 b_t^2 where the regular kernel works on the lower triangles of C and Q, + its mirror pass) / MEDIAN of their "
+                        "HIP-event times over the timed passes"}
+    per_pt = _traffic(tkey, "wave_insts_per_point_update")
+    src = "profiles/traffic.json (SQ_INSTS_VALU + SALU + LDS + SMEM + VMEM of the add kernels, PMC passes)"
+    if per_pt is None:
+        per_pt, src = 650.0 / 4.0, "model: ~650 wave-instructions per wave-point for four patches (DESIGN 5.4a); no PMC pass on file"
+    ginst = per_pt * point_updates / (add_ms * 1e-3) / 1e9
+    return {"bound": "issue", "achieved": ginst, "peak": ISSUE_PEAK_GINST, "unit": "G wave-instructions/s", "frac": ginst / ISSUE_PEAK_GINST,
+            "traffic": _traffic(tkey), "kernel_ms": add_ms, "kernel_ms_stats": add_stats,
+            "wave_insts_per_point_update": per_pt, "wave_insts_source": src, "point_updates": point_updates,
+            "hbm_algorithmic_GBps": gbps, "bytes_per_patch": bytes_total / P,
+            "what": "instruction-issue roofline of the add calls (rows phase + small-basis phase + regular kernel): counted wave-instructions "
+                    "per point update x point updates of the pass / MEDIAN HIP-event time, against 1024 SIMDs x 1 instruction / cycle x 2.4 GHz; "
+                    "with ~13 basis vectors the state lives in LDS and HBM traffic (`traffic`) is noise"}
+
+
+def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s, ny=1, with_sigma=False):
     """BASELINE configs[3]: sparse_gp online updates, patches of n points streamed in `chunks` add calls, capacity `cap`,
     then predict on the grid.  regime "fill": kernel parameters under which the basis reaches the capacity (l = res/8,
     sigma_f^2 = 1, s20 = 1e-4); "defaults": the reference's own hyper-parameters (the basis stays at ~13).
     ny = 3: the colour GP the reference trains beside every depth GP (sparse_gp_field, src/gp_compressor.cpp:163, 334) at ITS
     defaults (s20 = 1e2f, eps_tol = 1e-4f).
+    with_sigma: a SECOND record of the same workload whose predict also returns sigma = sqrt(s20 + k* + k^T C k), as the reference's
+    predict_measurements always computes it (/root/reference/src/sparse_gp.hpp:299-351; call sites src/gp_compressor.cpp:333-334) --
+    its own timed passes, its own CPU baseline (the oracle with sigma), the predict kernel's MFMA roofline on F_pred = m (2 b^2 + 9 b).
+    Returns a list of records.
     Parity is stated the way tests/sparse_parity.py defines it (the regime decides branches by rounding noise): reconstruction
     RMSE against the training targets, per-patch error against the binary128 arbiter as percentiles, blow-up counts -- for the
     GPU and the fp64 oracle side by side; results_ok fails when the GPU is worse than the oracle by the frozen factors."""
@@ -328,6 +398,7 @@ def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s, ny=1):
     xs0, xs1 = synth.grid(RES, SZ)
     d_xs0, d_xs1 = t(xs0), t(xs1)
     f = torch.empty((P, ny, M), dtype=torch.float64, device=dev)
+    d_sig = torch.empty((P, M), dtype=torch.float64, device=dev) if with_sigma else None
     cn = n // chunks
     coff = t((np.arange(P + 1) * cn).astype(np.int32))
     bufs = []
@@ -340,74 +411,76 @@ def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s, ny=1):
         g.add_dev(coff, cn, P * cn, *bufs[c])
         torch.cuda.synchronize()
         sizes.append(g.sizes().astype(np.float64))
-    g.predict_dev(M, d_xs0, d_xs1, f)
+    g.predict_dev(M, d_xs0, d_xs1, f, sigma=d_sig)
     torch.cuda.synchronize()
-    # B_add = 32 b^2 bytes per point (C and Q read once, written once), b interpolated linearly between the
-    # measured basis sizes at the chunk boundaries.  Round 3: a patch that arrives at an add call with >= 32 basis vectors runs that
-    # call on the LOWER TRIANGLES of C and Q (csrc/sparse.hip, sp_tri_pass; capacity > 100, Gaussian noise): 16 b^2 bytes per
-    # point + one mirror pass (16 b^2) when it leaves the kernel -- the bytes the path has to move, which is what `achieved` counts.
-    tri_on = cap > 100 and os.environ.get("GPC_SPARSE_FULL") is None
-    tri_min = int(os.environ.get("GPC_SPARSE_TRI_MIN", "32"))
-    bytes_total = 0.0
-    frac = (np.arange(cn) + 0.5) / cn
-    for c in range(chunks):
-        b = sizes[c][:, None] + (sizes[c + 1] - sizes[c])[:, None] * frac[None, :]
-        tri = (sizes[c] >= tri_min) & tri_on
-        per_b2 = np.where(tri, 16.0, 32.0)[:, None]
-        bytes_total += float(np.sum(per_b2 * b * b)) + float(np.sum(np.where(tri, 16.0, 0.0) * sizes[c + 1] ** 2))
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(chunks)] for _ in range(steps)]
-    t_tot = 0.0
-    for k in range(steps):
-        g.reset()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for c in range(chunks):
-            ev[k][c][0].record()
-            g.add_dev(coff, cn, P * cn, *bufs[c])
-            ev[k][c][1].record()
-        g.predict_dev(M, d_xs0, d_xs1, f)
-        torch.cuda.synchronize()
-        t_tot += time.perf_counter() - t0
-    add_ms = float(np.mean([sum(a.elapsed_time(b) for a, b in ev[k]) for k in range(steps)]))
+    bytes_total, tri_on = sparse_add_bytes(sizes, cn, cap)
+
+    def timed_passes(sigma):
+        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(chunks + 1)] for _ in range(steps)]
+        t_tot = 0.0
+        for k in range(steps):
+            g.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for c in range(chunks):
+                ev[k][c][0].record()
+                g.add_dev(coff, cn, P * cn, *bufs[c])
+                ev[k][c][1].record()
+            ev[k][chunks][0].record()
+            g.predict_dev(M, d_xs0, d_xs1, f, sigma=sigma)
+            ev[k][chunks][1].record()
+            torch.cuda.synchronize()
+            t_tot += time.perf_counter() - t0
+        add = _kstats([sum(a.elapsed_time(b) for a, b in ev[k][:chunks]) for k in range(steps)])
+        pred = _kstats([ev[k][chunks][0].elapsed_time(ev[k][chunks][1]) for k in range(steps)])
+        return t_tot, add, pred
+
+    t_tot, add_stats, pred_stats = timed_passes(None)
     bv = g.sizes()
     f_host = f.cpu().numpy()
     ok = bool(np.all(np.isfinite(f_host)))
-    achieved = bytes_total / (add_ms * 1e-3) / 1e9
     what = "sparse_gp" if ny == 1 else "sparse_gp_field (3 colour channels)"
     hyp = (" -- basis-filling kernel l=res/8, sigma_f^2=1, s20=1e-4" if regime == "fill"
            else (" -- the reference's default hyper-parameters (sigma_f^2=100, l^2=1, s20=0.1)" if ny == 1
                  else " -- the reference's default hyper-parameters of the colour GP (sigma_f^2=100, l^2=1, s20=100, eps_tol=1e-4)"))
-    rec = {"metric": "patches/sec (compress+predict)", "value": P * steps / t_tot, "unit": "patches/s", "n_gpus": 1, "steps": steps,
-           "warmup": 1, "ms_per_step": 1e3 * t_tot / steps, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"C4 {what} online ({regime}): {P} patches x {n} pts streamed in {chunks} add calls, capacity {cap}, "
-                                  f"then predictive mean on the {SZ}x{SZ} grid" + hyp,
-                      "patches_per_gpu": P, "points_per_patch": n, "capacity": cap, "channels": ny, "bv_mean": float(bv.mean()), "bv_max": int(bv.max()),
-                      "kernel": "sparse_add_rows_kernel<16> (rows phase) + sparse_add_kernel<true, false> (small-basis phase) + "
-                                + ("sparse_add_kernel<false, false, true> (triangular passes from 32 basis vectors on)" if tri_on
-                                   else "sparse_add_kernel<false, false>") + " + sparse_predict_kernel",
-                      "results_ok": ok},
-           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                        "traffic": _traffic(f"sparse_add@C4_{regime}" + ("" if ny == 1 else "_ny3")), "kernel_ms": add_ms, "bytes_per_patch": bytes_total / P,
-                        "what": "the add calls of one pass (rows phase + small-basis phase + regular kernel): sum over points of 32 b_t^2 bytes "
-                                "(16 b_t^2 where the regular kernel works on the lower triangles of C and Q, + its mirror pass) / their HIP-event time"
-                                + ("" if regime == "fill" else "; with ~13 basis vectors the pass is latency-bound, not stream-bound")}}
+    kern = ("sparse_add_rows_kernel<16> (rows phase) + sparse_add_kernel<true, false> (small-basis phase) + "
+            + ("sparse_add_kernel<false, false, true> (triangular passes from 32 basis vectors on)" if tri_on
+               else "sparse_add_kernel<false, false>") + " + sparse_predict_kernel")
+
+    def record(t_tot_, add_, pred_, sigma):
+        return {"metric": "patches/sec (compress+predict)", "value": P * steps / t_tot_, "unit": "patches/s", "n_gpus": 1, "steps": steps,
+                "warmup": 1, "ms_per_step": 1e3 * t_tot_ / steps, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"C4 {what} online ({regime}){' + sigma' if sigma else ''}: {P} patches x {n} pts streamed in {chunks} add calls, "
+                                       f"capacity {cap}, then predictive mean{' AND sigma (what predict_measurements computes)' if sigma else ''} "
+                                       f"on the {SZ}x{SZ} grid" + hyp,
+                           "patches_per_gpu": P, "points_per_patch": n, "capacity": cap, "channels": ny, "bv_mean": float(bv.mean()),
+                           "bv_max": int(bv.max()), "kernel": kern, "predict_ms": pred_["median"], "results_ok": ok},
+                "roofline": sparse_add_roofline(regime, ny, bytes_total, add_, P, float(P) * n)}
+
+    rec = record(t_tot, add_stats, pred_stats, False)
+    recs = [rec]
+    O = op = run_threads = None
     if budget_s > 0:
         O = _oracle()
         import sparse_parity as SP
         op = O.sparse_params(ny, p0=prm.sigmaf_sq, p1=prm.l_sq, s20=prm.noise, eps_tol=prm.eps_tol, capacity=cap)
 
-        def run(lo, hi):
-            # one C call per thread range (orc_sparse_fit_predict_batch: add_measurements + predict per patch; ctypes drops the GIL)
-            sub = (off[lo:hi + 1] - off[lo]).astype(np.int32)
-            sl = slice(int(off[lo]), int(off[hi]))
-            return O.sparse_fit_predict_batch(op, sub, x0[sl], x1[sl], np.ascontiguousarray(y[:, sl]), xs0, xs1, fast=True)[0]
-        cores = host_cores()
-        outs, done, dt, single = _timed_threads(run, P, cores, budget_s, probe=4 if regime == "fill" else 256)
-        f_cpu = np.concatenate(outs, axis=0)
+        def run_threads(sigma):
+            def run(lo, hi):
+                # one C call per thread range (orc_sparse_fit_predict_batch: add_measurements + predict per patch; ctypes drops the GIL)
+                sub = (off[lo:hi + 1] - off[lo]).astype(np.int32)
+                sl = slice(int(off[lo]), int(off[hi]))
+                r_ = O.sparse_fit_predict_batch(op, sub, x0[sl], x1[sl], np.ascontiguousarray(y[:, sl]), xs0, xs1, sigma=sigma, fast=True)
+                return r_[1] if sigma else r_[0]
+            cores = host_cores()
+            outs, done, dt, single = _timed_threads(run, P, cores, budget_s, probe=4 if regime == "fill" else 256)
+            base = {"value": done / dt, "unit": "patches/s", "cores": cores, "kind": "port", "single_thread_value": single,
+                    "sample": f"{done} of the {P} patches (same buffers, same insertion order), orc_sparse_fit_predict_batch "
+                              f"(oracle/gpc_oracle.c -O3 -march=native{', with sigma' if sigma else ''}), one C call per thread, "
+                              f"{cores} threads, {dt:.1f} s"}
+            return np.concatenate(outs, axis=0), done, base
+        f_cpu, done, rec["cpu_baseline"] = run_threads(False)
         diff = f_host[:done] - f_cpu
-        rec["cpu_baseline"] = {"value": done / dt, "unit": "patches/s", "cores": cores, "kind": "port", "single_thread_value": single,
-                               "sample": f"{done} of the {P} patches (same buffers, same insertion order), orc_sparse_fit_predict_batch "
-                                         f"(oracle/gpc_oracle.c -O3 -march=native), one C call per thread, {cores} threads, {dt:.1f} s"}
         rec["rmse_vs_ref"] = {"rmse": float(np.sqrt(np.mean(diff * diff))), "max_abs": float(np.max(np.abs(diff))),
                               "f_rms": float(np.sqrt(np.mean(f_cpu * f_cpu))),
                               "what": "GPU f* vs CPU oracle f* on the cpu_baseline sample -- in this regime two correct fp64 implementations "
@@ -424,8 +497,31 @@ def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s, ny=1):
         rec["parity"] = par
         rec["config"]["results_ok"] = ok = ok and par["gate"]["ok"]
         del ft, d_off, d_x0, d_x1
+    if with_sigma:
+        t2, add2, pred2 = timed_passes(d_sig)
+        s_host = d_sig.cpu().numpy()
+        ok_s = ok and bool(np.all(np.isfinite(s_host))) and bool(np.all(s_host >= 0.0))
+        rs = record(t2, add2, pred2, True)
+        rs["config"]["results_ok"] = ok_s
+        b_ = bv.astype(np.float64)
+        fl = float(np.sum(M * (2.0 * b_ * b_ + 9.0 * b_)))
+        ach = fl / (pred2["median"] * 1e-3) / 1e12
+        rs["roofline_predict"] = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+                                  "traffic": _traffic(f"sparse_predict_sigma@C4_{regime}"), "kernel_ms": pred2["median"], "kernel_ms_stats": pred2,
+                                  "flops_per_patch": fl / P,
+                                  "what": "sparse_predict_kernel with sigma: F_pred = m (2 b^2 + 9 b) flops per patch (SURVEY 8(d), b = the patch's "
+                                          "basis size) / MEDIAN HIP-event time of the predict call; the k^T C k part runs on the MFMA pipe (DESIGN 5.6)"}
+        if budget_s > 0:
+            s_cpu, done, rs["cpu_baseline"] = run_threads(True)
+            diff = s_host[:done] - s_cpu
+            rs["rmse_vs_ref"] = {"rmse": float(np.sqrt(np.mean(diff * diff))), "max_abs": float(np.max(np.abs(diff))),
+                                 "f_rms": float(np.sqrt(np.mean(s_cpu * s_cpu))),
+                                 "what": "GPU sigma vs CPU oracle sigma on the cpu_baseline sample (same caveat as the mean: the states differ "
+                                         "patch by patch in this regime; `parity` of the mean-only record is the statement)"}
+            rs["speedup_vs_cpu_baseline"] = rs["value"] / rs["cpu_baseline"]["value"]
+        recs.append(rs)
     g.close()
-    return rec
+    return recs
 
 
 def bench_sparse_c4_sharded(env, regime, P, n, chunks, cap, steps):
@@ -462,25 +558,40 @@ def bench_sparse_c4_sharded(env, regime, P, n, chunks, cap, steps):
     gather, exchange = gdist.make_gather(slots, Pg, f, world, rank, dev.index or 0,
                                          prefer_cabi=os.environ.get("GPC_BENCH_TORCH_GATHER") != "1")
 
-    def one_pass():
+    sizes = [np.zeros(S)]
+    evs = []
+
+    def one_pass(record_sizes=False, timed=False):
         g.reset()
+        ev = []
         for c in range(chunks):
+            if timed:
+                ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                ev[-1][0].record()
             g.add_dev(*bufs[c])
+            if timed:
+                ev[-1][1].record()
+            if record_sizes:
+                torch.cuda.synchronize()
+                sizes.append(g.sizes().astype(np.float64))
         g.predict_dev(M, d_xs0, d_xs1, f)
         gather.start(f, async_op=False)
+        if timed:
+            evs.append(ev)
 
     def fence():
         torch.cuda.synchronize()
         if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
-    one_pass()
+    one_pass(record_sizes=True)         # warm-up + the basis sizes at the chunk boundaries (this rank's slots)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        one_pass()
+        one_pass(timed=True)
     fence()
     elapsed = time.perf_counter() - t0
+    add_stats = _kstats([sum(a.elapsed_time(b) for a, b in ev) for ev in evs])
     if dist.is_initialized():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -491,6 +602,10 @@ def bench_sparse_c4_sharded(env, regime, P, n, chunks, cap, steps):
         okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
+    # roofline of rank 0's add calls (per GPU: its own slots, its own HIP-event times) -- the same model as the one-GPU records
+    bytes_total, _ = sparse_add_bytes(sizes, cn, cap)
+    roof = sparse_add_roofline(regime, 1, bytes_total, add_stats, max(S, 1), float(int(cnt.sum())))
+    roof["what"] = "rank 0's GPU: " + roof["what"]
     rec = {"metric": "patches/sec (compress+predict)", "value": world * P * steps / elapsed, "unit": "patches/s", "n_gpus": world, "steps": steps,
            "warmup": 1, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"C4 sparse_gp online ({regime}), sharded: {world * P} patches x {n} pts, {P} per GPU, streamed in {chunks} add calls "
@@ -498,7 +613,7 @@ def bench_sparse_c4_sharded(env, regime, P, n, chunks, cap, steps):
                       "patches_per_gpu": P, "points_per_patch": n, "capacity": cap, "bv_mean_rank0": float(bv.mean()),
                       "parallelism": f"gpc_partition_patches(sparse_capacity={cap}) -> {S} slots per rank; state stays on its GPU across the add calls",
                       "exchange": exchange, "results_ok": ok},
-           "roofline": None}
+           "roofline": roof}
     if hasattr(gather, "close"):
         gather.close()
     g.close()
@@ -537,7 +652,8 @@ def bench_irls_c5(env, P, n, steps, budget_s):
         step(ev[k])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kt = _kstats([a.elapsed_time(b) for a, b in ev])
+    kern_ms = kt["median"]
     it, st, f_host = d_it.cpu().numpy(), d_st.cpu().numpy(), d_f.cpu().numpy()
     ok = bool(np.all(st == 0)) and bool(np.all(np.isfinite(f_host))) and int(it.max()) < ir.max_iter
     flops = float(np.sum(irls_flops(n, M, it.astype(np.float64))))
@@ -549,7 +665,7 @@ def bench_irls_c5(env, P, n, steps, budget_s):
                       "patches_per_gpu": P, "points_per_patch": n, "newton_steps_mean": float(it.mean()), "newton_steps_max": int(it.max()),
                       "kernel": ctx.last_dense_kernel(), "results_ok": ok},
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                        "traffic": _traffic("dense_mfma_big_irls@n1024"), "kernel_ms": kern_ms, "flops_per_patch": flops / P,
+                        "traffic": _traffic("dense_mfma_big_irls@n1024"), "kernel_ms": kern_ms, "kernel_ms_stats": kt, "flops_per_patch": flops / P,
                         "what": "sum over patches of newton_steps x (3.5 n^2 + n^3/3 + 2 n^2) + 9 n m flops / HIP-event time of the launch"}}
     if budget_s > 0:
         O = _oracle()
@@ -582,7 +698,7 @@ def main():
     ap.add_argument("--points", type=int, default=256, help="points per patch (C2: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling passes)")
-    ap.add_argument("--only", default="", help="profiling: run just one workload -- c3 | c4fill | c4defaults | c4defaults3 | c5 | c2var -- and print its record")
+    ap.add_argument("--only", default="", help="profiling: run just one workload -- c3 | c4fill | c4defaults | c4defaults3 | c4fills | c4defaultss (with sigma) | c5 | c2var -- and print its record")
     args = ap.parse_args()
 
     # stdout carries ONE JSON line: whatever else writes to fd 1 while the bench runs (RCCL prints a version banner there when a
@@ -627,9 +743,12 @@ def main():
         if args.only == "c3":
             r = bench_dense(env, 8192, 512, sec_steps, 1, seed=3)
             out = dense_record("C3 outdoor scan (one GPU's share)", r, 8192, 512, world, sec_steps, 1)
-        elif args.only in ("c4fill", "c4defaults", "c4defaults3"):
-            out = bench_sparse_c4(env, args.only[2:].rstrip("3"), int(os.environ.get("GPC_C4_P", "32768")), 256, 4, 200, 1,
-                                  float(os.environ.get("GPC_C4_CPU_S", "0")), ny=3 if args.only.endswith("3") else 1)
+        elif args.only in ("c4fill", "c4defaults", "c4defaults3", "c4fills", "c4defaultss"):
+            sig = args.only.endswith("s")                      # c4fills / c4defaultss: the record with sigma (profiling its predict kernel)
+            reg = args.only[2:].rstrip("3s")
+            recs = bench_sparse_c4(env, reg, int(os.environ.get("GPC_C4_P", "32768")), 256, 4, 200, int(os.environ.get("GPC_C4_STEPS", "1")),
+                                   float(os.environ.get("GPC_C4_CPU_S", "0")), ny=3 if args.only.endswith("3") else 1, with_sigma=sig)
+            out = recs[-1]
         elif args.only == "c5":
             out = bench_irls_c5(env, 4096, 1024, 1, 0.0)
         elif args.only == "c2var":
@@ -712,7 +831,8 @@ def main():
             secondary.append(bench_dense_variance(env, 8192, 256, 3, 3.0 if cpu else 0.0))
             torch.cuda.empty_cache()
             for regime, ny_ in (("fill", 1), ("defaults", 1), ("defaults", 3)):
-                secondary.append(bench_sparse_c4(env, regime, 32768, 256, 4, 200, 2, 4.0 if cpu else 0.0, ny=ny_))
+                # depth plane: a second record with sigma, as the reference's predict_measurements computes it (sparse_gp.hpp:299-351)
+                secondary.extend(bench_sparse_c4(env, regime, 32768, 256, 4, 200, 2, 4.0 if cpu else 0.0, ny=ny_, with_sigma=(ny_ == 1)))
                 torch.cuda.empty_cache()
             secondary.append(bench_irls_c5(env, 4096, 1024, 2, 3.0 if cpu else 0.0))
     _log("printing the line")

@@ -76,7 +76,10 @@ __global__ __launch_bounds__(GEN_THREADS) void dense_generic_kernel(GenParams g)
     const double sf = A.prm.sigmaf_sq, cexp = g.c_exp, noise = A.prm.noise;
     const int m = A.m;
 
-    for (int patch = blockIdx.x; patch < A.P; patch += gridDim.x) {
+    // (size-class dispatch: the overflow launch behind a class launch sized from a host-side hint works on sel[sel_base .. *sel_count))
+    const int n_items = A.sel ? A.sel_count[0] - A.sel_base : A.P;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int patch = A.sel ? A.sel[A.sel_base + item] : item;
         const int o = A.off[patch];
         const int n = A.off[patch + 1] - o;
         double* fs = A.f_star + (size_t)patch * ny * m;
@@ -355,13 +358,13 @@ size_t dense_generic_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_
     return (size_t)grid * slot * sizeof(double);
 }
 
-int dense_generic_launch(gpc_ctx* ctx, const DenseArgs& a, int grid)
+int dense_generic_launch(gpc_ctx* ctx, const DenseArgs& a, int grid, double* ws_override)
 {
     GenParams g;
     g.a = a;
     g.c_exp = (double)(-0.5f) / a.prm.l_sq;
     g.pivot_tol = GPC_PIVOT_RTOL * (a.prm.sigmaf_sq + a.prm.noise);
-    g.ws = static_cast<double*>(ctx->ws);
+    g.ws = ws_override ? ws_override : static_cast<double*>(ctx->ws);
     g.ld = a.n_max + a.ny;
     g.mpad = (a.m + 63) & ~63;
     g.slot = (size_t)g.ld * g.ld + (a.v_star ? (size_t)a.n_max * g.mpad : 0);

@@ -144,7 +144,11 @@ __device__ static __forceinline__ void w1_gram_row(d4 (&v)[W1_C], const double* 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int pj = MF_TS * (c0 + t) + lg + 4 * q;
+#ifdef W1_EXP_NOGRAM       // diagnostic (results wrong by construction, the matrix stays SPD): what the Gram evaluations cost
+            v[t][q] = (pi == pj) ? sf : 1e-3 * sf;
+#else
             v[t][q] = SMALL ? gpc_rbf_small(sf, cexp, xi0, xi1, px0[pj], px1[pj]) : gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T);
+#endif
         }
     }
     if constexpr (DIAG) {
@@ -671,19 +675,21 @@ bool dense_w1_supported(const DenseArgs& a)
 }
 
 // One factor slot per patch of a launch (304 KB: 2.5 GB for the 8192 patches of BASELINE config 2 -- sized for 288 GB); a larger
-// batch goes through in launches of W1_MAX_SLOTS patches that reuse the slots.
-#define W1_MAX_SLOTS 16384
-static int w1_chunk(const DenseArgs& a)
+// batch goes through in launches of W1_MAX_SLOTS patches that reuse the slots (a launch of 8192 patches is four rounds of the 2048
+// resident workgroups: its ramp and tail are ~3 % of it).  `cap` > 0: the dispatcher's retry with fewer slots after GPC_ENOMEM.
+#define W1_MAX_SLOTS 8192
+static int w1_chunk(const DenseArgs& a, int cap_in)
 {
     const char* e = getenv("GPC_W1_SLOTS");
-    const int cap = e && atoi(e) > 0 ? atoi(e) : W1_MAX_SLOTS;
+    int cap = e && atoi(e) > 0 ? atoi(e) : W1_MAX_SLOTS;
+    if (cap_in > 0 && cap_in < cap) cap = cap_in;
     return a.P < cap ? a.P : cap;
 }
 
-size_t dense_w1_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
+size_t dense_w1_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out, int cap)
 {
     (void)ctx;
-    const int grid = w1_chunk(a);
+    const int grid = w1_chunk(a, cap);
     if (grid_out) *grid_out = grid;
     // factor slots | L_kk^-T images | (variance without alpha_out: the weights the variance kernel forms the mean from)
     return sizeof(double) * ((size_t)(W1_TRI + W1_NT) * MF_IMG * (size_t)grid + (a.v_star ? (size_t)a.n_total : 0));

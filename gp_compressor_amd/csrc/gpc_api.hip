@@ -317,11 +317,21 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
             const char* mp = getenv("GPC_W1_MIN_P");
             const int min_p = mp ? atoi(mp) : 4 * ctx->num_cus;
             if (a.n_max <= 256 && a.P >= min_p && a.P > 1 && (a.n_max > 192 || !a.v_star) && dense_w1_supported(a) && !getenv("GPC_NO_W1")) {
-                int grid_w1 = 0;
-                const size_t w1_bytes = (dense_w1_ws_bytes(ctx, a, &grid_w1) + 255) & ~(size_t)255;
-                const int rcw = gpc_ws_reserve(ctx, w1_bytes);
-                if (rcw != GPC_OK) return rcw;
-                return dense_w1_launch(ctx, a, grid_w1);
+                // One factor slot (304 KB) per patch of a launch.  If the device cannot serve that, the batch goes
+                // through in smaller launches that reuse fewer slots, and below two launches' worth of resident patches it takes the
+                // register-resident kernel, which needs no workspace at all.
+                int grid_w1 = 0, rcw = GPC_ENOMEM;
+                DenseArgs aw = a;
+                for (int cap_w1 = 0;;) {
+                    const size_t w1_bytes = (dense_w1_ws_bytes(ctx, aw, &grid_w1, cap_w1) + 255) & ~(size_t)255;
+                    rcw = gpc_ws_reserve(ctx, w1_bytes);
+                    if (rcw != GPC_ENOMEM) break;
+                    cap_w1 = grid_w1 / 2;
+                    if (cap_w1 < 4 * ctx->num_cus) break;             // (below the batch-size rule of this kernel)
+                }
+                if (rcw == GPC_OK) return dense_w1_launch(ctx, a, grid_w1);
+                if (rcw != GPC_ENOMEM || a.v_star) return rcw;
+                (void)hipGetLastError();
             }
         }
         // (GPC_W2=1: the two-wave shape of the tiled kernel, round 3's first headline kernel, kept as a cross-check)
@@ -342,9 +352,18 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
             const bool need_big = !(nt17 && a.n_max <= 17 * 16);
             int grid_b = 0;
             const size_t big_bytes = need_big ? (dense_big_ws_bytes(ctx, a, &grid_b) + 255) & ~(size_t)255 : 0;
-            int rc = gpc_ws_reserve(ctx, big_bytes + sizeof(int32_t) * (3 * (size_t)a.P + 64));
+            // Class sizes known on the host (the batch came from gpc_project_cloud on this context): the class launches get exactly that
+            // many workgroups.  The hint is matched by pointer and P only -- a caller that rewrites `off` IN PLACE keeps both -- so every
+            // hinted launch is followed by an OVERFLOW launch of the generic kernel (a few workgroups that stride over
+            // sel[hint .. count), count on the device: no patch when the hint was right, every patch the hint missed otherwise).
+            const bool hinted = ctx->hint_off == a.off && ctx->hint_P == a.P && !getenv("GPC_NO_HINT");
+            constexpr int OVF_GRID = 8;
+            const size_t ovf_slot = sizeof(double) * (size_t)(17 * 16 + a.ny) * (size_t)(17 * 16 + a.ny);
+            const size_t ovf_bytes = hinted ? (2 * OVF_GRID * ovf_slot + 255) & ~(size_t)255 : 0;
+            int rc = gpc_ws_reserve(ctx, big_bytes + ovf_bytes + sizeof(int32_t) * (3 * (size_t)a.P + 64));
             if (rc != GPC_OK) return rc;
-            int32_t* counts = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->ws) + big_bytes);
+            double* ovf_ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + big_bytes);
+            int32_t* counts = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->ws) + big_bytes + ovf_bytes);
             int32_t* sel0 = counts + 64;
             int32_t* sel1 = sel0 + a.P;
             int32_t* sel2 = sel1 + a.P;
@@ -380,10 +399,15 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
                 ctx->stream = main_s;
                 if (rc != GPC_OK) return bail(rc);
             }
-            // Class sizes known on the host (the batch came from gpc_project_cloud on this context): launch exactly that many
-            // workgroups.  Otherwise P per class -- the ones beyond the class count leave at once, but each still waits for a CU
+            // Without a hint: P workgroups per class -- the ones beyond the class count leave at once, but each still waits for a CU
             // with 158 KB of LDS free.
-            const bool hinted = ctx->hint_off == a.off && ctx->hint_P == a.P && !getenv("GPC_NO_HINT");
+            auto overflow = [&](const DenseArgs& cls, int launched, int which) -> int {
+                if (!hinted || launched >= a.P) return GPC_OK;
+                DenseArgs o = cls;
+                o.sel_base = launched;
+                o.P = a.P;
+                return dense_generic_launch(ctx, o, OVF_GRID, ovf_ws + (size_t)which * OVF_GRID * (ovf_slot / sizeof(double)));
+            };
             const int c0 = hinted ? ctx->hint_le256 : a.P;
             const int c1 = hinted ? (nt17 ? ctx->hint_le272 - ctx->hint_le256 : 0) : a.P;
             DenseArgs s = a;
@@ -393,7 +417,13 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
                 s.P = c1;
                 if (fork) ctx->stream = ctx->s_in;
                 rc = dense_mfma_launch(ctx, s);
+                if (rc == GPC_OK) rc = overflow(s, c1, 1);
                 ctx->stream = main_s;
+                if (rc != GPC_OK) return bail(rc);
+            } else if (nt17 && hinted) {
+                s.n_max = 17 * 16;
+                s.sel = sel1; s.sel_count = counts + 1;
+                rc = overflow(s, 0, 1);
                 if (rc != GPC_OK) return bail(rc);
             }
             if (c0 > 0) {
@@ -401,6 +431,12 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
                 s.sel = sel0; s.sel_count = counts;
                 s.P = c0;
                 rc = dense_mfma_launch(ctx, s);
+                if (rc == GPC_OK) rc = overflow(s, c0, 0);
+                if (rc != GPC_OK) return bail(rc);
+            } else if (hinted) {
+                s.n_max = 256;
+                s.sel = sel0; s.sel_count = counts;
+                rc = overflow(s, 0, 0);
                 if (rc != GPC_OK) return bail(rc);
             }
             if (fork) {

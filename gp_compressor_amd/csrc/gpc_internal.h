@@ -84,14 +84,40 @@ static inline int gpc_fail(gpc_ctx* ctx, int code, const char* fmt, ...)
 static inline int gpc_ws_reserve(gpc_ctx* ctx, size_t bytes)
 {
     if (bytes <= ctx->ws_bytes) return GPC_OK;
-    if (ctx->ws) {
-        // the previous workspace may still be in use by work enqueued on the stream
+    // The new block is allocated BEFORE the old one is released: a request the device cannot serve leaves the context with the
+    // workspace it had.  Only when old + new do not fit side by side is the old one given up first.
+    void* nw = nullptr;
+    // (diagnostic: GPC_WS_FAIL_ABOVE=<bytes> makes every larger request fail like an exhausted device -- the test of the fallbacks)
+    const char* lim = getenv("GPC_WS_FAIL_ABOVE");
+    if (lim && bytes > (size_t)atoll(lim)) return gpc_fail(ctx, GPC_ENOMEM, "workspace allocation failed (GPC_WS_FAIL_ABOVE)");
+    hipError_t e = hipMalloc(&nw, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (!ctx->ws) return gpc_fail(ctx, GPC_ENOMEM, "workspace allocation failed");
         GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t old_bytes = ctx->ws_bytes;
         GPC_HIP(ctx, hipFree(ctx->ws));
         ctx->ws = nullptr;
         ctx->ws_bytes = 0;
+        e = hipMalloc(&nw, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            // put back what was there, so that later (smaller) calls find the context as it was
+            if (hipMalloc(&ctx->ws, old_bytes) == hipSuccess) {
+                ctx->ws_bytes = old_bytes;
+                (void)hipMemsetAsync(ctx->ws, getenv("GPC_POISON_LDS") ? 0xFF : 0, old_bytes, ctx->stream);
+            } else {
+                (void)hipGetLastError();
+                ctx->ws = nullptr;
+            }
+            return gpc_fail(ctx, GPC_ENOMEM, "workspace allocation failed");
+        }
+    } else if (ctx->ws) {
+        // the previous workspace may still be in use by work enqueued on the stream
+        GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GPC_HIP(ctx, hipFree(ctx->ws));
     }
-    GPC_HIP(ctx, hipMalloc(&ctx->ws, bytes));
+    ctx->ws = nw;
     ctx->ws_bytes = bytes;
     // recycled device memory holds arbitrary bit patterns; the kernels write every workspace element before they use it,
     // but their (clamped, unconditional) prefetches may touch elements they never consume: keep those reads free of
@@ -121,11 +147,13 @@ struct DenseArgs {
     // (both on the device) instead of 0 .. P-1
     const int32_t* sel;
     const int32_t* sel_count;
+    int sel_base;              // generic kernel only: it works on sel[sel_base .. *sel_count) -- the overflow launch behind a class launch that
+                               // was sized from a host-side hint (gpc_api.hip)
 };
 
 // generic kernel: any n <= GPC_MAX_POINTS, K/L in a global-memory workspace slot per workgroup
 size_t dense_generic_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out);
-int dense_generic_launch(gpc_ctx* ctx, const DenseArgs& a, int grid);
+int dense_generic_launch(gpc_ctx* ctx, const DenseArgs& a, int grid, double* ws_override = nullptr);
 
 // register-tile MFMA kernel: n <= 256, trailing matrix resident in VGPRs (see dense_mfma.hip)
 bool dense_mfma_supported(const DenseArgs& a);
@@ -146,7 +174,7 @@ size_t dense_big_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out)
 int dense_big_launch(gpc_ctx* ctx, const DenseArgs& a, int grid);
 // one wave per patch, eight patches per CU: n <= 256, depth plane, mean only (see dense_mfma_w1.hip) -- the C2 headline kernel
 bool dense_w1_supported(const DenseArgs& a);
-size_t dense_w1_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out);
+size_t dense_w1_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out, int cap = 0);
 int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a, int grid);
 // the same kernel inside the Newton / IRLS loop of the probit variant (BASELINE config 5; any n <= 1024, ny == 1)
 struct IrlsArgs {

@@ -251,7 +251,7 @@ __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int l
     }
 }
 
-// ---- TRIANGULAR passes (the four-wave regular kernel, capacity > 100: SpAddParams::tri) ----------------------------------------
+// ---- TRIANGULAR passes (the two- and four-wave shapes of the regular kernel, i.e. capacity > 64, Gaussian noise: SpAddParams::tri) ----------------------------------------
 // C and Q are symmetric, and with a large basis the add path is bound by their stream: one read + one write of both per point
 // (32 b^2 bytes).  In this mode the kernel works on the LOWER triangles only -- element (i, j), i >= j, at [i + j ld]; the upper
 // triangle is ignored on entry and mirrored from the lower one when the patch leaves the kernel, so every other kernel still sees

@@ -125,19 +125,32 @@ class CabiGather:
         self.row = int(np.prod(like.shape[1:]))
         self.owner = share is None
         if share is None:
-            uid = [None]
-            if rank == 0:
-                try:
-                    uid[0] = capi.Comm.unique_id()
-                except Exception:
-                    uid[0] = None                            # the other ranks must not be left waiting in the broadcast
+            # Agree BEFORE the collective: every step that can fail locally -- the side stream, the context, binding
+            # RCCL (drawing a unique id does that on every rank; only rank 0's is used) -- runs first, then one all_reduce(MIN) of an
+            # `able` flag decides for all ranks alike.  Only then does anybody enter ncclCommInitRank, which blocks until every rank is in.
+            uid, able, err = [None], 1, None
+            self.side = self.cctx = None
+            try:
+                self.side = torch.cuda.Stream(device=like.device)
+                self.cctx = capi.Context(device_index)
+                self.cctx.set_stream(self.side.cuda_stream)
+                mine = capi.Comm.unique_id()
+                if rank == 0:
+                    uid[0] = mine
+            except Exception as e:
+                able, err = 0, e
+            if dist.is_initialized() and world > 1:
+                okt = torch.tensor([able], dtype=torch.int32, device=like.device)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                able_all = int(okt.item())
+            else:
+                able_all = able
+            if not able_all:
+                if self.cctx is not None:
+                    self.cctx.close()
+                raise RuntimeError(f"the C-ABI communicator cannot be set up on every rank ({err if err else 'another rank failed'})")
             if dist.is_initialized() and world > 1:
                 dist.broadcast_object_list(uid, src=0)       # the channel "the host has" for the 128 bytes
-            if uid[0] is None:
-                raise RuntimeError("rank 0 could not draw an RCCL unique id")
-            self.side = torch.cuda.Stream(device=like.device)
-            self.cctx = capi.Context(device_index)
-            self.cctx.set_stream(self.side.cuda_stream)
             self.comm = capi.Comm(self.cctx, world, rank, uid[0])
             self.comm.set_partition(P, slots)
         else:
@@ -182,15 +195,9 @@ def make_gather(slots, P, like, world, rank, device_index, prefer_cabi=True):
     g, why = None, ""
     if prefer_cabi and like.is_cuda:
         try:
-            g = CabiGather(slots, P, like, world, rank, device_index)
-        except Exception as e:          # RCCL not found / communicator refused: every rank must learn of it
+            g = CabiGather(slots, P, like, world, rank, device_index)      # (raises on every rank or on none: it agrees before the collective)
+        except Exception as e:          # RCCL not found / context refused
             why = f"{type(e).__name__}: {e}"
-        if dist.is_initialized() and world > 1:
-            okt = torch.tensor([1 if g is not None else 0], dtype=torch.int32, device=like.device)
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-            if int(okt.item()) == 0 and g is not None:
-                g.close()
-                g, why = None, "another rank could not bind RCCL"
     if g is not None:
         return g, "C-ABI: gpc_comm_create + gpc_allgather_fstar_dev (ncclAllGather + un-permute kernel, " + capi.load().gpc_comm_library().decode() + ")"
     return ShardedGather(slots, P, like, world), "torch.distributed.all_gather_into_tensor + index_select" + (f" (C-ABI communicator unavailable: {why})" if why else "")

@@ -163,15 +163,27 @@ void gp_compressor::train_sparse_sharded(const std::vector<int32_t>& perm_d, con
     init_shards();
     const int S = (P + world - 1) / world;
     if (shard_slots_.empty()) {
-        shard_slots_.assign((size_t)S * world, -1);
-        check(gpc_partition_patches(P, batch_.off.data(), world, depth_params.capacity > 0 ? depth_params.capacity : 1, shard_slots_.data()),
+        // built in locals and committed to the members only when every create has succeeded (as init_shards() does): a create that
+        // throws midway must not leave shard_slots_ filled beside half-created GPs
+        std::vector<int32_t> slots((size_t)S * world, -1);
+        check(gpc_partition_patches(P, batch_.off.data(), world, depth_params.capacity > 0 ? depth_params.capacity : 1, slots.data()),
               nullptr, "gpc_partition_patches");
-        shard_gps_.assign(world, nullptr);
-        shard_rgb_.assign(world, nullptr);
-        for (int r = 0; r < world; ++r) {
-            check(gpc_sparse_create(shard_ctx_[r], &depth_params, S, 1, &shard_gps_[r]), shard_ctx_[r], "gpc_sparse_create(depth, shard)");
-            check(gpc_sparse_create(shard_ctx_[r], &rgb_params, S, 3, &shard_rgb_[r]), shard_ctx_[r], "gpc_sparse_create(rgb, shard)");
+        std::vector<gpc_sparse*> gps(world, nullptr), rgb(world, nullptr);
+        try {
+            for (int r = 0; r < world; ++r) {
+                check(gpc_sparse_create(shard_ctx_[r], &depth_params, S, 1, &gps[r]), shard_ctx_[r], "gpc_sparse_create(depth, shard)");
+                check(gpc_sparse_create(shard_ctx_[r], &rgb_params, S, 3, &rgb[r]), shard_ctx_[r], "gpc_sparse_create(rgb, shard)");
+            }
+        } catch (...) {
+            for (int r = 0; r < world; ++r) {
+                if (gps[r]) gpc_sparse_destroy(gps[r]);
+                if (rgb[r]) gpc_sparse_destroy(rgb[r]);
+            }
+            throw;
         }
+        shard_slots_.swap(slots);
+        shard_gps_.swap(gps);
+        shard_rgb_.swap(rgb);
     }
     const size_t N = batch_.x0.size();
     struct Shard {

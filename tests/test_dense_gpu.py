@@ -537,10 +537,9 @@ def test_dense_full_size_properties(gp, oracle, P, n, label):
 
 
 def test_dense_headline_kernel_is_bit_reproducible(gp):
-    """The two-wave shape of the tiled kernel (the C2 bench path) gives the same bits run after run: which wave takes which row
-    pass changes from run to run, but a row's arithmetic does not depend on who runs it, and every LDS accumulator of the backward
-    solve and of the predictive sums has exactly two contributors (a + b is commutative in IEEE arithmetic).  The register-resident
-    kernel is reproducible to a rounding or two only (seven waves add into w_k in arrival order; VERDICT round 2, "weak")."""
+    """The one-wave kernel (dense_mfma_w1, the C2 bench path) gives the same bits run after run: a patch is the business of a single
+    wave, there is no LDS atomic and no hand-over whose arrival order could enter a sum.  (The register-resident kernel is reproducible
+    to a rounding or two only: seven waves add into w_k in arrival order; VERDICT round 2, "weak".)"""
     capi, ctx = gp
     res, sz = 0.15, 20
     off, x0, x1, y = synth.make_patches(2048, 256, res=res, seed=77, ragged=True, n_min=200)
@@ -550,6 +549,34 @@ def test_dense_headline_kernel_is_bit_reproducible(gp):
     for _ in range(3):
         f1, st1, al1 = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz, want_alpha=True)
         assert np.array_equal(f1, f0) and np.array_equal(al1, al0) and np.array_equal(st1, st0)
+
+
+def test_one_wave_kernel_survives_a_refused_workspace(gp, monkeypatch):
+    """The one-wave kernel wants one 304 KB factor slot per patch of a launch.  When the device refuses that (GPC_WS_FAIL_ABOVE makes
+    gpc_ws_reserve fail like an exhausted device) the batch goes through in smaller launches that reuse fewer slots,
+    and below that on the register-resident kernel, which needs no workspace -- same results, never an error for the caller; the
+    context keeps a usable workspace afterwards."""
+    from gp_compressor_amd import capi as capi_mod
+    capi, _ = gp
+    ctx = capi_mod.Context(0)                     # own context: the module's may already hold a large workspace
+    res, sz = 0.15, 20
+    off, x0, x1, y = synth.make_patches(2048, 256, res=res, seed=78, ragged=True, n_min=200)
+    p = capi.default_params_dense()
+    f0, st0 = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz)
+    assert ctx.last_dense_kernel() == "dense_mfma_w1" and np.all(st0 == 0)
+    ctx.close()
+    slot = 152 * 2048
+    for limit, want in ((slot * 1100, "dense_mfma_w1"), (slot * 100, "dense_mfma_nt16")):
+        c2 = capi_mod.Context(0)
+        monkeypatch.setenv("GPC_WS_FAIL_ABOVE", str(limit))
+        monkeypatch.setenv("GPC_W1_MIN_P", "64")
+        f1, st1 = c2.dense_fit_predict_grid(p, off, x0, x1, y, res, sz)
+        assert c2.last_dense_kernel() == want, c2.last_dense_kernel()
+        monkeypatch.delenv("GPC_WS_FAIL_ABOVE")
+        assert np.all(st1 == 0) and np.max(np.abs(f1 - f0)) <= 1e-9 * np.max(np.abs(f0))
+        f2, st2 = c2.dense_fit_predict_grid(p, off, x0, x1, y, res, sz)      # and the context is whole afterwards
+        assert c2.last_dense_kernel() == "dense_mfma_w1" and np.array_equal(f2, f0)
+        c2.close()
 
 
 def test_dense_does_not_read_stale_lds(gp, oracle, monkeypatch):

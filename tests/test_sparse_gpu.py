@@ -156,7 +156,9 @@ def test_sparse_online_growth_equals_one_shot(gp, oracle):
     # The worst patch is bounded against the oracle's worst too (tests/sparse_parity.py MAX_FACTOR), not by a constant: a kernel
     # change that makes the single worst patch 10x worse than the CPU's worst fails here.
     assert rms(e_gpu) <= 3.0 * rms(e_orc) + 2e-6 and np.median(e_gpu) <= 3.0 * np.median(e_orc) + 2e-6
-    assert e_gpu.max() <= 10.0 * e_orc.max() + 2e-6, (e_gpu.max(), e_orc.max())
+    # ... with an absolute ceiling beside it: the relative bound follows whatever the CPU oracle's outlier happens to
+    # be; measured worst patches of this batch: GPU 1e-5 .. 1e-4 over the builds of rounds 2-3, the oracle the same
+    assert e_gpu.max() <= min(10.0 * e_orc.max() + 2e-6, 1e-3), (e_gpu.max(), e_orc.max())
     # reset() (src/sparse_gp.hpp:573-582)
     g2.reset()
     assert np.all(g2.sizes() == 0)
