@@ -50,6 +50,32 @@ __device__ static __forceinline__ int w1_exp_zero() { int z; asm volatile("s_mov
 #ifndef W1_HINT
 #define W1_HINT 1
 #endif
+// Round 4 (each with its own switch, so that one library build can be timed against another on the same box):
+//   W1_TRSM_CHAIN  the four products of a TRSM chained through the accumulator instead of four independent products + an add tree
+//                  (12 VALU adds per TRSM, 136 TRSMs per patch)
+//   W1_CMASK       the diagonal factor with constant lane masks in SGPR pairs (mf_diag_factor_c: 4 instead of ~12 VALU per pivot)
+//   W1_CARRY       the row pass of a step that covers the NEXT block's rows runs last and its sixteen result tiles stay in registers:
+//                  the next step's block takes the products over those four tile columns from them, its sweep reads only the columns
+//                  before (48 of the 96 sweep images of a 16-row factor are not read at all)
+//   W1_LASTRES     the last step's block (six tiles + four L_cc^-T) goes into the backward solve from registers / LDS and is never
+//                  written to the workspace (n a multiple of 64 points' worth of tiles, no factor export)
+#ifndef W1_TRSM_CHAIN
+#define W1_TRSM_CHAIN 1
+#endif
+#ifndef W1_CMASK
+#define W1_CMASK 1
+#endif
+// (W1_CARRY and W1_LASTRES are OFF in the shipped build: hipcc answers both with register spills that move more bytes than they save --
+//  46 / 386 / 208 spilled VGPRs without / with the carry / with the resident last block, scratch stores and reloads in every step)
+#ifndef W1_CARRY
+#define W1_CARRY 0
+#endif
+#ifndef W1_LASTRES
+#define W1_LASTRES 0
+#endif
+#if W1_LASTRES && !W1_CMASK
+#error "W1_LASTRES needs the diagonal factor that can skip its L^-T store (W1_CMASK)"
+#endif
 #define W1_LOAD_BACK(p, l) ((W1_HINT & 1) ? mf_img_load_nt(p, l) : mf_img_load(p, l))
 #define W1_LOAD_ROWOP(p, l) ((W1_HINT & 2) ? mf_img_load_nt(p, l) : mf_img_load(p, l))
 #define W1_STORE_TILE(p, l, v)                                                                                        \
@@ -61,7 +87,11 @@ __device__ static __forceinline__ int w1_exp_zero() { int z; asm volatile("s_mov
 struct W1Params {
     DenseArgs a;
     double c_exp;
-    double pivot_tol;
+    double pivot_tol;   // (already in the scale the factor runs in: see noise_u)
+    // host-computed wave-uniform constants (kernel arguments live in SGPRs; computed in the kernel they would be VGPR pairs for its whole
+    // length): sqrt(-c), the noise term and the weight multipliers of the scale the factor runs in -- unit scale (K / sigma_f^2: noise_u =
+    // noise / sigma_f^2, prediction weights as they are, alpha_out = a' / sigma_f^2) unless the factor is exported for the variance
+    double cs, noise_u, sfp, a_out;
     double* ws;         // factor slots, one per patch of the launch: W1_TRI images, the lower triangle packed row-major -- tile (i, j) at
                         // (i (i + 1) / 2 + j) * 256 -- which is the layout dense_variance_kernel<16> reads (dense_variance.hip)
     double* linvt;      // the L_kk^-T images: [patch][16][256]
@@ -121,6 +151,12 @@ __device__ static __forceinline__ d4 w1_mfma4_neg(d4 a, d4 b, d4 acc)
 __device__ static __forceinline__ d4 w1_trsm(d4 lv, d4 src)
 {
     const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
+#if W1_TRSM_CHAIN
+    d4 D = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], src[0], z4, 0, 0, 0);
+    D = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], src[1], D, 0, 0, 0);
+    D = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], src[2], D, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(lv[3], src[3], D, 0, 0, 0);
+#endif
     const d4 D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[0], src[0], z4, 0, 0, 0);
     const d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[1], src[1], z4, 0, 0, 0);
     const d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[2], src[2], z4, 0, 0, 0);
@@ -133,9 +169,13 @@ __device__ static __forceinline__ d4 w1_trsm(d4 lv, d4 src)
 // tiles -- distance, exponential, nothing else -- come first, in ONE basic block: 4 CNT independent dependency chains for the
 // scheduler (evaluated tile by tile behind per-tile mode branches the Gram tiles ran at a fifth of the VALU rate: stamps, round 3).
 // The noise diagonal (DIAG: the row's last tile is the diagonal tile r == c0 + CNT - 1) and the padding are wave-uniform fix-ups.
-template <bool SMALL, int CNT, bool DIAG>
-__device__ static __forceinline__ void w1_gram_row(d4 (&v)[W1_C], const double* px0, const double* px1, const double* T, double sf, double cexp,
-                                                   double noise, bool dbl, int n, int r, int c0, int lr, int lg)
+// Round 4: MODE 0 = table-driven exponential of c d^2 on the caller's coordinates; MODE 1 / 2 = the patch proved c d^2 >= -2^-5 / -2^-8
+// for every pair and holds its coordinates pre-scaled by sqrt(-c): the squared distance IS the argument, exp(-t) is a degree-7 / degree-5
+// polynomial with literal coefficients -- 11 / 9 VALU operations per value (round 3: 13).  The kernel is evaluated WITHOUT sigma_f^2
+// (unit scale: the factor of K / sigma_f^2, see the kernel body) unless the factor is exported (scale_sf).
+template <int MODE, int CNT, bool DIAG>
+__device__ static __forceinline__ void w1_gram_row(d4 (&v)[W1_C], const double* px0, const double* px1, const double* T, double sf, bool scale_sf,
+                                                   double cexp, double noise, bool dbl, int n, int r, int c0, int lr, int lg)
 {
     const int pi = MF_TS * r + lr;
     const double xi0 = px0[pi], xi1 = px1[pi];
@@ -145,11 +185,19 @@ __device__ static __forceinline__ void w1_gram_row(d4 (&v)[W1_C], const double* 
         for (int q = 0; q < 4; ++q) {
             const int pj = MF_TS * (c0 + t) + lg + 4 * q;
 #ifdef W1_EXP_NOGRAM       // diagnostic (results wrong by construction, the matrix stays SPD): what the Gram evaluations cost
-            v[t][q] = (pi == pj) ? sf : 1e-3 * sf;
+            v[t][q] = (pi == pj) ? 1.0 : 1e-3;
 #else
-            v[t][q] = SMALL ? gpc_rbf_small(sf, cexp, xi0, xi1, px0[pj], px1[pj]) : gpc_rbf_neg(sf, cexp, xi0, xi1, px0[pj], px1[pj], T);
+            const double d0 = xi0 - px0[pj], d1 = xi1 - px1[pj];
+            const double sq = __builtin_fma(d0, d0, d1 * d1);
+            v[t][q] = MODE == 0 ? gpc_exp_neg(cexp * sq, T) : gpc_expm_poly<MODE == 1 ? 7 : 5>(sq);
 #endif
         }
+    }
+    if (scale_sf) {
+#pragma unroll
+        for (int t = 0; t < CNT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[t][q] *= sf;
     }
     if constexpr (DIAG) {
 #pragma unroll
@@ -217,86 +265,164 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
         unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
 #endif
 
-        // ---- points into LDS; extent of the patch around its first point (max-norm) bounds every kernel argument ----
+        // ---- points into LDS; the bounding box of the patch bounds every kernel argument ----
+        // Regimes of the exponential (wave-uniform; false for NaN / inf extents):
+        //   mode_g (Gram):  2 when |c| d^2 <= 2^-8 for every pair of the patch (box diagonal), 1 when <= 2^-5, else 0
+        //   mode_p (separable grid factors): the same thresholds on |c| (grid-to-point distance along one axis)^2; 0 when mode_g is 0
+        // mode_g > 0: the coordinates go to LDS centred on the first point and SCALED by sqrt(-c), so that a squared distance is the
+        // argument itself (gpc_expm_poly: no multiplication by c, literal coefficients); the rounding of the scaled coordinates moves an
+        // argument by <= 2^-50 |c| extent^2 <= 2^-55 here.  mode_g == 0: raw coordinates, table-driven exponential, as in round 3.
+        // That is the regime of a GP patch model whose length scale exceeds the patch -- the reference's dense defaults and C2.
         const double xo0 = A.x0[o], xo1 = A.x1[o];
-        double dev = 0.0;
+        double qr0[W1_NPAD / 64], qr1[W1_NPAD / 64];
+        double mn0 = xo0, mx0 = xo0, mn1 = xo1, mx1 = xo1;
 #pragma unroll
         for (int u = 0; u < W1_NPAD / 64; ++u) {
             const int i = lane + 64 * u;
             const bool live = i < n;
-            const double q0 = live ? A.x0[o + i] : xo0, q1 = live ? A.x1[o + i] : xo1;
-            dev = __builtin_fmax(dev, __builtin_fmax(__builtin_fabs(q0 - xo0), __builtin_fabs(q1 - xo1)));
-            px0[i] = live ? q0 : 0.0;
-            px1[i] = live ? q1 : 0.0;
+            qr0[u] = live ? A.x0[o + i] : xo0;
+            qr1[u] = live ? A.x1[o + i] : xo1;
+            mn0 = __builtin_fmin(mn0, qr0[u]); mx0 = __builtin_fmax(mx0, qr0[u]);
+            mn1 = __builtin_fmin(mn1, qr1[u]); mx1 = __builtin_fmax(mx1, qr1[u]);
             zv[i] = live ? A.y[o + i] : 0.0;        // the right-hand side; the forward solve turns it into z column by column, in place
         }
 #pragma unroll
-        for (int o_ = 32; o_ > 0; o_ >>= 1) dev = __builtin_fmax(dev, __shfl_xor(dev, o_, 64));
-        // Small-argument regime (dense_mfma.hip): |c| d^2 <= 2^-5 for every Gram argument / every separable grid factor -> the
-        // degree-7 polynomial instead of the table-driven exponential.  Wave-uniform; false for NaN / inf extents.
-        bool small_gram, small_grid;
-        {
-            const double r = dev;
-            const double bq = 0.5 * A.grid_res + __builtin_fmax(__builtin_fabs(xo0), __builtin_fabs(xo1)) + r;
-            small_gram = __builtin_amdgcn_readfirstlane((int)(-cexp * (8.0 * r * r) <= GPC_EXP_SMALL_MAX)) != 0;
-            small_grid = __builtin_amdgcn_readfirstlane((int)(-cexp * (bq * bq) <= GPC_EXP_SMALL_MAX)) != 0;
+        for (int o_ = 32; o_ > 0; o_ >>= 1) {
+            mn0 = __builtin_fmin(mn0, __shfl_xor(mn0, o_, 64)); mx0 = __builtin_fmax(mx0, __shfl_xor(mx0, o_, 64));
+            mn1 = __builtin_fmin(mn1, __shfl_xor(mn1, o_, 64)); mx1 = __builtin_fmax(mx1, __shfl_xor(mx1, o_, 64));
         }
+        int mode_g, mode_p;
+        {
+            const bool nan_box = !((mx0 - mn0) + (mx1 - mn1) < __builtin_inf());         // a NaN coordinate slips through fmin / fmax
+            const double rx = mx0 - mn0, ry = mx1 - mn1;
+            const double tg = nan_box ? __builtin_inf() : -cexp * __builtin_fma(rx, rx, ry * ry);
+            const double hb = 0.5 * A.grid_res;
+            const double bx = hb + __builtin_fmax(__builtin_fabs(mn0), __builtin_fabs(mx0));
+            const double by = hb + __builtin_fmax(__builtin_fabs(mn1), __builtin_fabs(mx1));
+            const double bq = __builtin_fmax(bx, by);
+            const double tp = nan_box ? __builtin_inf() : -cexp * (bq * bq);
+            mode_g = __builtin_amdgcn_readfirstlane(tg <= GPC_EXP_TINY_MAX ? 2 : tg <= GPC_EXP_SMALL_MAX ? 1 : 0);
+            mode_p = __builtin_amdgcn_readfirstlane(tp <= GPC_EXP_TINY_MAX ? 2 : tp <= GPC_EXP_SMALL_MAX ? 1 : 0);
+            if (mode_g == 0) mode_p = 0;
+#ifdef W1_EXP_FORCE_MODE      // diagnostic: the regime chosen by hand (0 table, 1 degree 7, 2 degree 5)
+            mode_g = mode_g > 0 ? W1_EXP_FORCE_MODE : 0;
+            mode_p = mode_p > 0 ? W1_EXP_FORCE_MODE : 0;
+#endif
+        }
+        const bool scaled = mode_g > 0;
+        {
+            const double cs = scaled ? g.cs : 1.0;                             // coordinate scale
+            const double co0 = scaled ? xo0 : 0.0, co1 = scaled ? xo1 : 0.0;   // ... and centre
+#pragma unroll
+            for (int u = 0; u < W1_NPAD / 64; ++u) {
+                const int i = lane + 64 * u;
+                const bool live = i < n;
+                px0[i] = live ? cs * (qr0[u] - co0) : 0.0;
+                px1[i] = live ? cs * (qr1[u] - co1) : 0.0;
+            }
+        }
+        // Unit scale: K + 2 noise I = sigma_f^2 (E + 2 (noise / sigma_f^2) I) with E the kernel without sigma_f^2.  The wave factors
+        // E' = E + ..., solves E' a' = y, and predicts f* = E*^T a' -- sigma_f^2 cancels in the predictive mean, so no kernel value is
+        // ever multiplied by it (one VALU operation per value); alpha_out = a' / sigma_f^2.  With the factor exported for the
+        // predictive variance the true K is factored (scale_sf): the variance kernel reads L and L_kk^-1 of K itself.
+        const bool scale_sf = g.export_factor != 0;
+        const double noise_u = g.noise_u, ptol = g.pivot_tol;
         W1_LDS_SYNC();
-#ifdef W1_EXP_SMALLONLY      // diagnostic: no table-driven path at all (what the code size costs)
-#define W1_GRAM_ROW(v, CNT, DIAG, r, c0) w1_gram_row<true, CNT, DIAG>(v, px0, px1, T, sf, cexp, noise, dbl, n, r, c0, lr, lg)
-#else
 #define W1_GRAM_ROW(v, CNT, DIAG, r, c0)                                                                              \
     do {                                                                                                             \
-        if (small_gram) w1_gram_row<true, CNT, DIAG>(v, px0, px1, T, sf, cexp, noise, dbl, n, r, c0, lr, lg);          \
-        else w1_gram_row<false, CNT, DIAG>(v, px0, px1, T, sf, cexp, noise, dbl, n, r, c0, lr, lg);                    \
+        if (mode_g == 2) w1_gram_row<2, CNT, DIAG>(v, px0, px1, T, sf, scale_sf, cexp, noise_u, dbl, n, r, c0, lr, lg);   \
+        else if (mode_g == 1) w1_gram_row<1, CNT, DIAG>(v, px0, px1, T, sf, scale_sf, cexp, noise_u, dbl, n, r, c0, lr, lg); \
+        else w1_gram_row<0, CNT, DIAG>(v, px0, px1, T, sf, scale_sf, cexp, noise_u, dbl, n, r, c0, lr, lg);            \
     } while (0)
-#endif
 
         bool bad = false;
         W1_STAMP(0);
         // ---- tiled left-looking Cholesky, four tile columns (k .. k+3) per step ----
-        for (int k = 0; k < nt; k += W1_C) {
+        // Rotated loop (W1_CARRY): the accumulators of a step's diagonal block, tacc, and its forward-solve sums, part, are set up at
+        // the END of the previous step, right behind the row pass of the block's own rows -- that pass runs last, its sixteen result
+        // tiles cy[c][t] (the operand images of L_(k+4+t)(k+c)) are still in registers, and the block takes its products over those
+        // four tile columns from them.  The step then sweeps only the tile columns before (jend), from the workspace.  What crosses
+        // the loop's back edge is tacc and part (88 registers that the sweep needs anyway), never the sixteen tiles.
+#if W1_CARRY
+        d4 tacc[W1_NDT];
+        double part[W1_C];
+#endif
+        // block row bi of the step at kb (nb tile columns): Gram tiles (kb + bi, kb .. kb + bi), the last one the diagonal tile; WITH_CY:
+        // minus the products over the previous step's tile columns, and the forward-solve sums over them (z of those columns is final).
+        // From the last row down, so that the carry rows above bi are dead once it is done.
+#define W1_BLOCK_ROW(bi, kb, nb, WITH_CY)                                                                            \
+    do {                                                                                                             \
+        if ((bi) < (nb)) {                                                                                           \
+            d4 gv[W1_C];                                                                                             \
+            W1_GRAM_ROW(gv, (bi) + 1, true, (kb) + (bi), (kb));                                                      \
+            _Pragma("unroll") for (int bc = 0; bc <= (bi); ++bc) tacc[(bi) * ((bi) + 1) / 2 + bc] = gv[bc];           \
+            if (WITH_CY) {                                                                                           \
+                _Pragma("unroll") for (int c = 0; c < W1_C; ++c) {                                                   \
+                    _Pragma("unroll") for (int bc = 0; bc <= (bi); ++bc)                                             \
+                        tacc[(bi) * ((bi) + 1) / 2 + bc] = w1_mfma4_neg(cy[c][bc], cy[c][bi], tacc[(bi) * ((bi) + 1) / 2 + bc]); \
+                    const double* zq = zv + MF_TS * ((kb) - W1_C + c) + lg;                                          \
+                    part[bi] += (cy[c][bi][0] * zq[0] + cy[c][bi][1] * zq[4]) + (cy[c][bi][2] * zq[8] + cy[c][bi][3] * zq[12]); \
+                }                                                                                                    \
+            }                                                                                                        \
+        } else {     /* (zeroed HERE, not up front: ten live zero tiles beside the sixteen carry tiles do not fit) */       \
+            _Pragma("unroll") for (int bc = 0; bc <= (bi); ++bc) tacc[(bi) * ((bi) + 1) / 2 + bc] = d4{0.0, 0.0, 0.0, 0.0}; \
+        }                                                                                                            \
+    } while (0)
+#define W1_BLOCK_INIT(kb, nb, WITH_CY)                                                                               \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < W1_C; ++i) part[i] = 0.0;                                              \
+        /* (scheduling barriers: left alone, hipcc evaluates all ten Gram tiles first -- 80 registers beside the sixteen carry   \
+           tiles -- and spills the accumulators) */                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        W1_BLOCK_ROW(3, kb, nb, WITH_CY);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        W1_BLOCK_ROW(2, kb, nb, WITH_CY);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        W1_BLOCK_ROW(1, kb, nb, WITH_CY);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        W1_BLOCK_ROW(0, kb, nb, WITH_CY);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#if W1_CARRY
+        {
+            d4 cy[W1_C][4];       // (never read: step 0 has no columns before it)
+            const int nb0 = min(W1_C, nt);
+            W1_BLOCK_INIT(0, nb0, false);
+        }
+#endif
+        d4 LbK[W1_C * (W1_C - 1) / 2];            // W1_LASTRES: the last step's strictly lower block tiles, kept for the backward solve
+                                                  // (assigned on the loop's exit edge only)
+        const bool lastres = W1_LASTRES && (nt & 3) == 0 && !g.export_factor;
+        W1_STAMP(1);
+        for (int k = 0;; k += W1_C) {                                      // (left by `break` at the last step)
             const int nc = min(W1_C, nt - k);                              // tile columns of this step
-            const int kl = k - 1;
+            const int jend = (W1_CARRY && k > 0) ? k - W1_C : k;           // the sweep reads tile columns j < jend from the workspace
+            const int kl = jend - 1;
+            const bool last_step = k + W1_C >= nt;
             W1_FRESH_LANE();
             // ---- the diagonal block: T_(k+i)(k+c) = A - sum_{j<k} L_(k+i)j L_(k+c)j^T, tile d = i (i + 1) / 2 + c, one sweep over j;
             //      the forward-solve sums  part_c = sum_{j<k} L_(k+c)j z_j  from the same operands ----
             const double* rrow[W1_C];
 #pragma unroll
             for (int i = 0; i < W1_C; ++i) rrow[i] = Lt + W1_TILE(k + min(i, nc - 1), 0);
-            d4 op[2][W1_C], tacc[W1_NDT];
+#if !W1_CARRY
+            d4 tacc[W1_NDT];
             double part[W1_C];
+#endif
+            d4 op[2][W1_C];
 #pragma unroll
-            for (int i = 0; i < W1_C; ++i) {
-                op[0][i] = op[1][i] = d4{0.0, 0.0, 0.0, 0.0};
-                part[i] = 0.0;
-            }
-            if (k > 0) {
+            for (int i = 0; i < W1_C; ++i) op[0][i] = op[1][i] = d4{0.0, 0.0, 0.0, 0.0};
+            if (jend > 0) {
 #pragma unroll
                 for (int i = 0; i < W1_C; ++i) op[0][i] = mf_img_load(rrow[i], lane);
             }
-#pragma unroll
-            for (int d = 0; d < W1_NDT; ++d) tacc[d] = d4{0.0, 0.0, 0.0, 0.0};
+#if !W1_CARRY
             {
-                // block row bi: tiles (k + bi, k .. k + bi), the last one the diagonal tile
-                d4 gv[W1_C];
-                W1_GRAM_ROW(gv, 1, true, k, k);
-                tacc[0] = gv[0];
-                if (nc > 1) {
-                    W1_GRAM_ROW(gv, 2, true, k + 1, k);
-                    tacc[1] = gv[0]; tacc[2] = gv[1];
-                }
-                if (nc > 2) {
-                    W1_GRAM_ROW(gv, 3, true, k + 2, k);
-                    tacc[3] = gv[0]; tacc[4] = gv[1]; tacc[5] = gv[2];
-                }
-                if (nc > 3) {
-                    W1_GRAM_ROW(gv, 4, true, k + 3, k);
-                    tacc[6] = gv[0]; tacc[7] = gv[1]; tacc[8] = gv[2]; tacc[9] = gv[3];
-                }
+                d4 cy[W1_C][4];   // (never read)
+                W1_BLOCK_INIT(k, nc, false);
             }
-            W1_STAMP(1);
-            for (int j = 0; j < k; j += 2) {
+#endif
+            for (int j = 0; j < jend; j += 2) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int jn = min(j + h + 1, kl);
@@ -320,7 +446,15 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             d4 Lb[W1_C * (W1_C - 1) / 2];
 #pragma unroll
             for (int q = 0; q < W1_C * (W1_C - 1) / 2; ++q) Lb[q] = d4{0.0, 0.0, 0.0, 0.0};
-            bool ok = mf_diag_factor<true>(tacc[0], rsbuf, LinvC, LinvTg + (size_t)k * MF_IMG, g.pivot_tol, lane);
+            // (W1_LASTRES: the last step's block never reaches the workspace -- its tiles go into the backward solve as registers, its
+            // L_cc^-T images are read back transposed from the L_cc^-1 images in LDS)
+            const bool keep = lastres && last_step;
+#if W1_CMASK
+#define W1_DIAG(Wt, c_) mf_diag_factor_c(Wt, rsbuf, LinvC + (c_) * MF_IMG, keep ? nullptr : LinvTg + (size_t)(k + (c_)) * MF_IMG, ptol, lane)
+#else
+#define W1_DIAG(Wt, c_) mf_diag_factor<true>(Wt, rsbuf, LinvC + (c_) * MF_IMG, LinvTg + (size_t)(k + (c_)) * MF_IMG, ptol, lane)
+#endif
+            bool ok = W1_DIAG(tacc[0], 0);
             W1_LDS_SYNC();
             if (g.export_factor) mf_img_store(Lt + W1_TILE(k, k), lane, mf_img_load(LinvC, lane));
 #pragma unroll
@@ -334,16 +468,17 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                         const d4 lvc = mf_img_load(LinvC + c * MF_IMG, mf_opaque(lane));
                         const d4 L = w1_trsm(lvc, Tt);                     // operand image of L_(k+i)(k+c)
                         Lb[i * (i - 1) / 2 + c] = L;
-                        W1_STORE_TILE(Lt + W1_TILE(k + i, k + c), lane, L);
+                        if (!keep) W1_STORE_TILE(Lt + W1_TILE(k + i, k + c), lane, L);
                     }
                     d4 Dii = tacc[i * (i + 1) / 2 + i];
 #pragma unroll
                     for (int c = 0; c < i; ++c) Dii = w1_mfma4_neg(Lb[i * (i - 1) / 2 + c], Lb[i * (i - 1) / 2 + c], Dii);
-                    ok = mf_diag_factor<true>(Dii, rsbuf, LinvC + i * MF_IMG, LinvTg + (size_t)(k + i) * MF_IMG, g.pivot_tol, lane);
+                    ok = W1_DIAG(Dii, i);
                     W1_LDS_SYNC();
                     if (g.export_factor) mf_img_store(Lt + W1_TILE(k + i, k + i), lane, mf_img_load(LinvC + i * MF_IMG, mf_opaque(lane)));
                 }
             }
+#undef W1_DIAG
 #if defined(W1_EXP_HOT) || defined(W1_EXP_NOPASSTRSM) || defined(W1_EXP_NOBACK)
             ok = true;
 #endif
@@ -381,29 +516,47 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                 }
             }
             W1_STAMP(4);
-            const int rows_tot_ = nt - (k + nc);
-            if (rows_tot_ > 0 && !(k == 0 && nc == W1_C)) __syncthreads();     // the chain's tiles are in the workspace before the row passes read them back
-            // ---- rows k + nc .. nt - 1, two per pass: update the four accumulators over j < k, then column by column
-            //      T_r(k+c) -= sum_{c2<c} L_r(k+c2) L_(k+c)(k+c2)^T,  L_r(k+c) = T L_cc^-T ----
-            const int rows_tot = rows_tot_;
-            int first_row0 = 0;
-            if (k == 0 && nc == W1_C) {
-                // Step 0 has no update loop, so its registers are free: FOUR rows per pass with the block's lower tiles resident (no
-                // reload from the workspace -- at eight patches per CU those reloads miss L2: 36 of a patch's 512 image reads) and
-                // four independent TRSM chains interleaved.
-                for (; first_row0 < rows_tot; first_row0 += 4) {
+            const int rows_tot = nt - (k + nc);
+            if (rows_tot == 0) {
+                // the last step: no rows below its block.  (The loop's only regular exit: values kept for the backward solve are live on
+                // this edge alone, not across the row passes of the earlier steps.)
+                if (keep) {
+#pragma unroll
+                    for (int q = 0; q < W1_C * (W1_C - 1) / 2; ++q) LbK[q] = Lb[q];
+                } else {
+                    __syncthreads();   // the block's tiles are in the workspace before the backward solve reads them back
+                }
+                break;
+            }
+            if (k > 0) __syncthreads();     // the chain's tiles are in the workspace before the row passes read them back
+            // ---- rows k + 4 .. nt - 1 (rows below a block exist only when the block has all four columns), FOUR per pass: update the
+            //      sixteen accumulators over j < k, then column by column  T_r(k+c) -= sum_{c2<c} L_r(k+c2) L_(k+c)(k+c2)^T,
+            //      L_r(k+c) = T L_cc^-T.  The pass of the NEXT block's rows (first_row 0) runs LAST and its result tiles stay in cy for
+            //      the next step's block (W1_CARRY). ----
+            const int npass = (rows_tot + 3) / 4;      // (a descending loop makes hipcc spill 90 more registers: the passes run 4, 8, .., then 0)
+            const int klp = k - 1;
+#if W1_CARRY
+            d4 cy[W1_C][4];                            // the accumulators of a pass; after the loops: the tiles of the pass that ran last
+#endif
+            if (k == 0) {
+                // Step 0 has no update loop, so its registers are free: the block's lower tiles stay resident (no reload from the
+                // workspace -- at eight patches per CU those reloads miss L2) and four independent TRSM chains interleave.
+                for (int pi_ = 0; pi_ < npass; ++pi_) {
+                    const int first_row0 = (pi_ + 1 < npass) ? 4 * (pi_ + 1) : 0;
                     const int np4 = min(4, rows_tot - first_row0);
                     W1_FRESH_LANE();
-                    d4 a4[W1_C][4];
+#if !W1_CARRY
+                    d4 cy[W1_C][4];
+#endif
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int r_ = W1_C + first_row0 + min(t, np4 - 1);       // (t >= np4: a copy of the last row, never stored)
                         d4 gv[W1_C];
                         W1_GRAM_ROW(gv, 2, false, r_, 0);
-                        a4[0][t] = gv[0]; a4[1][t] = gv[1];
+                        cy[0][t] = gv[0]; cy[1][t] = gv[1];
                         __builtin_amdgcn_sched_barrier(0);
                         W1_GRAM_ROW(gv, 2, false, r_, 2);
-                        a4[2][t] = gv[0]; a4[3][t] = gv[1];
+                        cy[2][t] = gv[0]; cy[3][t] = gv[1];
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     W1_STAMP(5);
@@ -413,47 +566,50 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
 #pragma unroll
-                            for (int c2 = 0; c2 < c; ++c2) a4[c][t] = w1_mfma4_neg(Lb[c * (c - 1) / 2 + c2], a4[c2][t], a4[c][t]);
-                            a4[c][t] = w1_trsm(lv, a4[c][t]);
-                            if (t < np4) W1_STORE_TILE(Lt + W1_TILE(W1_C + first_row0 + t, c), lane, a4[c][t]);
+                            for (int c2 = 0; c2 < c; ++c2) cy[c][t] = w1_mfma4_neg(Lb[c * (c - 1) / 2 + c2], cy[c2][t], cy[c][t]);
+                            cy[c][t] = w1_trsm(lv, cy[c][t]);
+                            if (t < np4) W1_STORE_TILE(Lt + W1_TILE(W1_C + first_row0 + t, c), lane, cy[c][t]);
                         }
                     }
                     W1_STAMP(7);
                 }
-            }
-            // k > 0 (rows beyond the block exist only when the block has all four columns): FOUR rows per pass -- 16 accumulators; the four
-            // column operands L_(k+c)j double-buffered, the four row operands L_rj single-buffered and re-requested for j + 1 as soon as
-            // their four products of j are issued (twelve products of lead).  Eight images per 16 products: the two-row passes of the
-            // first version fetched six per eight, and at eight patches per CU every one of them is an L2 miss (the kernel moves
-            // 10.7 GB per launch at 6 TB/s: it runs at the HBM bandwidth the part delivers).
-            for (int first_row = first_row0; first_row < rows_tot; first_row += 4) {
-                const int np4 = min(4, rows_tot - first_row);
-                W1_FRESH_LANE();
-                int rr[4];
-                const double* rw_[4];
+            } else {
+                // k > 0: 16 accumulators; the four column operands L_(k+c)j double-buffered, the four row operands L_rj single-buffered and
+                // re-requested for j + 1 as soon as their four products of j are issued (twelve products of lead).  Eight images per 16
+                // products: the two-row passes of the first version fetched six per eight, and at eight patches per CU every one of them
+                // is an L2 miss (the kernel runs at the HBM bandwidth the part delivers).
+                for (int pi_ = 0; pi_ < npass; ++pi_) {
+                    const int first_row = (pi_ + 1 < npass) ? 4 * (pi_ + 1) : 0;
+                    const int np4 = min(4, rows_tot - first_row);
+                    W1_FRESH_LANE();
+#if !W1_CARRY
+                    d4 cy[W1_C][4];
+#endif
+                    int rr[4];
+                    const double* rw_[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    rr[t] = k + W1_C + first_row + min(t, np4 - 1);        // (t >= np4: a copy of the last row, never stored)
-                    rw_[t] = Lt + W1_TILE(rr[t], 0);
-                }
-                d4 acc[W1_C][4], A2[2][W1_C], B[4];
+                    for (int t = 0; t < 4; ++t) {
+                        rr[t] = k + W1_C + first_row + min(t, np4 - 1);        // (t >= np4: a copy of the last row, never stored)
+                        rw_[t] = Lt + W1_TILE(rr[t], 0);
+                    }
+                    d4 A2[2][W1_C], B[4];
 #pragma unroll
-                for (int c = 0; c < W1_C; ++c) A2[0][c] = mf_img_load(rrow[c], lane);
+                    for (int c = 0; c < W1_C; ++c) A2[0][c] = mf_img_load(rrow[c], lane);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) B[t] = W1_LOAD_ROWOP(rw_[t], lane);
+                    for (int t = 0; t < 4; ++t) B[t] = W1_LOAD_ROWOP(rw_[t], lane);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    d4 gv[W1_C];
-                    W1_GRAM_ROW(gv, 2, false, rr[t], k);
-                    acc[0][t] = gv[0]; acc[1][t] = gv[1];
-                    __builtin_amdgcn_sched_barrier(0);
-                    W1_GRAM_ROW(gv, 2, false, rr[t], k + 2);
-                    acc[2][t] = gv[0]; acc[3][t] = gv[1];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                W1_STAMP(5);
-                d4 Lq[W1_C * (W1_C - 1) / 2];      // images of L_(k+i)(k+c2), c2 < i, at i (i - 1) / 2 + c2
-                // one j: request the column operands of jn into the other stage, then row by row the four products and the row's next request
+                    for (int t = 0; t < 4; ++t) {
+                        d4 gv[W1_C];
+                        W1_GRAM_ROW(gv, 2, false, rr[t], k);
+                        cy[0][t] = gv[0]; cy[1][t] = gv[1];
+                        __builtin_amdgcn_sched_barrier(0);
+                        W1_GRAM_ROW(gv, 2, false, rr[t], k + 2);
+                        cy[2][t] = gv[0]; cy[3][t] = gv[1];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    W1_STAMP(5);
+                    d4 Lq[W1_C * (W1_C - 1) / 2];      // images of L_(k+i)(k+c2), c2 < i, at i (i - 1) / 2 + c2
+                    // one j: request the column operands of jn into the other stage, then row by row the four products and the row's next request
 #define W1_PASS_J(st, jn, PREFETCH)                                                                                  \
     do {                                                                                                             \
         /* (the scheduling barriers pin the requests where they are written: left alone, hipcc sinks every one of them to its  \
@@ -463,7 +619,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                              \
-            _Pragma("unroll") for (int c = 0; c < W1_C; ++c) acc[c][t] = w1_mfma4_neg(A2[st][c], B[t], acc[c][t]);    \
+            _Pragma("unroll") for (int c = 0; c < W1_C; ++c) cy[c][t] = w1_mfma4_neg(A2[st][c], B[t], cy[c][t]);      \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
             if (PREFETCH) B[t] = W1_LOAD_ROWOP(rw_[t] + (size_t)W1_JX(jn) * MF_IMG, lane);                           \
             else {     /* the last j: the block's lower tiles for the TRSMs take the place of the operands that are done */ \
@@ -475,35 +631,46 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
     } while (0)
-                for (int j = 0; j + 2 < k; j += 2) {
-                    W1_PASS_J(0, j + 1, true);
-                    W1_PASS_J(1, j + 2, true);
-                }
-                W1_PASS_J(0, kl, true);                 // (k is a multiple of four: the last pair of j; its second half requests nothing)
-                W1_PASS_J(1, kl, false);
+                    for (int j = 0; j + 2 < k; j += 2) {
+                        W1_PASS_J(0, j + 1, true);
+                        W1_PASS_J(1, j + 2, true);
+                    }
+                    W1_PASS_J(0, klp, true);                // (k is a multiple of four: the last pair of j; its second half requests nothing)
+                    W1_PASS_J(1, klp, false);
 #undef W1_PASS_J
-                W1_STAMP(6);
-                W1_FRESH_LANE();
-                // (the block's strictly lower tiles Lq came back from the workspace during the last j -- this wave's own stores of the
-                // chain, fenced below it: as registers they would be live across the update loop, 48 VGPRs on top of its 224)
+                    W1_STAMP(6);
+                    W1_FRESH_LANE();
+                    // (the block's strictly lower tiles Lq came back from the workspace during the last j -- this wave's own stores of the
+                    // chain, fenced below it: as registers they would be live across the update loop, 48 VGPRs on top of its 224)
 #pragma unroll
-                for (int c = 0; c < W1_C; ++c) {
-                    const d4 lv = mf_img_load(LinvC + c * MF_IMG, mf_opaque(lane));
+                    for (int c = 0; c < W1_C; ++c) {
+                        const d4 lv = mf_img_load(LinvC + c * MF_IMG, mf_opaque(lane));
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                        for (int t = 0; t < 4; ++t) {
 #ifndef W1_EXP_NOPASSTRSM      // (diagnostic: what the TRSM chains of the row passes cost -- stores only)
 #pragma unroll
-                        for (int c2 = 0; c2 < c; ++c2) acc[c][t] = w1_mfma4_neg(Lq[c * (c - 1) / 2 + c2], acc[c2][t], acc[c][t]);
-                        acc[c][t] = w1_trsm(lv, acc[c][t]);
+                            for (int c2 = 0; c2 < c; ++c2) cy[c][t] = w1_mfma4_neg(Lq[c * (c - 1) / 2 + c2], cy[c2][t], cy[c][t]);
+                            cy[c][t] = w1_trsm(lv, cy[c][t]);
 #endif
-                        if (t < np4) W1_STORE_TILE(Lt + W1_TILE(rr[t], k + c), lane, acc[c][t]);
+                            if (t < np4) W1_STORE_TILE(Lt + W1_TILE(rr[t], k + c), lane, cy[c][t]);
+                        }
                     }
+                    W1_STAMP(7);
                 }
-                W1_STAMP(7);
             }
-            __syncthreads();   // the column block is in the workspace (this wave's own stores, read back by its next sweep)
+#if W1_CARRY
+            // ---- the next step's block, while the tiles of its rows over this step's columns are in registers ----
+            W1_FRESH_LANE();
+            {
+                const int kn = k + W1_C, nbn = min(W1_C, nt - kn);
+                W1_BLOCK_INIT(kn, nbn, true);
+            }
+#endif
+            __syncthreads();   // the column block is in the workspace (this wave's own stores, read back by its next sweep and passes)
             W1_STAMP(8);
         }
+#undef W1_BLOCK_INIT
+#undef W1_BLOCK_ROW
 
         if (bad) {
             for (int p = lane; p < m; p += 64) fs[p] = __builtin_nan("");
@@ -535,7 +702,33 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                 const double* ad = (t < kk) ? Lt + W1_TILE(kq + 1 + t, kq) : LinvTg + (size_t)kq * MF_IMG;
                 return kk < nt ? ad : Lt;
             };
-            w1_static_for<0, W1_BW>([&](auto P) __attribute__((always_inline)) {
+            // W1_LASTRES: the first ten positions -- the last block's six tiles and four L_cc^-T -- never went to the workspace: tile
+            // (k + 1 + t, k) of column kk from the end is block tile (4 - kk + t, 3 - kk), and the image of L_cc^-T is the image of
+            // L_cc^-1 (LDS, left there by the last step's chain) read transposed
+            constexpr int NLAST = W1_C * (W1_C + 1) / 2;
+            static_assert(NLAST <= W1_BW, "the resident block must fit the ring's first fill");
+            if (lastres) {
+                w1_static_for<0, NLAST>([&](auto P) __attribute__((always_inline)) {
+                    constexpr int q = decltype(P)::value;
+                    constexpr int kk = w1_stream_col(q), t = q - kk * (kk + 1) / 2;
+                    if constexpr (t < kk) {
+                        constexpr int bi = W1_C - kk + t, bc = W1_C - 1 - kk;
+                        win[q] = LbK[bi * (bi - 1) / 2 + bc];
+                    } else {
+                        const double* Mi = LinvC + (W1_C - 1 - kk) * MF_IMG;
+                        d4 r_;
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_) r_[s_] = Mi[mf_img_rc(lg + 4 * s_, lr)];
+                        win[q] = r_;
+                    }
+                });
+            } else {
+                w1_static_for<0, NLAST>([&](auto P) __attribute__((always_inline)) {
+                    constexpr int q = decltype(P)::value;
+                    win[q % W1_BW] = W1_LOAD_BACK(stream_addr(P), lane);
+                });
+            }
+            w1_static_for<NLAST, W1_BW>([&](auto P) __attribute__((always_inline)) {
                 constexpr int q = decltype(P)::value;
                 win[q % W1_BW] = W1_LOAD_BACK(stream_addr(P), lane);
             });
@@ -583,7 +776,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
         W1_STAMP(9);
         double* av = zv;
         if (A.alpha_out)
-            for (int i = lane; i < n; i += 64) A.alpha_out[o + i] = av[i];
+            for (int i = lane; i < n; i += 64) A.alpha_out[o + i] = av[i] * g.a_out;      // (unit scale: the weights of K are a' / sigma_f^2)
 
 #ifndef W1_EXP_NOPRED
         // ---- predictive mean ----
@@ -599,28 +792,39 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nl = 0; nl < 2; ++nl) P[mt][nl] = d4{0.0, 0.0, 0.0, 0.0};
-            double gq[2];
+            double gqx[2], gqy[2];        // grid coordinates of this lane's rows / columns in the coordinates the points are held in
+            const double cs = scaled ? g.cs : 1.0, co0 = scaled ? A.x0[o] : 0.0, co1 = scaled ? A.x1[o] : 0.0;
+            const double argc = scaled ? -1.0 : cexp, sfp = g.sfp;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) gq[h] = res * (((double)(16 * h + lr) + 0.5) / (double)sz - 0.5);
-            // No masks in the loop: a point beyond n contributes nothing because its weight sf alpha_i is SELECTED to zero (alpha is
-            // zero from n to 16 nt -- identity padding solves to 0 -- but never written beyond: select, do not multiply), and the
-            // grid rows / columns beyond sz are finite numbers that are never stored.  One basic block per 32 points: 32 independent
-            // exponentials for the scheduler (behind per-element masks and mode branches this phase took a sixth of the kernel).
-            auto predict_loop = [&](auto small_tag) __attribute__((always_inline)) {
-                constexpr bool SM = decltype(small_tag)::value;
+            for (int h = 0; h < 2; ++h) {
+                const double gq = res * (((double)(16 * h + lr) + 0.5) / (double)sz - 0.5);
+                gqx[h] = cs * (gq - co0);
+                gqy[h] = cs * (gq - co1);
+            }
+            // No masks in the loop: a point beyond n contributes nothing because its weight is SELECTED to zero (alpha is zero from n
+            // to 16 nt -- identity padding solves to 0 -- but never written beyond: select, do not multiply), and the grid rows / columns
+            // beyond sz are finite numbers that are never stored.  One basic block per 32 points: 32 independent exponentials for the
+            // scheduler (behind per-element masks and mode branches this phase took a sixth of the kernel).
+            auto predict_loop = [&](auto mode_tag) __attribute__((always_inline)) {
+                constexpr int MP = decltype(mode_tag)::value;
                 for (int ibase = 0; ibase < n; ibase += 32) {
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
                         const int i = ibase + 4 * s + lg;
                         const int ic = min(i, W1_NPAD - 1);
-                        const double al = (i < n) ? sf * av[ic] : 0.0;
+                        const double al = (i < n) ? sfp * av[ic] : 0.0;
                         const double xi0 = px0[ic], xi1 = px1[ic];
                         double ea[2], eb[2];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const double dy = gq[h] - xi1, dx = gq[h] - xi0;
-                            ea[h] = SM ? gpc_exp_small(cexp * (dy * dy)) : gpc_exp_neg(cexp * (dy * dy), T);            // Ey[py][i]
-                            eb[h] = (SM ? gpc_exp_small(cexp * (dx * dx)) : gpc_exp_neg(cexp * (dx * dx), T)) * al;     // Ex[px][i] * sf alpha_i
+                            const double dy = gqy[h] - xi1, dx = gqx[h] - xi0;
+                            if constexpr (MP == 0) {
+                                ea[h] = gpc_exp_neg(argc * (dy * dy), T);                 // Ey[py][i]
+                                eb[h] = gpc_exp_neg(argc * (dx * dx), T) * al;            // Ex[px][i] * weight_i
+                            } else {
+                                ea[h] = gpc_expm_poly<MP == 1 ? 7 : 5>(dy * dy);
+                                eb[h] = gpc_expm_poly<MP == 1 ? 7 : 5>(dx * dx) * al;
+                            }
                         }
 #pragma unroll
                         for (int nl = 0; nl < 2; ++nl)
@@ -630,8 +834,9 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     }
                 }
             };
-            if (small_grid) predict_loop(std::true_type{});
-            else predict_loop(std::false_type{});
+            if (mode_p == 2) predict_loop(std::integral_constant<int, 2>{});
+            else if (mode_p == 1) predict_loop(std::integral_constant<int, 1>{});
+            else predict_loop(std::integral_constant<int, 0>{});
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -643,6 +848,8 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     }
         } else {
             // point-wise X* (or a grid wider than 32): one lane per prediction point
+            const double cs = scaled ? g.cs : 1.0, co0 = scaled ? A.x0[o] : 0.0, co1 = scaled ? A.x1[o] : 0.0;
+            const double argc = scaled ? -1.0 : cexp, sfp = g.sfp;
             for (int p = lane; p < m; p += 64) {
                 double q0, q1;
                 if (A.xs0) {
@@ -653,9 +860,14 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     q0 = A.grid_res * (((double)gx + 0.5) / (double)A.grid_sz - 0.5);
                     q1 = A.grid_res * (((double)gy + 0.5) / (double)A.grid_sz - 0.5);
                 }
+                q0 = cs * (q0 - co0);
+                q1 = cs * (q1 - co1);
                 double s_ = 0.0;
-                for (int i = 0; i < n; ++i) s_ += gpc_rbf_neg(sf, cexp, px0[i], px1[i], q0, q1, T) * av[i];
-                fs[p] = s_;
+                for (int i = 0; i < n; ++i) {
+                    const double d0 = px0[i] - q0, d1 = px1[i] - q1;
+                    s_ += gpc_exp_neg(argc * __builtin_fma(d0, d0, d1 * d1), T) * av[i];
+                }
+                fs[p] = sfp * s_;
             }
         }
 #endif
@@ -702,10 +914,16 @@ int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
     a.v_star = nullptr;
     W1Params g;
     g.c_exp = (double)(-0.5f) / a.prm.l_sq;
-    g.pivot_tol = GPC_PIVOT_RTOL * (a.prm.sigmaf_sq + a.prm.noise);
     g.ws = static_cast<double*>(ctx->ws);
     g.linvt = g.ws + (size_t)W1_TRI * MF_IMG * (size_t)grid;
     g.export_factor = v_star ? 1 : 0;
+    const double sf = a.prm.sigmaf_sq;
+    const bool unit = !v_star;                        // unit scale (see the kernel) unless the factor is exported
+    g.cs = sqrt(-g.c_exp);
+    g.noise_u = unit ? a.prm.noise / sf : a.prm.noise;
+    g.pivot_tol = GPC_PIVOT_RTOL * (unit ? 1.0 + a.prm.noise / sf : sf + a.prm.noise);
+    g.sfp = unit ? 1.0 : sf;
+    g.a_out = unit ? 1.0 / sf : 1.0;
     g.stamps = nullptr;
     if (v_star) {
         // Predictive variance (gaussian_process::predict_measurements, /root/reference/src/gaussian_process.cpp:35-43): the slots are the

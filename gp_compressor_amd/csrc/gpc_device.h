@@ -89,6 +89,27 @@ __host__ __device__ static inline double gpc_exp_small(double x)
     return __builtin_fma(x, p, 1.0);
 }
 
+// exp(-t) for 0 <= t <= 2^-5 (DEG 7) / 0 <= t <= 2^-8 (DEG 5): Taylor polynomials with literal coefficients (truncation t^8/8! <= 2.3e-17,
+// t^6/6! <= 4.9e-18: below a tenth of an ulp of the result, which is ~1).  Callers hold coordinates pre-scaled by sqrt(-c), so that the
+// squared distance IS t: distance (4 operations) + 5 or 7 FMAs per kernel value, no multiplication by c (one-wave dense kernel, round 4).
+#define GPC_EXP_TINY_MAX 0.00390625
+template <int DEG>
+__host__ __device__ static inline double gpc_expm_poly(double t)
+{
+    double p;
+    if (DEG == 7) {
+        p = __builtin_fma(t, -1.0 / 5040.0, 1.0 / 720.0);
+        p = __builtin_fma(t, p, -1.0 / 120.0);
+        p = __builtin_fma(t, p, 1.0 / 24.0);
+    } else {
+        p = __builtin_fma(t, -1.0 / 120.0, 1.0 / 24.0);
+    }
+    p = __builtin_fma(t, p, -1.0 / 6.0);
+    p = __builtin_fma(t, p, 0.5);
+    p = __builtin_fma(t, p, -1.0);
+    return __builtin_fma(t, p, 1.0);
+}
+
 __device__ static inline void gpc_exp_table_init(double* T_lds)
 {
     for (int i = threadIdx.x; i < GPC_EXP_TABLE_SIZE; i += blockDim.x) T_lds[i] = c_gpc_exp_table[i];

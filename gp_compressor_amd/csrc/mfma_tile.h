@@ -192,6 +192,76 @@ __device__ __forceinline__ static bool mf_diag_factor(d4 W, double* rsbuf, doubl
     return ok;
 }
 
+// ---- the same factor with CONSTANT lane masks (round 4; the one-wave kernel) -------------------------------------------------------
+// Which lanes form contraction slot q, which lane is the pivot's own column, which rows lie below it: per pivot these are three
+// 64-bit lane masks known at compile time.  mf_diag_factor derives them from the lane id (hoisted by the compiler: 30 live values that
+// spill in the tiled kernels; OPAQUE: re-derived per pivot, ~12 VALU instructions).  Here they are literals in SGPR pairs -- two
+// s_mov_b32 on the scalar unit -- and a select is ONE v_cndmask_b32 per 32-bit half: 4 VALU instructions per pivot instead of ~12,
+// nothing to hoist, nothing to spill.
+__device__ static __forceinline__ int mf_sel32(int v, unsigned long long mask)      // lanes in `mask` keep v, the others get 0
+{
+    int r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(mask));
+    return r;
+}
+__device__ static __forceinline__ double mf_sel64(double v, unsigned long long mask)
+{
+    return __hiloint2double(mf_sel32(__double2hiint(v), mask), mf_sel32(__double2loint(v), mask));
+}
+__device__ static __forceinline__ double mf_one_in(unsigned long long mask, int one_hi)   // 1.0 in the lanes of `mask`, 0.0 elsewhere
+{
+    return __hiloint2double(mf_sel32(one_hi, mask), 0);
+}
+__device__ __forceinline__ static bool mf_diag_factor_c(d4 W, double* rsbuf, double* Linv_out, double* LinvT_out, double pivot_tol, int lane_in)
+{
+    const int one_hi = 0x3FF00000;
+    double rp = mf_rcp(mf_readlane(W[0], 0));
+    double rpv = mf_sel64(rp, 0xFFFEull);                 // lg == 0 && lr > 0
+    double one_q = mf_one_in(0xFFFFull, one_hi);          // lg == 0
+    double ev = mf_one_in(0x1ull, one_hi);                // lane 0
+#pragma unroll
+    for (int c = 0; c < MF_TS - 1; ++c) {
+        const int q = c & 3, r = c >> 2, q1 = (c + 1) & 3, r1 = (c + 1) >> 2;
+        // on the chain: two VALU ops and the MFMA
+        const double a_op = W[r] * rpv;
+        const double b_op = __builtin_fma(W[r], one_q, ev);
+        const d4 Wn = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, W, 0, 0, 1);   // blgp = 1: NEG(A)
+        __builtin_amdgcn_sched_barrier(0);
+        // in the shadow of the MFMA: the reciprocal of the next pivot from the OLD tile (kept alive in its own registers)
+        const double s01 = mf_readlane(W[r], 16 * q + c + 1);      // W[c][c+1]
+        const double s11 = mf_readlane(W[r1], 16 * q1 + c + 1);    // W[c+1][c+1]
+        const double t = s01 * rp;
+        rp = mf_rcp(__builtin_fma(-t, s01, s11));
+        // lanes of slot q1: 16 q1 .. 16 q1 + 15; rows below pivot c + 1: lr > c + 1
+        const unsigned long long slot = 0xFFFFull << (16 * q1);
+        const unsigned long long below = ((0xFFFFull << (c + 2)) & 0xFFFFull) << (16 * q1);
+        rpv = mf_sel64(rp, below);
+        one_q = mf_one_in(slot, one_hi);
+        ev = mf_one_in(1ull << (16 * q1 + c + 1), one_hi);
+        __builtin_amdgcn_sched_barrier(0);
+        W = Wn;
+    }
+    const int lt_ = mf_opaque(lane_in);
+    const int lrt = lt_ & 15, lgt = lt_ >> 4;
+    const int rsel = lrt >> 2;
+    const double pd = rsel == 0 ? W[0] : rsel == 1 ? W[1] : rsel == 2 ? W[2] : W[3];
+    const bool on_diag = (lrt & 3) == lgt;
+    const bool ok = __builtin_amdgcn_ballot_w64(on_diag && !(pd > pivot_tol)) == 0;
+    const double rs = mf_rsqrt(on_diag ? pd : 1.0);
+    if (on_diag) rsbuf[lrt] = rs;       // one wave: LDS operations execute in program order, no barrier needed
+    d4 fin;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = lgt + 4 * r;
+        const double rsr = rsbuf[row];
+        fin[r] = (lrt < row) ? W[r] * rsr : (lrt == row ? rsr : 0.0);
+    }
+    if (LinvT_out) mf_img_store(LinvT_out, lt_, fin);     // C/D registers of L^-1 = operand image of L^-T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Linv_out[mf_img_rc(lgt + 4 * r, lrt)] = fin[r];
+    return ok;
+}
+
 // out[mr] = sum_kk M[mr][kk] * v[kk] for a 16 x 16 matrix stored as an operand image, one thread per row
 __device__ static __forceinline__ double mf_row_dot(const double* img, int mr, const double* v)
 {

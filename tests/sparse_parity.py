@@ -25,7 +25,16 @@ BLOWUP = 5.0            # (c): max|f*| > BLOWUP * max|y| of the patch
 RMSE_TRAIN_FACTOR = 1.02      # (a) the GPU's reconstruction RMSE may exceed the oracle's by 2 %
 PCT_FACTOR = 3.0              # (b) each percentile (50 / 90 / 99) of the GPU's error vs the arbiter <= 3 x the oracle's
 MAX_FACTOR = 10.0             # (b) the worst patch: <= 10 x the oracle's worst (heavy tail: one patch decides it)
-BLOWUP_FACTOR = 3.0           # (c) blow-ups: <= 3 x the oracle's count + 2
+BLOWUP_FACTOR = 3.0           # (c) blow-ups, POOLED counts (>= 4 batches of 32768): <= 3 x the oracle's count + 2
+BLOWUP_P_MIN = 1e-3           # (c) blow-ups, any sample: fail when P(X >= gpu | X ~ Binomial(gpu + oracle, share of the GPU's patches)) < 1e-3
+# Round 4 -- the RATE behind (c), measured before the gate was re-frozen (tools/r4_blowup_rate.py, 8 seeded batches of 32768 x 256 at the
+# reference's default hyper-parameters, C4 shape; gpurun_out/r4/blowup_rate.json -> profiles/r04_blowup_rate.json):
+#   GPU     29 of 262144 = 3.6 per 32768   (per batch 4 3 7 4 0 4 2 5)
+#   oracle  43 of 262144 = 5.4 per 32768   (per batch 1 8 4 6 4 9 6 5)
+#   the binary128 arbiter on every one of those 72 patches: 0 blow-ups; no patch blows up in both fp64 implementations.
+# The GPU does NOT blow up more often than the CPU restatement (one-sided p = 0.96 for "GPU rate > oracle rate"); round 3's "4 against 1"
+# was one batch of Poisson noise.  A one-batch rule of the form gpu <= 3 oracle + 2 fails a correct build about once in a hundred
+# batches at these rates, so the single-batch gate is the two-sample test above and the factor rule is applied to pooled counts only.
 
 
 def _threads():
@@ -152,6 +161,51 @@ def stats(op, off, x0, x1, y, xs0, xs1, f_gpu, ft_gpu, sample, full_oracle=True,
     return out
 
 
+def blowup_p_value(g, g_over, o, o_over):
+    """Two-sample Poisson test, conditional form: given g + o blow-ups in all, each falls on the GPU's side with probability
+    g_over / (g_over + o_over) if the two rates are equal.  Returns P(X >= g) -- small means the GPU blows up more often."""
+    import math
+    n = int(g) + int(o)
+    if n == 0:
+        return 1.0
+    q = g_over / float(g_over + o_over)
+    return float(sum(math.comb(n, k) * q ** k * (1.0 - q) ** (n - k) for k in range(int(g), n + 1)))
+
+
+def blowup_counts(run_gpu, op, P, n, seeds, res, sz, synth):
+    """(c) over several seeded batches.  run_gpu(off, x0, x1, y) -> f* (P, ny, m) of the GPU; the fp64 oracle runs on every patch too.
+    Returns per-seed counts, the pooled counts, the named patches (with the arbiter on each) and the pooled gate."""
+    xs0, xs1 = synth.grid(res, sz)
+    per_seed, named = [], []
+    for seed in seeds:
+        off, x0, x1, y = synth.make_patches(P, n, res=res, seed=seed)
+        f_gpu = run_gpu(off, x0, x1, y)
+        f_or = run_cpu(op, off, x0, x1, y, xs0, xs1, np.arange(P))[0]
+        ymax = np.maximum(np.max(np.abs(y[0].reshape(P, n)), axis=1), 1e-300)
+        r_g = np.max(np.abs(f_gpu), axis=(1, 2)) / ymax
+        r_o = np.max(np.abs(f_or), axis=(1, 2)) / ymax
+        bg, bo = np.where(r_g > BLOWUP)[0], np.where(r_o > BLOWUP)[0]
+        both = np.array(sorted(set(bg.tolist()) | set(bo.tolist())), dtype=np.int64)
+        if len(both):
+            f_hp = run_cpu(op, off, x0, x1, y, xs0, xs1, both, hp=True)[0]
+            for k, i in enumerate(both):
+                named.append({"seed": int(seed), "patch": int(i), "gpu": float(r_g[i]), "oracle": float(r_o[i]),
+                              "arbiter": float(np.max(np.abs(f_hp[k])) / ymax[i])})
+        per_seed.append({"seed": int(seed), "gpu": int(len(bg)), "oracle": int(len(bo)),
+                         "both": int(len(set(bg.tolist()) & set(bo.tolist()))),
+                         "rmse_gpu_vs_oracle": float(np.sqrt(np.mean((f_gpu - f_or) ** 2)))})
+    G, Oc, N = sum(s_["gpu"] for s_ in per_seed), sum(s_["oracle"] for s_ in per_seed), P * len(seeds)
+    p_one = blowup_p_value(G, N, Oc, N)
+    return {"patches_per_batch": P, "batches": len(seeds), "patches": N,
+            "gpu": {"count": G, "per_32768": G * 32768.0 / N, "per_batch": [s_["gpu"] for s_ in per_seed]},
+            "oracle": {"count": Oc, "per_32768": Oc * 32768.0 / N, "per_batch": [s_["oracle"] for s_ in per_seed]},
+            "arbiter_blowups_on_named_patches": int(sum(1 for e in named if e["arbiter"] > BLOWUP)),
+            "pooled_gate": {"rule": f"gpu <= {BLOWUP_FACTOR} x oracle + 2 on the pooled counts and one-sided p >= {BLOWUP_P_MIN}",
+                            "ok": bool(G <= BLOWUP_FACTOR * Oc + 2 and p_one >= BLOWUP_P_MIN)},
+            "two_sample": {"rule": "P(X >= gpu | X ~ Binomial(gpu + oracle, 1/2))", "p_one_sided": p_one},
+            "per_seed": per_seed, "named": named}
+
+
 def gate(s):
     """pass / fail with the reasons: the GPU against the fp64 oracle in the frozen factors above"""
     why = []
@@ -168,8 +222,10 @@ def gate(s):
     if not eg["max"] <= MAX_FACTOR * eo["max"]:
         why.append(f"err_vs_arbiter max gpu {eg['max']:.3g} > {MAX_FACTOR} x oracle {eo['max']:.3g}")
     b = s["blowups"]
-    scale = b["gpu_over"] / max(1, b["oracle_over"])
-    if not b["gpu"] <= BLOWUP_FACTOR * b["oracle"] * scale + 2:
-        why.append(f"blow-ups gpu {b['gpu']} of {b['gpu_over']} > {BLOWUP_FACTOR} x oracle {b['oracle']} of {b['oracle_over']} + 2")
+    p_one = blowup_p_value(b["gpu"], b["gpu_over"], b["oracle"], b["oracle_over"])
+    b["p_gpu_rate_not_above_oracle"] = p_one
+    if p_one < BLOWUP_P_MIN:
+        why.append(f"blow-ups gpu {b['gpu']} of {b['gpu_over']} vs oracle {b['oracle']} of {b['oracle_over']}: one-sided p = {p_one:.2e} < {BLOWUP_P_MIN}")
     return {"ok": not why, "why": why,
-            "factors": {"rmse_train": RMSE_TRAIN_FACTOR, "percentiles": PCT_FACTOR, "max": MAX_FACTOR, "blowups": BLOWUP_FACTOR}}
+            "factors": {"rmse_train": RMSE_TRAIN_FACTOR, "percentiles": PCT_FACTOR, "max": MAX_FACTOR,
+                        "blowups": f"two-sample one-sided p >= {BLOWUP_P_MIN} (pooled batches: also gpu <= {BLOWUP_FACTOR} x oracle + 2)"}}

@@ -177,7 +177,8 @@ def test_stale_class_size_hint_leaves_no_patch_behind(gp):
     assert np.max(np.abs(f.cpu().numpy() - f_ref.reshape(v.P, m))) <= 1e-9 * np.max(np.abs(f_ref))
     # the rewrite: same points, same P, another partition -- the small class shrinks to a handful, most patches move up a class
     new_off = np.round(np.arange(v.P + 1) * (v.n_total / v.P)).astype(np.int32)
-    new_off[3] = new_off[2] + 40                                   # (keep a few small ones so that every class list is non-empty)
+    for q in (3, 40, 90):                                           # (keep a few small ones so that every class list is non-empty)
+        new_off[q] = new_off[q - 1] + 230                           # patch q - 1: 230 points, patch q: ~298
     new_cnt = np.diff(new_off)
     assert new_cnt.min() > 0 and new_cnt.max() <= v.n_max and (new_cnt <= 256).sum() < (cnt <= 256).sum() - 5
     assert ctx.lib.gpc_dev_memcpy(ctx.h, v.off, new_off.ctypes.data, new_off.nbytes, 1) == 0

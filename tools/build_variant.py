@@ -13,9 +13,7 @@ CSRC = os.path.join(ROOT, "gp_compressor_amd", "csrc")
 
 def main():
     name, unit, flags = sys.argv[1], sys.argv[2], sys.argv[3:]
-    sys.path.insert(0, ROOT)
-    from gp_compressor_amd import build as b
-    b.build()                                                   # the shipped objects are current
+    # (the other units come from the objects of the last regular build as they are: a variant never touches the shipped library)
     src = os.path.join(CSRC, unit)
     obj = os.path.join(CSRC, os.path.splitext(unit)[0] + f".{name}.o")
     hipcc = "/opt/rocm/bin/hipcc"
