@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
         lg = lane >> 4;                                                                                              \
     } while (0)
     const int m = A.m;
-    const double sf = A.prm.sigmaf_sq, cexp = g.c_exp, noise = A.prm.noise;
+    const double sf = A.prm.sigmaf_sq, cexp = g.c_exp;
     const bool dbl = A.prm.ref_double_noise != 0;
     // ONE patch per workgroup and one factor slot per patch (no persistent patch loop: hipcc hoists every loop-invariant value of
     // the body -- lane masks, addresses, grid constants -- in front of such a loop and then spills them: 350 VGPRs in that form)
