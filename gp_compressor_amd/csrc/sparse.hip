@@ -266,6 +266,20 @@ __device__ static __forceinline__ size_t sp_tri_at(int i, int j, int ld)
 {
     return i >= j ? (size_t)i + (size_t)j * ld : (size_t)j + (size_t)i * ld;
 }
+// PACKED lower triangle (round 4: the state of a patch resident in LDS, sparse_add_kernel<.., RES>): column j holds its rows j .. ld - 1
+// back to back, so element (i, j), i >= j, sits at  j ld - j (j - 1) / 2 + (i - j);  ld (ld + 1) / 2 doubles per matrix -- 41 KB at the
+// reference's default capacity of 100, both matrices in half of a CU's LDS.  PK = false: the strided layout of the state in HBM.
+template <bool PK>
+__device__ static __forceinline__ size_t sp_at(int i, int j, int ld)        // i >= j
+{
+    if (PK) return (size_t)(j * ld - ((j * (j - 1)) >> 1) + (i - j));
+    return (size_t)i + (size_t)j * ld;
+}
+template <bool PK>
+__device__ static __forceinline__ size_t sp_sym_at(int i, int j, int ld)    // element (i, j) of the symmetric matrix out of its lower triangle
+{
+    return i >= j ? sp_at<PK>(i, j, ld) : sp_at<PK>(j, i, ld);
+}
 // first column of wave q's share (of nw = 4, 2 or 1 waves): equal areas of the lower triangle, 1 - sqrt(1 - q / nw), in multiples of SP_TB
 __device__ static __forceinline__ int sp_tri_bound(int nb, int q, int nw)
 {
@@ -302,7 +316,7 @@ __device__ static __forceinline__ double sp_row_reduce4(double x0, double x1, do
 // the column -- the same lane every time, in program order: deterministic.  All 8 + 8 loads of a trip come first.
 // MODE bits: 1 apply f(i, j, c, q) and store C | 2 store Q too | 4 mat-vecs with kv: row parts to prow [4][2][lv], column parts
 // to pcol [2][lv] | 8 Q is neither read nor written.
-template <int MODE, class F>
+template <int MODE, bool PK = false, class F>
 __device__ static inline void sp_tri_pass(double* C, double* Q, int ld, int lv, int nb, const double* kv, double* prow, double* pcol, F f)
 {
     constexpr bool UPD = (MODE & 1) != 0, WQ = (MODE & 2) != 0, MV = (MODE & 4) != 0, NOQ = (MODE & 8) != 0;
@@ -343,7 +357,7 @@ __device__ static inline void sp_tri_pass(double* C, double* Q, int ld, int lv, 
 #pragma unroll
                 for (int s_ = 0; s_ < 2; ++s_) {
                     const int jc = s_ ? jbc : jac;
-                    at[2 * t + s_] = (ic[t] < jc ? jc : ic[t]) + jc * ld;
+                    at[2 * t + s_] = (int)sp_at<PK>(ic[t] < jc ? jc : ic[t], jc, ld);
                     c[2 * t + s_] = C[at[2 * t + s_]];
                     q[2 * t + s_] = NOQ ? 0.0 : Q[at[2 * t + s_]];
                 }
@@ -399,7 +413,7 @@ __device__ static inline void sp_tri_pass(double* C, double* Q, int ld, int lv, 
 }
 
 // delete_bv(loc): sparse_gp.hpp:252-295 / sparse_gp_field.hpp:219-263.  b is workgroup-uniform; returns b-1.
-template <int RB, bool TRI = false>
+template <int RB, bool TRI = false, bool PK = false>
 __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_bug, double* Cstar, double* Qstar,
                                    double* Crep, double* Qrep, bool tri_p = false)
 {
@@ -407,11 +421,11 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
     const int tid = threadIdx.x, ld = S.ld, ldm = S.ldm, last = b - 1, ny = S.ny;
     double alphastar[3];
     for (int c = 0; c < ny; ++c) alphastar[c] = S.alpha[c * ld + loc];
-    const double cstar = S.C[loc + (size_t)loc * ldm];
-    const double qstar = S.Q[loc + (size_t)loc * ldm];
+    const double cstar = S.C[sp_at<PK>(loc, loc, ldm)];
+    const double qstar = S.Q[sp_at<PK>(loc, loc, ldm)];
     for (int i = tid; i < b; i += SP_NTH) {
         if (tri) {                                   // columns of the symmetric matrices out of their lower triangles
-            const size_t al = sp_tri_at(i, loc, ldm), aa = sp_tri_at(last, i, ldm);
+            const size_t al = sp_sym_at<PK>(i, loc, ldm), aa = sp_sym_at<PK>(last, i, ldm);
             Cstar[i] = S.C[al];
             Qstar[i] = S.Q[al];
             Crep[i] = S.C[aa];
@@ -434,7 +448,7 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
     for (int i = tid; i < b; i += SP_NTH) {
         const double cr = Crep[i], qr = Qrep[i];
         if (tri) {
-            const size_t al = sp_tri_at(i, loc, ldm);
+            const size_t al = sp_sym_at<PK>(i, loc, ldm);
             S.C[al] = cr;
             S.Q[al] = qr;
         } else {
@@ -467,7 +481,7 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
         c += qq - cc;
         q -= qq;
     };
-    if (tri) sp_tri_pass<1 | 2>(S.C, S.Q, ldm, ld, nb, nullptr, nullptr, nullptr, downdate);
+    if (tri) sp_tri_pass<1 | 2, PK>(S.C, S.Q, ldm, ld, nb, nullptr, nullptr, nullptr, downdate);
     else sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, downdate);
     __syncthreads();
     return nb;
@@ -482,7 +496,7 @@ __device__ static int sp_delete_bv(const SpState& S, int b, int loc, int field_b
 // in the same order as the two-pass form, so the result is the same to the last bit; only the intermediate (b+1) x (b+1)
 // matrices never reach memory.  b == capacity on entry and on return.
 // When the coordinates of the NEXT point are known (nxt != nullptr) the pass also forms that point's mat-vecs (sp_rmw_cq_next).
-template <int RB, bool TRI = false>
+template <int RB, bool TRI = false, bool PK = false>
 __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, double gamma, const double* qv, double px0, double px1,
                                             int field_bug, const double* ck, double* eh, double* sv, double* Cstar, double* Qstar,
                                             double* Crep, double* Qrep, double* anew, double* sval, int* sidx,
@@ -509,7 +523,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
     for (int i = tid; i <= b; i += SP_NTH) {
         double a2 = 0.0;
         for (int c = 0; c < ny; ++c) { const double a = anew[c * ld + i]; a2 += a * a; }
-        const double c0 = (i < b) ? S.C[i + (size_t)i * ldm] : 0.0, q0 = (i < b) ? S.Q[i + (size_t)i * ldm] : 0.0;
+        const double c0 = (i < b) ? S.C[sp_at<PK>(i, i, ldm)] : 0.0, q0 = (i < b) ? S.Q[sp_at<PK>(i, i, ldm)] : 0.0;
         const double cd = c0 + (rr * sv[i]) * sv[i], qd = q0 + (ig * eh[i]) * eh[i];
         const double score = a2 / (qd + cd);
         if (!have || score < best) { best = score; loc = i; have = true; }
@@ -520,7 +534,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
     // columns loc and last of the updated matrices (delete_bv :259-278)
     for (int i = tid; i <= b; i += SP_NTH) {
         const bool old = (i < b) && (loc < b);
-        const size_t al = tri ? sp_tri_at(old ? i : 0, old ? loc : 0, ldm) : (size_t)i + (size_t)loc * ldm;
+        const size_t al = tri ? sp_sym_at<PK>(old ? i : 0, old ? loc : 0, ldm) : (size_t)i + (size_t)loc * ldm;
         const double c0 = old ? S.C[al] : 0.0, q0 = old ? S.Q[al] : 0.0;
         Cstar[i] = c0 + (rr * sv[i]) * sv[loc];
         Qstar[i] = q0 + (ig * eh[i]) * eh[loc];
@@ -573,10 +587,10 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
         const double n0 = nxt[0], n1 = nxt[1];
         for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
         __syncthreads();
-        if (tri) sp_tri_pass<1 | 2 | 4>(S.C, S.Q, ldm, ld, nb, kvn, pnext, pnext_col, element);
+        if (tri) sp_tri_pass<1 | 2 | 4, PK>(S.C, S.Q, ldm, ld, nb, kvn, pnext, pnext_col, element);
         else sp_rmw_cq_next<true, RB>(S.C, S.Q, ldm, ld, nb, kvn, pnext, element);
     } else {
-        if (tri) sp_tri_pass<1 | 2>(S.C, S.Q, ldm, ld, nb, nullptr, nullptr, nullptr, element);
+        if (tri) sp_tri_pass<1 | 2, PK>(S.C, S.Q, ldm, ld, nb, nullptr, nullptr, nullptr, element);
         else sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, element);
     }
     __syncthreads();
@@ -615,9 +629,15 @@ struct SpAddParams {
 // PROBIT: the probit functor (sqrt, erf, exp: ~450 instructions and their constants) is compiled in only where it is used -- in the
 // Gaussian instantiation, the reference's production path, its registers go to the point loop
 // TRI: the triangular mode of the four-wave shape (see sp_tri_pass)
-template <bool SMALL, bool PROBIT = false, bool TRI = false>
+// RES (round 4; implies TRI): the lower triangles of C and Q of the patch in flight are RESIDENT IN LDS, packed (sp_at<true>), loaded once
+// when the patch enters the kernel and written back (both triangles) once when it leaves -- the add call moves 16 b^2 bytes per patch instead
+// of 16 b^2 per POINT.  Fits while 2 x (capacity + 1)(capacity + 2) / 2 doubles + the vectors stay within the CU's 160 KB: capacity <= 120,
+// which covers the reference's default of 100 (/root/reference/src/sparse_gp.h:48).  One workgroup of four waves per CU.  Every patch runs
+// the triangular passes (whatever basis it arrives with); same element updates, same summation order as the HBM-resident triangular mode.
+template <bool SMALL, bool PROBIT = false, bool TRI = false, bool RES = false>
 __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse_add_kernel(SpAddParams A)   // <= 256 VGPRs (128 for the small-basis phase)
 {
+    static_assert(!RES || (TRI && !SMALL && !PROBIT), "the LDS-resident mode is a form of the triangular mode");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ldg = A.ld, ny = A.ny;               // ldg: strides of the state in global memory
@@ -645,6 +665,9 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
     double* Ql = Cl + SP_BMAX * SP_BMAX;
     double* part_col = BVL + 2 * ld;               // TRI: column parts of the mat-vecs [2][ld], this point's and the next one's
     double* pnext_col = part_col + 2 * ld;
+    const int ldp = A.prm.capacity + 1;            // RES: leading dimension of the packed triangles
+    double* Cp = pnext_col + 2 * ld;               // RES: C, Q lower triangles, packed [ldp (ldp + 1) / 2]
+    double* Qp = Cp + (ldp * (ldp + 1)) / 2;
     gpc_exp_table_init(T);
 
     const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, eps_tol = A.prm.eps_tol;
@@ -670,20 +693,20 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
         }
         const int o = A.off[patch], n = A.off[patch + 1] - o;
         SpState S;
-        S.ld = ld; S.ny = ny; S.ldm = ldm;
+        S.ld = ld; S.ny = ny; S.ldm = RES ? ldp : ldm;
         double* const alphag = A.alpha + (size_t)patch * ny * ldg;
         double* const BVg = A.BV + (size_t)patch * ldg * 2;
         double* const Cg = A.C + (size_t)patch * ldg * ldg;
         double* const Qg = A.Q + (size_t)patch * ldg * ldg;
         S.alpha = alphaL;
-        S.C = SMALL ? Cl : Cg;
-        S.Q = SMALL ? Ql : Qg;
+        S.C = RES ? Cp : SMALL ? Cl : Cg;
+        S.Q = RES ? Qp : SMALL ? Ql : Qg;
         S.BV = BVL;
         int b = A.b[patch];
         int st = A.stat[patch];
         // the triangular passes pay from a mid-sized basis on (their per-block reductions and the uneven shares of the four waves cost
         // more than half a stream of a small matrix saves): decided per patch and call from the basis it arrives with
-        [[maybe_unused]] const bool tri = TRI && b >= A.tri_min;
+        [[maybe_unused]] const bool tri = RES || (TRI && b >= A.tri_min);
         const int it0 = A.start_it ? A.start_it[patch] : 0;     // an earlier phase (rows / small-basis) already took these
         __syncthreads();
         if (SMALL && (b > SP_BMAX || n == 0)) {          // too large from the start (or nothing to do): all of it is the regular kernel's
@@ -701,6 +724,15 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                 const int i = e % b, j = e / b;
                 Cl[i + j * SP_BMAX] = Cg[i + (size_t)j * ldg];
                 Ql[i + j * SP_BMAX] = Qg[i + (size_t)j * ldg];
+            }
+        }
+        if (RES) {                                       // the lower triangles come on chip (the upper ones are redundant: every producer mirrors)
+            for (int e = tid; e < b * b; e += SP_NTH) {
+                const int i = e % b, j = e / b;
+                if (i >= j) {
+                    Cp[sp_at<true>(i, j, ldp)] = Cg[i + (size_t)j * ldg];
+                    Qp[sp_at<true>(i, j, ldp)] = Qg[i + (size_t)j * ldg];
+                }
             }
         }
         int it_end = n;                                  // SMALL: where this phase stopped
@@ -763,7 +795,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
             const double* pp = from_prev ? pnext : part;
             [[maybe_unused]] const double* pc = from_prev ? pnext_col : part_col;
             if (TRI && tri && !from_prev) {
-                sp_tri_pass<4>(S.C, S.Q, ldm, ld, b, kv, part, part_col, [](int, int, double&, double&) {});
+                sp_tri_pass<4, RES>(S.C, S.Q, S.ldm, ld, b, kv, part, part_col, [](int, int, double&, double&) {});
             } else if (!from_prev && SMALL && b <= 32) {
                 // one wave, small basis: the four quarters side by side (see sp_rmw_cq_next)
                 const int shift = b <= 16 ? 4 : 5;
@@ -846,11 +878,11 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     for (int i = tid; i < b; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
                     auto proj = [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; };
-                    if (TRI && tri) sp_tri_pass<1 | 4>(S.C, S.Q, ldm, ld, b, kvn, pnext, pnext_col, proj);
+                    if (TRI && tri) sp_tri_pass<1 | 4, RES>(S.C, S.Q, S.ldm, ld, b, kvn, pnext, pnext_col, proj);
                     else sp_rmw_cq_next<false, RB>(S.C, S.Q, ldm, ld, b, kvn, pnext, proj);
                     have_next = true;
                 } else if (TRI && tri) {
-                    sp_tri_pass<1 | 8>(S.C, S.Q, ldm, ld, b, nullptr, nullptr, nullptr, [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; });
+                    sp_tri_pass<1 | 8, RES>(S.C, S.Q, S.ldm, ld, b, nullptr, nullptr, nullptr, [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; });
                 } else {
                     const int nn = b * b;
                     for (int e0 = tid; e0 < nn; e0 += SP_NTH * RB) {     // loads first, see sp_rmw_cq
@@ -882,7 +914,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     nx[0] = nx0;
                     nx[1] = nx1;
                 }
-                b = sp_full_update_delete<RB, TRI>(S, b, rr, gamma, qv, px0, px1, A.prm.ref_field_delete_bug, ck, eh, sv, Cstar, Qstar, Crep,
+                b = sp_full_update_delete<RB, TRI, RES>(S, b, rr, gamma, qv, px0, px1, A.prm.ref_field_delete_bug, ck, eh, sv, Cstar, Qstar, Crep,
                                                Qrep, part + 4 * ld, sval, sidx, more ? nx : nullptr, kvn, pnext, sf, A.c_exp, T, pnext_col, tri);
                 have_next = more;
                 dec = 1 | 2;
@@ -915,11 +947,11 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     const double n0 = nx0, n1 = nx1;
                     for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
-                    if (TRI && tri) sp_tri_pass<1 | 2 | 4>(S.C, S.Q, ldm, ld, nb, kvn, pnext, pnext_col, grow);
+                    if (TRI && tri) sp_tri_pass<1 | 2 | 4, RES>(S.C, S.Q, S.ldm, ld, nb, kvn, pnext, pnext_col, grow);
                     else sp_rmw_cq_next<true, RB>(S.C, S.Q, ldm, ld, nb, kvn, pnext, grow);
                     have_next = true;
                 } else {
-                    if (TRI && tri) sp_tri_pass<1 | 2>(S.C, S.Q, ldm, ld, nb, nullptr, nullptr, nullptr, grow);
+                    if (TRI && tri) sp_tri_pass<1 | 2, RES>(S.C, S.Q, S.ldm, ld, nb, nullptr, nullptr, nullptr, grow);
                     else sp_rmw_cq<RB>(S.C, S.Q, ldm, nb, grow);
                 }
                 b = nb;
@@ -934,13 +966,13 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                 for (int i = tid; i < b; i += SP_NTH) {
                     double a2 = 0.0;
                     for (int c = 0; c < ny; ++c) { const double a = S.alpha[c * ld + i]; a2 += a * a; }
-                    const double score = a2 / (S.Q[i + (size_t)i * ldm] + S.C[i + (size_t)i * ldm]);
+                    const double score = a2 / (S.Q[sp_at<RES>(i, i, S.ldm)] + S.C[sp_at<RES>(i, i, S.ldm)]);
                     if (!have || score < best) { best = score; loc = i; have = true; }
                 }
                 if (!have) best = __builtin_inf();
                 sp_block_argmin(best, loc, sval, sidx);
                 if (loc < 0 || loc >= b) loc = 0;          // all-NaN scores: the reference keeps minloc = 0
-                b = sp_delete_bv<RB, TRI>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep, tri);
+                b = sp_delete_bv<RB, TRI, RES>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep, tri);
                 have_next = false;
                 if (((dec >> 1) & 7) < 7) dec += 2;
             }
@@ -952,7 +984,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     int loc = 0x7fffffff;
                     bool have = false;
                     for (int i = tid; i < b; i += SP_NTH) {
-                        const double score = (double)1.0f / S.Q[i + (size_t)i * ldm];
+                        const double score = (double)1.0f / S.Q[sp_at<RES>(i, i, S.ldm)];
                         if (!have || score < best) { best = score; loc = i; have = true; }
                     }
                     if (!have) best = __builtin_inf();
@@ -963,7 +995,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     if (loc < 0 || loc >= b) loc = 0;
                     minscore = best;
                     if (minscore < (double)1e-9f) {
-                        b = sp_delete_bv<RB, TRI>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep, tri);
+                        b = sp_delete_bv<RB, TRI, RES>(S, b, loc, A.prm.ref_field_delete_bug, Cstar, Qstar, Crep, Qrep, tri);
                         have_next = false;              // the matrices and the basis changed after the pass
                         if (((dec >> 4) & 7) < 7) dec += 16;
                     }
@@ -991,7 +1023,21 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
             }
             if (tid == 0) A.done_it[patch] = it_end;
         }
-        if (TRI && tri) {
+        if (RES) {
+            // the state goes back to HBM, both triangles (every other kernel reads full matrices): 16 b^2 bytes once per call
+            for (int e = tid; e < b * b; e += SP_NTH) {
+                const int i = e % b, j = e / b;
+                if (i >= j) {
+                    const double cv_ = Cp[sp_at<true>(i, j, ldp)], qv_ = Qp[sp_at<true>(i, j, ldp)];
+                    Cg[i + (size_t)j * ldg] = cv_;
+                    Qg[i + (size_t)j * ldg] = qv_;
+                    if (i > j) {
+                        Cg[j + (size_t)i * ldg] = cv_;
+                        Qg[j + (size_t)i * ldg] = qv_;
+                    }
+                }
+            }
+        } else if (TRI && tri) {
             // the upper triangles from the lower ones: every other kernel (and the full mode) reads full matrices.  16 x 16 tiles, one
             // per 16 lanes and trip, read along their columns (once per call: 16 b^2 bytes against 16 b^2 per POINT)
             const int nt_ = (b + 15) >> 4, sub = tid >> 4, r = tid & 15;
@@ -1890,10 +1936,22 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     // the four-wave shape: tests).  Measured at capacity 100: 465 k vs 268 k patches/s in the small-basis regime, 75 k vs 68 k
     // with a full basis; at capacity 128 two waves lose (49 k vs 54 k).
     const int cap_ = g->prm.capacity;
-    const int nth = (cap_ <= 0 || getenv("GPC_SPARSE_WIDE")) ? SP_THREADS : cap_ <= 64 ? 64 : cap_ <= 100 ? 128 : SP_THREADS;
+    const int nth0 = (cap_ <= 0 || getenv("GPC_SPARSE_WIDE")) ? SP_THREADS : cap_ <= 64 ? 64 : cap_ <= 100 ? 128 : SP_THREADS;
     // four or two waves per patch (capacity > 64): the triangular mode (sp_tri_pass) -- half the stream of C and Q; GPC_SPARSE_FULL=1 keeps the full passes
-    const bool tri = nth >= 128 && A.prm.noise_model == GPC_NOISE_GAUSSIAN && !getenv("GPC_SPARSE_FULL");
-    const size_t lds = sp_add_lds(g->ld, tri);
+    const bool tri = nth0 >= 128 && A.prm.noise_model == GPC_NOISE_GAUSSIAN && !getenv("GPC_SPARSE_FULL");
+    // Round 4: 64 < capacity <= 120 (the reference's default is 100, /root/reference/src/sparse_gp.h:48): the lower triangles of C and Q
+    // of the patch in flight stay in LDS, packed -- four waves per patch, one patch per CU (sparse_add_kernel<.., RES>; GPC_SPARSE_NO_RES=1
+    // keeps the HBM-resident triangular mode of the two-wave shape)
+    const size_t lds_res = sp_add_lds(g->ld, true) + sizeof(double) * (size_t)(cap_ + 1) * (size_t)(cap_ + 2);
+    // MEASURED AND NOT THE DEFAULT (GPC_SPARSE_RES=1 selects it; 8192 patches x 256 points, basis-filling kernel, same box): capacity 100:
+    // 55 k patches/s against 111 k for the HBM-resident two-wave shape, capacity 120: 54 k against 83 k, capacity 80 (two workgroups per
+    // CU fit): 125 k against 141 k.  A point costs ~16 us of one workgroup either way (the pass is ~40 instructions per element and the
+    // ~20 barrier-separated phases of a point do not overlap inside ONE workgroup), and with the state in LDS a CU hosts one patch where
+    // the HBM-resident shape hosts four: the stream it removes was already hidden.  States bit-identical to the HBM-resident mode
+    // (tests/test_sparse_gpu.py::test_sparse_lds_resident_mode_is_bit_identical).
+    const bool res = tri && cap_ > 64 && lds_res <= 160u * 1024u && getenv("GPC_SPARSE_RES") && !getenv("GPC_SPARSE_NO_RES") && !getenv("GPC_SPARSE_WIDE");
+    const int nth = res ? SP_THREADS : nth0;
+    const size_t lds = res ? lds_res : sp_add_lds(g->ld, tri);
     A.tri_min = 32;   // (measured at the C4 size: 32 -> 62.0 k patches/s, 96 -> 59.0 k, 160 -> 51.1 k; full passes 42.0 k; the defaults regime is level)
     if (const char* e = getenv("GPC_SPARSE_TRI_MIN")) A.tri_min = atoi(e);      // (diagnostic: where the triangular passes start to pay)
     int per_cu = (int)((160u * 1024u) / lds);
@@ -1943,7 +2001,12 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
         A.done_it = nullptr;
     }
     if (!gauss) hipLaunchKernelGGL((sparse_add_kernel<false, true>), dim3(grid), dim3(nth), lds, ctx->stream, A);
-    else if (tri) hipLaunchKernelGGL((sparse_add_kernel<false, false, true>), dim3(grid), dim3(nth), lds, ctx->stream, A);
+    else if (res) {
+        // per call: the attribute is per device, and a process may hold contexts on several GPUs (idempotent, host-side only)
+        GPC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_add_kernel<false, false, true, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((sparse_add_kernel<false, false, true, true>), dim3(grid), dim3(nth), lds, ctx->stream, A);
+    } else if (tri) hipLaunchKernelGGL((sparse_add_kernel<false, false, true>), dim3(grid), dim3(nth), lds, ctx->stream, A);
     else hipLaunchKernelGGL((sparse_add_kernel<false, false>), dim3(grid), dim3(nth), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;

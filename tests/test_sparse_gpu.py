@@ -778,6 +778,57 @@ def test_sparse_triangular_mode(gp, oracle, ny, cap, kernel, monkeypatch):
     else:
         assert e_tri <= 3.0 * e_full + 1e-9, (e_tri, e_full, err)
 
+@pytest.mark.parametrize("ny,cap,kernel", [(1, 100, "fill"), (1, 80, "mixed"), (3, 100, "mixed"), (1, 100, "geo"), (1, 120, "fill"), (1, 100, "default"),
+                                           (1, 70, "fill")])
+def test_sparse_lds_resident_mode_is_bit_identical(gp, ny, cap, kernel, monkeypatch):
+    """Round 4: for 64 < capacity <= 120 (the reference's default is 100, /root/reference/src/sparse_gp.h:48) the regular kernel keeps the
+    lower triangles of C and Q of the patch in flight packed in LDS (sparse_add_kernel<.., RES>): loaded once per add call, written back
+    once.  It applies the element updates of the triangular mode in the same order with the same wave shares, so against the HBM-resident
+    triangular mode in the same four-wave shape (GPC_SPARSE_NO_RES=1 GPC_SPARSE_WIDE=1, triangular from the first vector on) the states,
+    sizes, status words and per-point decisions are the same BIT FOR BIT -- over two add calls (the second on the state the first left in
+    HBM), ragged patches, capacity and geometric deletions, three channels; and the matrices that come back are exactly symmetric."""
+    capi, ctx = gp
+    res, P, n = 0.15, 24, 256
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=77 + cap, ragged=True, ny=ny)
+    perm = synth.sattolo_perms(off, seed=6)
+    kw = dict(capacity=cap)
+    if kernel == "fill":
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 8) ** 2, noise=1e-4)
+    if kernel == "geo":
+        kw.update(sigmaf_sq=1.0, l_sq=(res * 0.6) ** 2, noise=1e-6, eps_tol=1e-14)
+    if kernel == "mixed":
+        kw.update(sigmaf_sq=1.0, l_sq=(res / 6) ** 2, noise=1e-2 if ny == 1 else 1.0, eps_tol=1e-3)
+    p = capi.default_params_sparse(ny, **kw)
+    xs0, xs1 = synth.grid(res, 20)
+    monkeypatch.setenv("GPC_SPARSE_TRI_MIN", "0")
+    monkeypatch.setenv("GPC_SPARSE_RES", "1")       # (measured slower than the HBM-resident shape and not the default: DESIGN 5.4c)
+    out = []
+    for hbm in (False, True):
+        if hbm:
+            monkeypatch.setenv("GPC_SPARSE_NO_RES", "1")
+            monkeypatch.setenv("GPC_SPARSE_WIDE", "1")
+        g = capi.Sparse(ctx, p, P, ny)
+        st1, tr1 = g.add(off, x0, x1, y, perm, trace=True)
+        st2, tr2 = g.add(off, x0, x1, y, trace=True)
+        f, sg, _ = g.predict(xs0, xs1)
+        out.append((st1, st2, tr1, tr2, g.sizes(), f, sg, *g.state()))
+        g.close()
+    a, b_ = out
+    if kernel in ("fill", "mixed"):
+        assert a[4].max() > 32                      # these patches did reach the regular kernel with a large basis
+    for q in range(7):
+        assert np.array_equal(a[q], b_[q], equal_nan=True), q
+    for i in range(P):
+        nb = int(a[4][i])
+        for q in (7, 8, 9, 10):
+            x_, y_ = a[q][i], b_[q][i]
+            x_, y_ = (x_[:, :nb], y_[:, :nb]) if q == 7 else (x_[:nb, :nb], y_[:nb, :nb]) if q in (8, 9) else (x_[:nb], y_[:nb])
+            assert np.array_equal(x_, y_, equal_nan=True), (i, q)
+        if nb > 24:
+            C, Q = a[8][i][:nb, :nb], a[9][i][:nb, :nb]
+            assert np.array_equal(C, C.T, equal_nan=True) and np.array_equal(Q, Q.T, equal_nan=True), i
+
+
 # ------------------------------------------------------------------ the tolerances, stated against the exact recursion
 
 def _arbiter_batch(oracle, kw, off, x0, x1, y, perm, xs0, xs1, cap):
