@@ -335,6 +335,46 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
         else w1_gram_row<0, CNT, DIAG>(v, px0, px1, T, sf, scale_sf, cexp, noise_u, dbl, n, r, c0, lr, lg);            \
     } while (0)
 
+        // One position of the backward solve's stream (see the solve below): column kk from the end (k = nt - 1 - kk) has kk tiles, rows
+        // k + 1 + t, then its L_kk^-T.  A tile adds its part of w_k = sum_{i>k} L_ik^T alpha_i on the VALU (the products contract over the
+        // ROW index, which the image layout cannot feed to an MFMA); L_kk^-T closes the column: transposing DPP row reduction of w_k,
+        // alpha_k = L_kk^-T (z_k - w_k) as four MFMAs, alpha_k into zv in place of z_k.
+        auto bw_step = [&](auto P, const d4 img, d4& pa) __attribute__((always_inline)) {
+            constexpr int q = decltype(P)::value;
+            constexpr int kk = w1_stream_col(q), t = q - kk * (kk + 1) / 2;
+            if (kk < nt) {
+                const int k = nt - 1 - kk;
+                if constexpr (t < kk) {
+                    const double a_ = zv[MF_TS * (k + 1 + t) + lr];
+                    pa += img * a_;                                      // the image of L_ik: [l & 15][(l >> 4) + 4 s]
+                } else {
+                    d4 ub = d4{0.0, 0.0, 0.0, 0.0};
+                    if constexpr (kk > 0) {
+                        const double tot = mf_row_reduce4(pa, lr);       // lanes lr = 0, 4, 8, 12 hold components 0 .. 3
+                        if ((lr & 3) == 0) wsc[lg + 4 * (lr >> 2)] = tot;
+                        W1_LDS_SYNC();
+                        if (lr == 0) {
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[MF_TS * k + lg + 4 * q4] - wsc[lg + 4 * q4];
+                        }
+                    } else {
+                        if (lr == 0) {
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[MF_TS * k + lg + 4 * q4];
+                        }
+                    }
+                    const d4 al = w1_trsm(img, ub);                      // lanes lr = 0: alpha[16 k + (l >> 4) + 4 r]
+                    W1_LDS_SYNC();
+                    if (lr == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zv[MF_TS * k + lg + 4 * r] = al[r];
+                    }
+                    W1_LDS_SYNC();
+                    pa = d4{0.0, 0.0, 0.0, 0.0};
+                }
+            }
+        };
+        constexpr int NLAST = W1_C * (W1_C + 1) / 2;   // stream positions of the last block: its six tiles and four L_cc^-T
         bool bad = false;
         W1_STAMP(0);
         // ---- tiled left-looking Cholesky, four tile columns (k .. k+3) per step ----
@@ -390,8 +430,6 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             W1_BLOCK_INIT(0, nb0, false);
         }
 #endif
-        d4 LbK[W1_C * (W1_C - 1) / 2];            // W1_LASTRES: the last step's strictly lower block tiles, kept for the backward solve
-                                                  // (assigned on the loop's exit edge only)
         const bool lastres = W1_LASTRES && (nt & 3) == 0 && !g.export_factor;
         W1_STAMP(1);
         for (int k = 0;; k += W1_C) {                                      // (left by `break` at the last step)
@@ -449,8 +487,14 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
             // (W1_LASTRES: the last step's block never reaches the workspace -- its tiles go into the backward solve as registers, its
             // L_cc^-T images are read back transposed from the L_cc^-1 images in LDS)
             const bool keep = lastres && last_step;
+            // (W1_LASTRES_NOSTORE: the block's tiles and L_cc^-T are not even written -- 10 image writes less, but the conditional stores
+            // cost the chain 100 spilled VGPRs; by default only the READS of the backward solve go)
+#ifndef W1_LASTRES_NOSTORE
+#define W1_LASTRES_NOSTORE 0
+#endif
+            const bool skip_store = W1_LASTRES_NOSTORE && keep;
 #if W1_CMASK
-#define W1_DIAG(Wt, c_) mf_diag_factor_c(Wt, rsbuf, LinvC + (c_) * MF_IMG, keep ? nullptr : LinvTg + (size_t)(k + (c_)) * MF_IMG, ptol, lane)
+#define W1_DIAG(Wt, c_) mf_diag_factor_c(Wt, rsbuf, LinvC + (c_) * MF_IMG, skip_store ? nullptr : LinvTg + (size_t)(k + (c_)) * MF_IMG, ptol, lane)
 #else
 #define W1_DIAG(Wt, c_) mf_diag_factor<true>(Wt, rsbuf, LinvC + (c_) * MF_IMG, LinvTg + (size_t)(k + (c_)) * MF_IMG, ptol, lane)
 #endif
@@ -468,7 +512,7 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                         const d4 lvc = mf_img_load(LinvC + c * MF_IMG, mf_opaque(lane));
                         const d4 L = w1_trsm(lvc, Tt);                     // operand image of L_(k+i)(k+c)
                         Lb[i * (i - 1) / 2 + c] = L;
-                        if (!keep) W1_STORE_TILE(Lt + W1_TILE(k + i, k + c), lane, L);
+                        if (!skip_store) W1_STORE_TILE(Lt + W1_TILE(k + i, k + c), lane, L);
                     }
                     d4 Dii = tacc[i * (i + 1) / 2 + i];
 #pragma unroll
@@ -521,8 +565,28 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                 // the last step: no rows below its block.  (The loop's only regular exit: values kept for the backward solve are live on
                 // this edge alone, not across the row passes of the earlier steps.)
                 if (keep) {
+#if !defined(W1_EXP_NOBACK)
+                    // W1_LASTRES: the last four columns of the backward solve right here, from the block's tiles in registers and the
+                    // L_cc^-1 images in LDS read transposed (tile (k + 1 + t, k) of column kk from the end is block tile
+                    // (4 - kk + t, 3 - kk)) -- nothing of the last block is written to or read from the workspace, and nothing of it
+                    // is live beyond this branch
+                    W1_FRESH_LANE();
+                    d4 pa0 = d4{0.0, 0.0, 0.0, 0.0};
+                    w1_static_for<0, NLAST>([&](auto P) __attribute__((always_inline)) {
+                        constexpr int q = decltype(P)::value;
+                        constexpr int kk = w1_stream_col(q), t = q - kk * (kk + 1) / 2;
+                        d4 img;
+                        if constexpr (t < kk) {
+                            constexpr int bi = W1_C - kk + t, bc = W1_C - 1 - kk;
+                            img = Lb[bi * (bi - 1) / 2 + bc];
+                        } else {
+                            const double* Mi = LinvC + (W1_C - 1 - kk) * MF_IMG;
 #pragma unroll
-                    for (int q = 0; q < W1_C * (W1_C - 1) / 2; ++q) LbK[q] = Lb[q];
+                            for (int s_ = 0; s_ < 4; ++s_) img[s_] = Mi[mf_img_rc(lg + 4 * s_, lr)];
+                        }
+                        bw_step(P, img, pa0);
+                    });
+#endif
                 } else {
                     __syncthreads();   // the block's tiles are in the workspace before the backward solve reads them back
                 }
@@ -573,7 +637,9 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                     }
                     W1_STAMP(7);
                 }
-            } else {
+            }
+            if (k > 0) {    // (a second `if`, not an `else`: hipcc lays an else-branch out FIRST and keeps the block tiles Lb, which only step 0's
+                            // passes read, live across it -- five tiles spilled and reloaded around the passes of every later step)
                 // k > 0: 16 accumulators; the four column operands L_(k+c)j double-buffered, the four row operands L_rj single-buffered and
                 // re-requested for j + 1 as soon as their four products of j are issued (twelve products of lead).  Eight images per 16
                 // products: the two-row passes of the first version fetched six per eight, and at eight patches per CU every one of them
@@ -702,73 +768,23 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
                 const double* ad = (t < kk) ? Lt + W1_TILE(kq + 1 + t, kq) : LinvTg + (size_t)kq * MF_IMG;
                 return kk < nt ? ad : Lt;
             };
-            // W1_LASTRES: the first ten positions -- the last block's six tiles and four L_cc^-T -- never went to the workspace: tile
-            // (k + 1 + t, k) of column kk from the end is block tile (4 - kk + t, 3 - kk), and the image of L_cc^-T is the image of
-            // L_cc^-1 (LDS, left there by the last step's chain) read transposed
-            constexpr int NLAST = W1_C * (W1_C + 1) / 2;
-            static_assert(NLAST <= W1_BW, "the resident block must fit the ring's first fill");
-            if (lastres) {
-                w1_static_for<0, NLAST>([&](auto P) __attribute__((always_inline)) {
-                    constexpr int q = decltype(P)::value;
-                    constexpr int kk = w1_stream_col(q), t = q - kk * (kk + 1) / 2;
-                    if constexpr (t < kk) {
-                        constexpr int bi = W1_C - kk + t, bc = W1_C - 1 - kk;
-                        win[q] = LbK[bi * (bi - 1) / 2 + bc];
-                    } else {
-                        const double* Mi = LinvC + (W1_C - 1 - kk) * MF_IMG;
-                        d4 r_;
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_) r_[s_] = Mi[mf_img_rc(lg + 4 * s_, lr)];
-                        win[q] = r_;
-                    }
-                });
-            } else {
-                w1_static_for<0, NLAST>([&](auto P) __attribute__((always_inline)) {
-                    constexpr int q = decltype(P)::value;
-                    win[q % W1_BW] = W1_LOAD_BACK(stream_addr(P), lane);
-                });
-            }
-            w1_static_for<NLAST, W1_BW>([&](auto P) __attribute__((always_inline)) {
+            // W1_LASTRES: the first NLAST positions -- the last block -- were consumed where the factorization ended; the stream starts
+            // behind them
+            const int bw_start = lastres ? NLAST : 0;
+            w1_static_for<0, NLAST + W1_BW>([&](auto P) __attribute__((always_inline)) {
                 constexpr int q = decltype(P)::value;
-                win[q % W1_BW] = W1_LOAD_BACK(stream_addr(P), lane);
+                if constexpr (q < SLEN) {
+                    if (q >= bw_start && q < bw_start + W1_BW) win[q % W1_BW] = W1_LOAD_BACK(stream_addr(P), lane);
+                }
             });
             d4 pa = d4{0.0, 0.0, 0.0, 0.0};
             w1_static_for<0, SLEN>([&](auto P) __attribute__((always_inline)) {
                 constexpr int q = decltype(P)::value;
-                constexpr int kk = w1_stream_col(q), t = q - kk * (kk + 1) / 2;
-                if (kk < nt) {
-                    const int k = nt - 1 - kk;
-                    if constexpr (t < kk) {
-                        const double a_ = zv[MF_TS * (k + 1 + t) + lr];
-                        pa += win[q % W1_BW] * a_;                       // the image of L_ik: [l & 15][(l >> 4) + 4 s]
-                    } else {
-                        d4 ub = d4{0.0, 0.0, 0.0, 0.0};
-                        if constexpr (kk > 0) {
-                            const double tot = mf_row_reduce4(pa, lr);   // lanes lr = 0, 4, 8, 12 hold components 0 .. 3
-                            if ((lr & 3) == 0) wsc[lg + 4 * (lr >> 2)] = tot;
-                            W1_LDS_SYNC();
-                            if (lr == 0) {
-#pragma unroll
-                                for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[MF_TS * k + lg + 4 * q4] - wsc[lg + 4 * q4];
-                            }
-                        } else {
-                            if (lr == 0) {
-#pragma unroll
-                                for (int q4 = 0; q4 < 4; ++q4) ub[q4] = zv[MF_TS * k + lg + 4 * q4];
-                            }
-                        }
-                        const d4 al = w1_trsm(win[q % W1_BW], ub);       // lanes lr = 0: alpha[16 k + (l >> 4) + 4 r]
-                        W1_LDS_SYNC();
-                        if (lr == 0) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) zv[MF_TS * k + lg + 4 * r] = al[r];
-                        }
-                        W1_LDS_SYNC();
-                        pa = d4{0.0, 0.0, 0.0, 0.0};
+                if (q >= NLAST || q >= bw_start) {
+                    bw_step(P, win[q % W1_BW], pa);
+                    if constexpr (q + W1_BW < SLEN) {
+                        win[q % W1_BW] = W1_LOAD_BACK(stream_addr(std::integral_constant<int, q + W1_BW>{}), lane);
                     }
-                }
-                if constexpr (q + W1_BW < SLEN) {
-                    win[q % W1_BW] = W1_LOAD_BACK(stream_addr(std::integral_constant<int, q + W1_BW>{}), lane);
                 }
             });
         }

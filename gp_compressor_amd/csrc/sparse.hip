@@ -1426,6 +1426,7 @@ struct SpPredParams {
     // RMS block calls it (/root/reference/src/gp_compressor.cpp:303-315).  nullptr: the shared grid of load_compressed.
     const int32_t* off;
     int n_total;
+    int small_max;   // patches with at most this many basis vectors are the business of sparse_predict_small_kernel (-1: none)
 };
 
 #define SP_PC 32   // grid points per chunk of the sigma path
@@ -1516,6 +1517,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_predict_kernel(SpPredParams
 
     for (int patch = blockIdx.x; patch < A.P; patch += gridDim.x) {
         const int b = A.b[patch];
+        if (b <= A.small_max) continue;                 // (workgroup-uniform, before any barrier) sparse_predict_small_kernel took it
         const double* Cg = A.C + (size_t)patch * ld * ld;
         __syncthreads();
         for (int i = tid; i < b; i += SP_THREADS) {
@@ -1587,6 +1589,101 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_predict_kernel(SpPredParams
         if (tid == 0 && A.status_out) {
             int st = A.stat[patch];
             if (st == GPC_STATUS_OK && *clamp) st = GPC_STATUS_SIGMA_CLAMPED;
+            A.status_out[patch] = st;
+        }
+    }
+}
+
+// ---- predict with a SMALL basis: one wave per patch, a lane per grid point (round 4) ------------------------------------------------
+// At the reference's default hyper-parameters a patch keeps ~13 basis vectors (8 .. 41 over a batch), and predict_measurements ALWAYS
+// computes sigma = sqrt(s20 + k* + k^T C k) (/root/reference/src/sparse_gp.hpp:299-351; the caller drops it, src/gp_compressor.cpp:333-334).
+// sparse_predict_kernel is shaped for a basis of 100 .. 200 -- a 256-thread workgroup per patch, chunks of 32 points, K and V = C K
+// through LDS, the MFMA pipe, five barriers per chunk -- and at b = 13 its sigma path took 4.3 ms for 32768 patches (the mean 0.5 ms):
+// 1.2 TFLOP/s on 6 GFLOP.  Here a lane owns a grid point: its b kernel values stay in registers (BM = 16 or 32 of them, zero beyond b),
+// C sits in LDS zero-padded to BM x BM and is read by broadcast, the mean and k^T C k are register FMAs -- no barrier, no reduction, no
+// second evaluation of k.  Mean: the same operations in the same order as sparse_predict_kernel (bit-identical); sigma: t_j = sum_i
+// C_ij k_i, then sum_j t_j k_j, a summation order of its own, held by the tolerance against the oracle.  Patches with more than BM
+// vectors are left to sparse_predict_kernel (SpPredParams::small_max), patches within the other instance's range to that one.
+template <int BM>
+__global__ __launch_bounds__(64) void sparse_predict_small_kernel(SpPredParams A, int b_lo)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* T = reinterpret_cast<double*>(smem);   // 64
+    double* Cl = T + 64;                           // [BM][BM] column-major, zero-padded
+    double* al = Cl + BM * BM;                     // [3][BM]
+    double* bv = al + 3 * BM;                      // [BM][2]
+    const int lane = threadIdx.x;
+    const int ld = A.ld, ny = A.ny;
+    gpc_exp_table_init(T);
+    const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, kstar = sf;
+    for (int patch = blockIdx.x; patch < A.P; patch += gridDim.x) {
+        const int b = __builtin_amdgcn_readfirstlane(A.b[patch]);
+        if (b < b_lo || b > BM) continue;
+        __builtin_amdgcn_wave_barrier();           // (one wave: LDS instructions execute in order; the compiler must keep them so)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const double* Cg = A.C + (size_t)patch * ld * ld;
+        for (int e = lane; e < BM * BM; e += 64) {
+            const int i = e % BM, j = e / BM;
+            Cl[e] = (i < b && j < b) ? Cg[i + (size_t)j * ld] : 0.0;
+        }
+        if (lane < BM) {
+            const bool in = lane < b;
+            bv[2 * lane] = in ? A.BV[(size_t)patch * ld * 2 + 2 * lane] : 0.0;
+            bv[2 * lane + 1] = in ? A.BV[(size_t)patch * ld * 2 + 2 * lane + 1] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) al[c * BM + lane] = (in && c < ny) ? A.alpha[((size_t)patch * ny + c) * ld + lane] : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int po = A.off ? A.off[patch] : 0;
+        const int m = A.off ? A.off[patch + 1] - po : A.m;
+        const size_t fstride = A.off ? (size_t)A.n_total : (size_t)m;
+        const double* xs0 = A.xs0 + po;
+        const double* xs1 = A.xs1 + po;
+        double* fs = A.off ? A.f_star + po : A.f_star + (size_t)patch * ny * m;
+        double* sg = A.sigma ? (A.off ? A.sigma + po : A.sigma + (size_t)patch * m) : nullptr;
+        bool clamped = false;
+        for (int p = lane; p < m; p += 64) {
+            const double q0 = xs0[p], q1 = xs1[p];
+            double k[BM];
+            double s[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < BM; ++i) {
+                k[i] = 0.0;
+                if (i < b) {                                    // (wave-uniform)
+                    k[i] = gpc_rbf(sf, A.c_exp, q0, q1, bv[2 * i], bv[2 * i + 1], T);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (c < ny) s[c] += al[c * BM + i] * k[i];   // f = alpha^T k (:329), in sparse_predict_kernel's order
+                }
+            }
+            for (int c = 0; c < ny; ++c) fs[(size_t)c * fstride + p] = s[c];
+            if (sg) {
+                double kCk = 0.0;
+#pragma unroll
+                for (int j = 0; j < BM; ++j) {
+                    if (j < b) {                                // (wave-uniform)
+                        double t = 0.0;
+#pragma unroll
+                        for (int i = 0; i < BM; ++i) t += k[i] * Cl[i + BM * j];     // (C k)_j (:330; rows beyond b are zero)
+                        kCk += t * k[j];
+                    }
+                }
+                double sigma = (b == 0) ? kstar + s20 : s20 + kstar + kCk;
+                if (sigma < 0) { sigma = 0; clamped = true; }                 // :334-337
+                if (A.conf) {
+                    sigma /= kstar + s20;
+                    sigma = (double)100.0f * ((double)1.0f - sigma);    // :340-345
+                } else {
+                    sigma = sqrt(sigma);
+                }
+                sg[p] = sigma;
+            }
+        }
+        const bool any_clamp = __builtin_amdgcn_ballot_w64(clamped) != 0;
+        if (lane == 0 && A.status_out) {
+            int st = A.stat[patch];
+            if (st == GPC_STATUS_OK && any_clamp) st = GPC_STATUS_SIGMA_CLAMPED;
             A.status_out[patch] = st;
         }
     }
@@ -1808,6 +1905,22 @@ static size_t sp_lik_lds(int ld, bool fast)
 static size_t sp_pred_lds(int ld, bool sigma, bool fast)
 {
     return sizeof(double) * (size_t)(64 + 5 * ld + (sigma ? (size_t)ld * SP_PC * (fast ? 2 : 1) : 0) + 8 * SP_PC + 2);
+}
+
+// The two instances of the small-basis predict kernel (b <= 16, 17 .. 32), ahead of sparse_predict_kernel on the same stream; sets
+// A.small_max so that the regular kernel skips what they took.  GPC_SPARSE_NO_SMALL_PREDICT=1: everything through the regular kernel.
+static int sp_predict_small_launch(gpc_ctx* ctx, SpPredParams& A)
+{
+    A.small_max = -1;
+    if (getenv("GPC_SPARSE_NO_SMALL_PREDICT") || A.ld < 1) return GPC_OK;
+    const int waves = std::min(A.P, ctx->num_cus * 16);
+    const size_t l16 = sizeof(double) * (size_t)(64 + 16 * 16 + 5 * 16), l32 = sizeof(double) * (size_t)(64 + 32 * 32 + 5 * 32);
+    hipLaunchKernelGGL((sparse_predict_small_kernel<16>), dim3(waves), dim3(64), l16, ctx->stream, A, 0);
+    GPC_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL((sparse_predict_small_kernel<32>), dim3(std::min(A.P, ctx->num_cus * 12)), dim3(64), l32, ctx->stream, A, 17);
+    GPC_HIP(ctx, hipGetLastError());
+    A.small_max = 32;
+    return GPC_OK;
 }
 
 extern "C" {
@@ -2040,6 +2153,7 @@ int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double
     { const int cap_blocks = sigma ? 4 : 8;   // mean only: a patch is a few hundred kernel evaluations, more resident blocks hide their latency
       per_cu = per_cu > cap_blocks ? cap_blocks : (per_cu < 1 ? 1 : per_cu); }
     int grid = std::min(g->P, ctx->num_cus * per_cu);
+    if (int rcs = sp_predict_small_launch(ctx, A)) return rcs;
     hipLaunchKernelGGL(sparse_predict_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;
@@ -2074,6 +2188,7 @@ int gpc_sparse_predict_points_dev(gpc_sparse* g, const int32_t* off, int n_total
     int per_cu = (int)((160u * 1024u) / lds);
     per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
     int grid = std::min(g->P, ctx->num_cus * per_cu);
+    if (int rcs = sp_predict_small_launch(ctx, A)) return rcs;
     hipLaunchKernelGGL(sparse_predict_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
     GPC_HIP(ctx, hipGetLastError());
     return GPC_OK;

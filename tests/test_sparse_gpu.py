@@ -235,6 +235,85 @@ def test_sparse_predict_points_vs_oracle_and_grid_entry(gp, oracle):
         g.close()
 
 
+@pytest.mark.parametrize("ny,regime", [(1, "defaults"), (3, "defaults"), (1, "mid"), (1, "conf")])
+def test_sparse_small_basis_predict_kernel(gp, oracle, ny, regime, monkeypatch):
+    """Round 4: patches with at most 32 basis vectors are predicted by sparse_predict_small_kernel (one wave per patch, a lane per
+    grid point, k in registers, C by broadcast from LDS) -- the shape of the reference's default regime, where predict_measurements
+    computes sigma for a basis of ~13 (src/sparse_gp.hpp:299-351).  Against sparse_predict_kernel on the same states
+    (GPC_SPARSE_NO_SMALL_PREDICT=1): the mean is the same BIT FOR BIT (same operations, same order), sigma^2 agrees to rounding of its
+    largest term (its own summation order of k^T C k), status words equal -- grid entry and per-patch-points entry, empty patches,
+    patches on either side of the 16- and 32-vector boundaries, three channels, the confidence form; and sigma against the oracle."""
+    capi, ctx = gp
+    res, P, n = 0.15, 300, 96
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=120 + ny, ragged=True, ny=ny)
+    off = off.copy()
+    off[8:] -= off[8] - off[7]                                       # patch 7 is empty (b = 0)
+    N = int(off[-1])
+    x0, x1, y = x0[:N].copy(), x1[:N].copy(), np.ascontiguousarray(y[:, :N])
+    if regime == "mid":                                               # bases of 10 .. 45: both instances and the regular kernel
+        kw = dict(sigmaf_sq=1.0, l_sq=(res / 3.5) ** 2, noise=1e-3, capacity=45, eps_tol=1e-5)
+    else:
+        kw = dict(capacity=200)
+    prm = capi.default_params_sparse(ny, **kw)
+    g = capi.Sparse(ctx, prm, P, ny)
+    g.add(off, x0, x1, y, synth.sattolo_perms(off, seed=9))
+    bv = g.sizes()
+    # (the colour GP at its defaults -- s20 = 100 -- keeps 6 .. 7 vectors; the depth GP 8 .. 41; "mid": 10 .. 45)
+    assert bv[7] == 0 and (ny == 3 or bv.max() > 16) and (regime != "mid" or (bv.max() > 32 and bv[bv > 0].min() <= 16))
+    xs0, xs1 = synth.grid(res, 20)
+    conf = regime == "conf"
+    out = []
+    for small in (True, False):
+        if not small:
+            monkeypatch.setenv("GPC_SPARSE_NO_SMALL_PREDICT", "1")
+        f, sg, st = g.predict(xs0, xs1, conf=conf)
+        ft, sgt, stt = g.predict_points(off, x0, x1, want_sigma=True, conf=conf)
+        fm, _, _ = g.predict(xs0, xs1, want_sigma=False)
+        out.append((f, sg, st, ft, sgt, stt, fm))
+    a, b_ = out
+    for q in (0, 2, 3, 5, 6):
+        assert np.array_equal(a[q], b_[q], equal_nan=True), q      # means and status words: bit for bit
+    assert np.array_equal(a[0], a[6])                               # the mean does not depend on whether sigma is asked for
+    kk = prm.sigmaf_sq + prm.noise
+    # sigma: two summation orders of k^T C k.  At the reference's defaults |C| reaches 1e4 .. 1e6 and the sum cancels from ~1e10 down to
+    # ~1e2, so the two orders legitimately differ by up to ~1e-4 in sigma^2: each is held against an extended-precision evaluation of
+    # s20 + k* + k^T C k on the GPU's own state, within a rounding bound on the sum of the magnitudes of its terms.
+    al_, Cs, Qs, BVs = g.state()
+    sample = [i for i in range(0, P, 13) if bv[i] > 0] + [int(np.argmax(bv))]
+    for i in sample:
+        nb = int(bv[i])
+        Bv = BVs[i][:nb].astype(np.longdouble)
+        Cm = Cs[i][:nb, :nb].astype(np.longdouble)
+        d0 = xs0.astype(np.longdouble)[None, :] - Bv[:, 0][:, None]
+        d1 = xs1.astype(np.longdouble)[None, :] - Bv[:, 1][:, None]
+        K = np.longdouble(prm.sigmaf_sq) * np.exp(np.longdouble(-0.5) / np.longdouble(prm.l_sq) * (d0 * d0 + d1 * d1))
+        exact = np.longdouble(prm.noise) + np.longdouble(prm.sigmaf_sq) + np.sum(K * (Cm @ K), axis=0)
+        mag = np.sum(np.abs(K) * (np.abs(Cm) @ np.abs(K)), axis=0).astype(np.float64)
+        bound = 256 * np.finfo(np.float64).eps * (mag + kk) * max(nb, 4)      # (incl. the <= 2 ulp of the device's exp in every k)
+        ex = np.maximum(exact.astype(np.float64), 0.0)
+        for arr in (a[1][i], b_[1][i]):
+            if conf:
+                s2 = (1.0 - arr / 100.0) * kk                                  # back from 100 (1 - sigma^2 / (k* + s20))
+            else:
+                s2 = arr ** 2
+            assert np.all(np.abs(s2 - ex) <= bound + 1e-12 * kk), (i, float(np.max(np.abs(s2 - ex) / bound)))
+    # against the oracle (sigma is sqrt(s20 + k* + k^T C k): compare squares, the cancellation is the oracle's too)
+    op = oracle.sparse_params(ny, p0=prm.sigmaf_sq, p1=prm.l_sq, s20=prm.noise, eps_tol=prm.eps_tol, capacity=kw["capacity"])
+    if regime == "mid":
+        worst, same = 0.0, 0
+        for i in range(0, P, 17):
+            sl = slice(off[i], off[i + 1])
+            h = oracle.Sparse(op, kw["capacity"] + 2)
+            h.add_measurements(x0[sl], x1[sl], y[:, sl], synth.sattolo_perms(off, seed=9)[sl])
+            fo, so = h.predict(xs0, xs1)
+            if h.size() != bv[i]:
+                continue                                              # (a gamma within rounding of eps_tol fell the other way)
+            same += 1
+            worst = max(worst, float(np.max(np.abs(a[1][i] ** 2 - so ** 2))) / kk)
+        assert same >= 12 and worst <= 1e-6, (same, worst)
+    g.close()
+
+
 def test_sparse_c4_defaults_full_size_parity(gp, oracle):
     """BASELINE config 4 at the reference's DEFAULT hyper-parameters (src/sparse_gp.h:48, src/rbf_kernel.h:24) -- the production
     regime, where `gamma < eps_tol` (src/sparse_gp.hpp:144-163) is decided by rounding noise -- at the full 32768 x 256 size, 4 add
