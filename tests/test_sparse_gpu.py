@@ -245,7 +245,7 @@ def test_sparse_small_basis_predict_kernel(gp, oracle, ny, regime, monkeypatch):
     patches on either side of the 16- and 32-vector boundaries, three channels, the confidence form; and sigma against the oracle."""
     capi, ctx = gp
     res, P, n = 0.15, 300, 96
-    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=120 + ny, ragged=True, ny=ny)
+    off, x0, x1, y = synth.make_patches(P, n, res=res, seed=120 + ny, ragged=True, ny=ny, n_min=(6 if regime == "mid" else None))
     off = off.copy()
     off[8:] -= off[8] - off[7]                                       # patch 7 is empty (b = 0)
     N = int(off[-1])

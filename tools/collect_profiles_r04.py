@@ -30,8 +30,8 @@ WORK = {
     "c4fill": ("sparse_add_", 4, 4, "sparse_add@C4_fill", 32768 * 256),      # one pass = 4 add calls (rows + small-basis + regular kernel each)
     "c4defaults": ("sparse_add_", 4, 4, "sparse_add@C4_defaults", 32768 * 256),
     "c4defaults3": ("sparse_add_", 4, 4, "sparse_add@C4_defaults_ny3", 32768 * 256),
-    "c4fills": ("sparse_predict_kernel", 2, 1, "sparse_predict_sigma@C4_fill", None),        # warm-up (with sigma), mean-only pass, then the sigma pass
-    "c4defaultss": ("sparse_predict_kernel", 2, 1, "sparse_predict_sigma@C4_defaults", None),
+    "c4fills": ("sparse_predict_", 2, 1, "sparse_predict_sigma@C4_fill", None),        # warm-up (with sigma), mean-only pass, then the sigma pass
+    "c4defaultss": ("sparse_predict_", 2, 1, "sparse_predict_sigma@C4_defaults", None),
     "c5": ("dense_big_kernel<8, 1024, 2, 2, true, 4, 3>", 1, 1, "dense_mfma_big_irls@n1024", None),
 }
 INSTS = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM")
