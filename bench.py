@@ -344,7 +344,7 @@ def sparse_add_bytes(sizes, cn, cap):
     return total, tri_on
 
 
-def sparse_add_roofline(regime, ny, bytes_total, add_stats, P, point_updates):
+def sparse_add_roofline(regime, ny, bytes_total, add_stats, P, point_updates, cap=200):
     """The roofline object of a sparse record's add calls.
     fill: the basis reaches the capacity and the pass streams C and Q -- bound = HBM, achieved = algorithmic bytes / time.
     defaults (the reference's hyper-parameters: ~13 basis vectors, the blocks live in LDS): the pass moves ~1 GB and is bound by
@@ -352,7 +352,7 @@ def sparse_add_roofline(regime, ny, bytes_total, add_stats, P, point_updates):
     profiles/traffic.json, scaled by this record's point updates) / time, peak = one instruction per SIMD and cycle.  The byte
     figure stays beside it as `hbm_algorithmic_GBps`: Sigma 32 b^2 over blocks that never leave LDS is NOT what the kernels move."""
     add_ms = add_stats["median"]
-    tkey = f"sparse_add@C4_{regime}" + ("" if ny == 1 else "_ny3")
+    tkey = f"sparse_add@C4_{regime}" + ("" if ny == 1 else "_ny3") + ("" if cap == 200 else f"_cap{cap}")
     gbps = bytes_total / (add_ms * 1e-3) / 1e9
     if regime == "fill":
         return {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
@@ -445,7 +445,8 @@ def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s, ny=1, with_
                  else " -- the reference's default hyper-parameters of the colour GP (sigma_f^2=100, l^2=1, s20=100, eps_tol=1e-4)"))
     kern = ("sparse_add_rows_kernel<16> (rows phase) + sparse_add_kernel<true, false> (small-basis phase) + "
             + ("sparse_add_kernel<false, false, true> (triangular passes from 32 basis vectors on)" if tri_on
-               else "sparse_add_kernel<false, false>") + " + sparse_predict_kernel")
+               else "sparse_add_kernel<false, false>") + (" in its two-wave shape" if 64 < cap <= 100 else "")
+            + " + sparse_predict_small_kernel<16 / 32> (patches of at most 32 basis vectors) + sparse_predict_kernel")
 
     def record(t_tot_, add_, pred_, sigma):
         return {"metric": "patches/sec (compress+predict)", "value": P * steps / t_tot_, "unit": "patches/s", "n_gpus": 1, "steps": steps,
@@ -455,7 +456,7 @@ def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s, ny=1, with_
                                        f"on the {SZ}x{SZ} grid" + hyp,
                            "patches_per_gpu": P, "points_per_patch": n, "capacity": cap, "channels": ny, "bv_mean": float(bv.mean()),
                            "bv_max": int(bv.max()), "kernel": kern, "predict_ms": pred_["median"], "results_ok": ok},
-                "roofline": sparse_add_roofline(regime, ny, bytes_total, add_, P, float(P) * n)}
+                "roofline": sparse_add_roofline(regime, ny, bytes_total, add_, P, float(P) * n, cap)}
 
     rec = record(t_tot, add_stats, pred_stats, False)
     recs = [rec]
@@ -604,7 +605,7 @@ def bench_sparse_c4_sharded(env, regime, P, n, chunks, cap, steps):
         ok = bool(okt.item())
     # roofline of rank 0's add calls (per GPU: its own slots, its own HIP-event times) -- the same model as the one-GPU records
     bytes_total, _ = sparse_add_bytes(sizes, cn, cap)
-    roof = sparse_add_roofline(regime, 1, bytes_total, add_stats, max(S, 1), float(int(cnt.sum())))
+    roof = sparse_add_roofline(regime, 1, bytes_total, add_stats, max(S, 1), float(int(cnt.sum())), cap)
     roof["what"] = "rank 0's GPU: " + roof["what"]
     rec = {"metric": "patches/sec (compress+predict)", "value": world * P * steps / elapsed, "unit": "patches/s", "n_gpus": world, "steps": steps,
            "warmup": 1, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "dtype": "f64", "data": "synthetic",
@@ -698,7 +699,7 @@ def main():
     ap.add_argument("--points", type=int, default=256, help="points per patch (C2: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling passes)")
-    ap.add_argument("--only", default="", help="profiling: run just one workload -- c3 | c4fill | c4defaults | c4defaults3 | c4fills | c4defaultss (with sigma) | c5 | c2var -- and print its record")
+    ap.add_argument("--only", default="", help="profiling: run just one workload -- c3 | c4fill | c4defaults | c4defaults3 | c4fills | c4defaultss (with sigma) | c4fill100 (capacity 100) | c5 | c2var -- and print its record")
     args = ap.parse_args()
 
     # stdout carries ONE JSON line: whatever else writes to fd 1 while the bench runs (RCCL prints a version banner there when a
@@ -743,6 +744,9 @@ def main():
         if args.only == "c3":
             r = bench_dense(env, 8192, 512, sec_steps, 1, seed=3)
             out = dense_record("C3 outdoor scan (one GPU's share)", r, 8192, 512, world, sec_steps, 1)
+        elif args.only == "c4fill100":
+            out = bench_sparse_c4(env, "fill", int(os.environ.get("GPC_C4_P", "32768")), 256, 4, 100, int(os.environ.get("GPC_C4_STEPS", "1")),
+                                  float(os.environ.get("GPC_C4_CPU_S", "0")))[0]
         elif args.only in ("c4fill", "c4defaults", "c4defaults3", "c4fills", "c4defaultss"):
             sig = args.only.endswith("s")                      # c4fills / c4defaultss: the record with sigma (profiling its predict kernel)
             reg = args.only[2:].rstrip("3s")
@@ -834,6 +838,9 @@ def main():
                 # depth plane: a second record with sigma, as the reference's predict_measurements computes it (sparse_gp.hpp:299-351)
                 secondary.extend(bench_sparse_c4(env, regime, 32768, 256, 4, 200, 2, 4.0 if cpu else 0.0, ny=ny_, with_sigma=(ny_ == 1)))
                 torch.cuda.empty_cache()
+            # the basis-filling regime at the reference's DEFAULT capacity (100, /root/reference/src/sparse_gp.h:48): the two-wave shape
+            secondary.extend(bench_sparse_c4(env, "fill", 32768, 256, 4, 100, 2, 3.0 if cpu else 0.0))
+            torch.cuda.empty_cache()
             secondary.append(bench_irls_c5(env, 4096, 1024, 2, 3.0 if cpu else 0.0))
     _log("printing the line")
     if rank == 0:
