@@ -785,7 +785,7 @@ def main():
         pageable = {"value": P / th, "unit": "patches/s", "ms_per_call": 1e3 * th,
                     "what": "same call on pageable numpy arrays: staged through the context's pinned buffers by a 4-thread memcpy"}
         # the entry as the reference-side binding uses it: the batch assembled in page-locked memory from
-        # gpc_host_alloc, transferred in place; 4-chunk pipeline of H2D / kernel / D2H on three streams, synchronous for the caller
+        # gpc_host_alloc, transferred in place; 8-chunk pipeline of H2D / kernel / D2H (copy-in, two compute, copy-out streams), synchronous for the caller
         pin = {k: ctx.host_array(a.shape, a.dtype) for k, a in (("off", off), ("x0", x0), ("x1", x1), ("y", y))}
         for k, a in (("off", off), ("x0", x0), ("x1", x1), ("y", y)):
             pin[k][...] = a
@@ -806,7 +806,7 @@ def main():
         out["host_pointer_entry"] = {"value": P / tp, "unit": "patches/s", "ms_per_call": 1e3 * tp,
                                      "results_equal_device_entry": bool(np.max(np.abs(pf - f_host)) <= 1e-12 * np.max(np.abs(f_host))),
                                      "what": "gpc_dense_fit_predict_grid with HOST buffers from gpc_host_alloc (page-locked): PCIe-inclusive, "
-                                             "H2D / kernel / D2H pipelined in 4 chunks; never `value`",
+                                             "H2D / kernel / D2H pipelined in 8 chunks whose kernels alternate between two streams; never `value`",
                                      "pageable": pageable}
         rec, rm = cpu_baseline_dense(off, x0, x1, y, f_host, 12.0)
         out["cpu_baseline"] = rec

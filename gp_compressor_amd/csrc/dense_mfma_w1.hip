@@ -930,7 +930,7 @@ int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
     a.v_star = nullptr;
     W1Params g;
     g.c_exp = (double)(-0.5f) / a.prm.l_sq;
-    g.ws = static_cast<double*>(ctx->ws);
+    g.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + ctx->ws_off);
     g.linvt = g.ws + (size_t)W1_TRI * MF_IMG * (size_t)grid;
     g.export_factor = v_star ? 1 : 0;
     const double sf = a.prm.sigmaf_sq;

@@ -190,6 +190,7 @@ void gpc_ctx_destroy(gpc_ctx* ctx)
             (void)hipStreamSynchronize(ctx->s_out);
             (void)hipStreamDestroy(ctx->s_in);
             (void)hipStreamDestroy(ctx->s_out);
+            if (ctx->s_c2) { (void)hipStreamSynchronize(ctx->s_c2); (void)hipStreamDestroy(ctx->s_c2); ctx->s_c2 = nullptr; }
             for (auto& row : ctx->ev)
                 for (auto& e : row) if (e) (void)hipEventDestroy(e);
             ctx->s_in = ctx->s_out = nullptr;
@@ -288,16 +289,44 @@ static int gpc_aux_streams(gpc_ctx* ctx)
     if (ctx->s_in) return GPC_OK;
     GPC_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
     GPC_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
+    GPC_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_c2, hipStreamNonBlocking));
     for (auto& row : ctx->ev)
         for (auto& e : row) GPC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return GPC_OK;
 }
 
+// The host-pointer pipeline (dense_host) runs the kernels of consecutive chunks on TWO streams, each in its own half of the workspace, so
+// that one chunk's last workgroups and the next chunk's first ones overlap: the stream and workspace offset of the call in hand, set by
+// the calling thread around its _dev call and applied under the context lock.
+static thread_local hipStream_t tl_stream_override = nullptr;
+static thread_local size_t tl_ws_off = 0;
+
+// the one-wave kernel takes this batch (the rule of dense_dispatch_locked, also asked by dense_host before it splits a batch over two streams)
+static bool dense_w1_takes(const gpc_ctx* ctx, const DenseArgs& a)
+{
+    const char* mp = getenv("GPC_W1_MIN_P");
+    const int min_p = mp ? atoi(mp) : 4 * ctx->num_cus;
+    const bool force = getenv("GPC_FORCE_GENERIC") || getenv("GPC_FORCE_BIG");
+    return !force && a.n_max <= 256 && a.P >= min_p && a.P > 1 && (a.n_max > 192 || !a.v_star) && dense_w1_supported(a) && !getenv("GPC_NO_W1");
+}
+
+static int dense_dispatch_locked(gpc_ctx* ctx, DenseArgs& a);
 static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
 {
     if (a.P == 0 || (a.m == 0 && !a.alpha_out)) return GPC_OK;
     if (a.n_max < 1) a.n_max = 1;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    hipStream_t const saved = ctx->stream;
+    if (tl_stream_override) ctx->stream = tl_stream_override;
+    ctx->ws_off = tl_ws_off;
+    const int rc = dense_dispatch_locked(ctx, a);
+    ctx->stream = saved;
+    ctx->ws_off = 0;
+    return rc;
+}
+
+static int dense_dispatch_locked(gpc_ctx* ctx, DenseArgs& a)
+{
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     if (!a.prm.want_variance) a.v_star = nullptr;
     {
@@ -314,9 +343,7 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
         // eight waves per patch win on latency (64 patches x 192 points: 0.066 against 0.134 ms) -- hence the batch-size rule
         // (GPC_W1_MIN_P overrides it; the variance goes this way for 193 .. 256 points, where its solve kernel is the <16> shape).
         {
-            const char* mp = getenv("GPC_W1_MIN_P");
-            const int min_p = mp ? atoi(mp) : 4 * ctx->num_cus;
-            if (a.n_max <= 256 && a.P >= min_p && a.P > 1 && (a.n_max > 192 || !a.v_star) && dense_w1_supported(a) && !getenv("GPC_NO_W1")) {
+            if (dense_w1_takes(ctx, a)) {
                 // One factor slot (304 KB) per patch of a launch.  If the device cannot serve that, the batch goes
                 // through in smaller launches that reuse fewer slots, and below two launches' worth of resident patches it takes the
                 // register-resident kernel, which needs no workspace at all.
@@ -324,7 +351,7 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
                 DenseArgs aw = a;
                 for (int cap_w1 = 0;;) {
                     const size_t w1_bytes = (dense_w1_ws_bytes(ctx, aw, &grid_w1, cap_w1) + 255) & ~(size_t)255;
-                    rcw = gpc_ws_reserve(ctx, w1_bytes);
+                    rcw = gpc_ws_reserve(ctx, ctx->ws_off + w1_bytes);
                     if (rcw != GPC_ENOMEM) break;
                     cap_w1 = grid_w1 / 2;
                     if (cap_w1 < 4 * ctx->num_cus) break;             // (below the batch-size rule of this kernel)
@@ -385,9 +412,9 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
             if (fork) {
                 rc = gpc_aux_streams(ctx);
                 if (rc != GPC_OK) return rc;
-                GPC_HIP(ctx, hipEventRecord(ctx->ev[0][5], main_s));
-                GPC_HIP(ctx, hipStreamWaitEvent(ctx->s_in, ctx->ev[0][5], 0));
-                GPC_HIP(ctx, hipStreamWaitEvent(ctx->s_out, ctx->ev[0][5], 0));
+                GPC_HIP(ctx, hipEventRecord(ctx->ev[0][13], main_s));
+                GPC_HIP(ctx, hipStreamWaitEvent(ctx->s_in, ctx->ev[0][13], 0));
+                GPC_HIP(ctx, hipStreamWaitEvent(ctx->s_out, ctx->ev[0][13], 0));
                 forked = true;
             }
             // largest patches first: the tiled kernel's workgroups are the long ones
@@ -440,10 +467,10 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
                 if (rc != GPC_OK) return bail(rc);
             }
             if (fork) {
-                GPC_HIP(ctx, hipEventRecord(ctx->ev[1][5], ctx->s_in));
-                GPC_HIP(ctx, hipEventRecord(ctx->ev[2][5], ctx->s_out));
-                GPC_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev[1][5], 0));
-                GPC_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev[2][5], 0));
+                GPC_HIP(ctx, hipEventRecord(ctx->ev[1][13], ctx->s_in));
+                GPC_HIP(ctx, hipEventRecord(ctx->ev[2][13], ctx->s_out));
+                GPC_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev[1][13], 0));
+                GPC_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev[2][13], 0));
             }
             ctx->last_dense_kernel = !need_big ? "dense_mfma_nt16 + dense_mfma_nt17" : nt17 ? "dense_mfma_nt16 + dense_mfma_nt17 + dense_mfma_big"
                                                                                              : "dense_mfma_nt16 + dense_mfma_big";
@@ -629,10 +656,33 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
     const bool want_v = !grid && params->want_variance && v_star;
     const size_t N = (size_t)n_total;
     // (chunks of at least 1024 patches: below four patches per CU the dense dispatch leaves the one-wave-per-patch kernel)
-    const int C = getenv("GPC_HOST_NO_PIPELINE") ? 1 : P >= 4096 ? 4 : P >= 2048 ? 2 : 1;
+    int C = getenv("GPC_HOST_NO_PIPELINE") ? 1 : P >= 4096 ? 4 : P >= 2048 ? 2 : 1;
+    // Round 4: when the one-wave kernel takes the chunks, the kernels of consecutive chunks run on TWO streams, each in its own half of
+    // the workspace (one factor slot per patch of a chunk), so that a chunk's draining workgroups and the next chunk's first ones share
+    // the chip -- a chunk of 1024 .. 2048 patches is a single round of resident workgroups, i.e. all ramp and tail -- and the batch goes
+    // through in EIGHT chunks: the first upload and the last download, which nothing overlaps, halve.  GPC_HOST_ONE_STREAM=1: as before.
+    bool two = false;
+    size_t half = 0;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         if ((rc = gpc_aux_streams(ctx))) return rc;
+        DenseArgs probe{};
+        probe.prm = *params;
+        probe.P = P / 8; probe.n_max = n_max; probe.ny = ny; probe.m = m;
+        probe.v_star = want_v ? v_star : nullptr;
+        probe.xs0 = grid ? nullptr : xs0;
+        // (measured on the C2 batch, same box: 1.95 against 2.12 ms per call, 4.2 against 3.87 M patches/s PCIe-inclusive; at 128 points per
+        // patch the kernel is a third of the call and eight chunks only add transfers' fixed costs -- 1.09 against 0.96 ms -- hence n_max > 160)
+        if (C == 4 && P >= 8192 && n_max > 160 && !alpha_out && !getenv("GPC_HOST_ONE_STREAM") && dense_w1_takes(ctx, probe)) {
+            probe.P = (P + 7) / 8;
+            half = (dense_w1_ws_bytes(ctx, probe, nullptr) + 255) & ~(size_t)255;
+            if (gpc_ws_reserve(ctx, 2 * half) == GPC_OK) {
+                two = true;
+                C = 8;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
     }
     // device arena: [off chunks | x0 | x1 | y planes per chunk | xs0 xs1 | f | v | alpha | status]
     auto al256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -670,14 +720,15 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
         sc = ctx->stream;
     }
     // the arena may still be read by work a previous call left on the compute stream
-    GPC_HIP(ctx, hipEventRecord(ctx->ev[0][7], sc));
-    GPC_HIP(ctx, hipStreamWaitEvent(si, ctx->ev[0][7], 0));
+    GPC_HIP(ctx, hipEventRecord(ctx->ev[0][15], sc));
+    GPC_HIP(ctx, hipStreamWaitEvent(si, ctx->ev[0][15], 0));
     if (!grid && m) {
         GPC_HIP(ctx, hipMemcpyAsync(d_xs0, xs0, 8 * (size_t)m, hipMemcpyHostToDevice, si));
         GPC_HIP(ctx, hipMemcpyAsync(d_xs1, xs1, 8 * (size_t)m, hipMemcpyHostToDevice, si));
     }
-    int p_lo[5];
+    int p_lo[9];
     for (int c = 0; c <= C; ++c) p_lo[c] = (int)((long long)P * c / C);
+    const hipStream_t sc_main = sc;
     int fail = GPC_OK;
     for (int c = 0; c < C && fail == GPC_OK; ++c) {
         const int p0 = p_lo[c], Pc = p_lo[c + 1] - p0;
@@ -706,14 +757,23 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
             }
         }
         GPC_HIP(ctx, hipEventRecord(ctx->ev[0][c], si));
+        sc = (two && (c & 1)) ? ctx->s_c2 : sc_main;                     // this chunk's compute stream
+        if (two && c == 1) {                                               // the second stream starts behind whatever the first one carried
+            GPC_HIP(ctx, hipStreamWaitEvent(sc, ctx->ev[0][15], 0));
+            if (!grid && m) GPC_HIP(ctx, hipStreamWaitEvent(sc, ctx->ev[0][0], 0));   // (xs0 / xs1 went up in front of chunk 0)
+        }
         GPC_HIP(ctx, hipStreamWaitEvent(sc, ctx->ev[0][c], 0));
         double* df = d_f + (size_t)p0 * ny * m;
+        tl_stream_override = two ? sc : nullptr;
+        tl_ws_off = (two && (c & 1)) ? half : 0;
         if (grid)
             rc = gpc_dense_fit_predict_grid_dev(ctx, params, Pc, d_off_c, nmax_c, (int)Nc, dx0, dx1, dy, ny, res, sz, df,
                                                 alpha_out ? d_al + r0 * ny : nullptr, d_st + p0);
         else
             rc = gpc_dense_fit_predict_dev(ctx, params, Pc, d_off_c, nmax_c, (int)Nc, dx0, dx1, dy, ny, m, d_xs0, d_xs1, df,
                                            want_v ? d_v + (size_t)p0 * m : nullptr, alpha_out ? d_al + r0 * ny : nullptr, d_st + p0);
+        tl_stream_override = nullptr;
+        tl_ws_off = 0;
         if (rc != GPC_OK) { fail = rc; break; }
         GPC_HIP(ctx, hipEventRecord(ctx->ev[1][c], sc));
         GPC_HIP(ctx, hipStreamWaitEvent(so, ctx->ev[1][c], 0));
@@ -725,7 +785,8 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
         GPC_HIP(ctx, hipEventRecord(ctx->ev[2][c], so));
     }
     if (fail != GPC_OK) {
-        (void)hipStreamSynchronize(si); (void)hipStreamSynchronize(sc); (void)hipStreamSynchronize(so);
+        (void)hipStreamSynchronize(si); (void)hipStreamSynchronize(sc_main); (void)hipStreamSynchronize(so);
+        if (two) (void)hipStreamSynchronize(ctx->s_c2);
         return fail;
     }
     // alpha has chunk-local planes on the device ([ny][Nc] per chunk): gathered plane by plane at the end (rarely requested)
@@ -745,7 +806,12 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
         }
         GPC_HIP(ctx, hipStreamSynchronize(so));
     }
-    GPC_HIP(ctx, hipStreamSynchronize(sc));
+    if (two) {
+        // the caller's stream is ordered behind the second one (the next _dev call on the context may reuse the workspace)
+        GPC_HIP(ctx, hipEventRecord(ctx->ev[1][15], ctx->s_c2));
+        GPC_HIP(ctx, hipStreamWaitEvent(sc_main, ctx->ev[1][15], 0));
+    }
+    GPC_HIP(ctx, hipStreamSynchronize(sc_main));
     return GPC_OK;
 }
 

@@ -28,6 +28,8 @@ struct gpc_ctx {
     // grow-only device workspace (K / L factors of the generic dense kernel, variance scratch, grid tables)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    size_t ws_off = 0;                 // offset of the region the launch in hand may use (the host-pointer pipeline runs the kernels of
+                                       // consecutive chunks on two streams, each in its own half; 0 everywhere else)
     int32_t* tickets = nullptr;        // 64 counters (allocated on first use): patches handed out one at a time where their cost varies (dense_mfma_big.hip)
     // host-pointer entries (gpc_api.hip, dense_host): a grow-only device arena for the batch, pinned staging buffers for
     // pageable caller memory, and two copy streams so that the upload of chunk c+1 and the download of chunk c-1 run on the
@@ -38,8 +40,8 @@ struct gpc_ctx {
     size_t pin_in_bytes = 0;
     void* pin_out = nullptr;
     size_t pin_out_bytes = 0;
-    hipStream_t s_in = nullptr, s_out = nullptr;
-    hipEvent_t ev[3][8] = {};
+    hipStream_t s_in = nullptr, s_out = nullptr, s_c2 = nullptr;   // copy-in, copy-out, second compute stream
+    hipEvent_t ev[3][16] = {};       // [.][0 .. 7] the chunks of the host-pointer pipeline, [.][13] the class fork, [0][15] the arena
     std::mutex host_mu;                // one host-pointer call at a time per context (they share the arena)
     // size classes of the last batch gpc_project_cloud produced on this context (its `off` buffer, how many of its P patches have
     // <= 256 / <= 272 points): lets the dense dispatch size its class launches exactly instead of P workgroups each

@@ -1457,30 +1457,40 @@ __device__ static inline void sp_ck_chunk(const double* __restrict__ Cg, int ld,
         rowok[t] = i < b;
         rowc[t] = min(i, b - 1);
     }
-    double an[SP_RT];
-    {
-        const int jc = min(lg, b - 1);
+    // Round 4: the A operands of SP_PF K-steps are in flight (a K-step is 8 MFMAs = 512 cycles of the pipe per wave; with one step of
+    // look-ahead every step waited out most of a ~2000-cycle load: the sigma path of a 200-vector basis ran at 0.18 of the FP64 peak)
+    constexpr int SP_PF = 4;
+    double an[SP_PF][SP_RT];
 #pragma unroll
-        for (int t = 0; t < SP_RT; ++t) an[t] = Cg[rowc[t] + (size_t)jc * ld];
+    for (int u = 0; u < SP_PF; ++u) {
+        const int jc = min(4 * u + lg, b - 1);
+#pragma unroll
+        for (int t = 0; t < SP_RT; ++t) an[u][t] = Cg[rowc[t] + (size_t)jc * ld];
     }
-    for (int j0 = 0; j0 < b; j0 += 4) {
-        const bool jok = j0 + lg < b;
-        double ac[SP_RT];
+    for (int jb = 0; jb < b; jb += 4 * SP_PF) {
 #pragma unroll
-        for (int t = 0; t < SP_RT; ++t) ac[t] = (jok && rowok[t]) ? an[t] : 0.0;
-        {
-            const int jn = min(j0 + 4 + lg, b - 1);
+        for (int u = 0; u < SP_PF; ++u) {
+            const int j0 = jb + 4 * u;
+            if (j0 < b) {                                  // (wave-uniform)
+                const bool jok = j0 + lg < b;
+                double ac[SP_RT];
 #pragma unroll
-            for (int t = 0; t < SP_RT; ++t) an[t] = Cg[rowc[t] + (size_t)jn * ld];
-        }
-        const int jl = min(j0 + lg, b - 1);
-        const double b0 = jok ? Kc[jl * SP_PC + lr] : 0.0;
-        const double b1 = jok ? Kc[jl * SP_PC + 16 + lr] : 0.0;
+                for (int t = 0; t < SP_RT; ++t) ac[t] = (jok && rowok[t]) ? an[u][t] : 0.0;
+                {
+                    const int jn = min(j0 + 4 * SP_PF + lg, b - 1);
 #pragma unroll
-        for (int t = 0; t < SP_RT; ++t) {
-            if (wave + 4 * t < nrt) {     // wave-uniform
-                acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], b0, acc[t][0], 0, 0, 0);
-                acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], b1, acc[t][1], 0, 0, 0);
+                    for (int t = 0; t < SP_RT; ++t) an[u][t] = Cg[rowc[t] + (size_t)jn * ld];
+                }
+                const int jl = min(j0 + lg, b - 1);
+                const double b0 = jok ? Kc[jl * SP_PC + lr] : 0.0;
+                const double b1 = jok ? Kc[jl * SP_PC + 16 + lr] : 0.0;
+#pragma unroll
+                for (int t = 0; t < SP_RT; ++t) {
+                    if (wave + 4 * t < nrt) {     // wave-uniform
+                        acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], b0, acc[t][0], 0, 0, 0);
+                        acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], b1, acc[t][1], 0, 0, 0);
+                    }
+                }
             }
         }
     }

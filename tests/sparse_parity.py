@@ -169,7 +169,13 @@ def blowup_p_value(g, g_over, o, o_over):
     if n == 0:
         return 1.0
     q = g_over / float(g_over + o_over)
-    return float(sum(math.comb(n, k) * q ** k * (1.0 - q) ** (n - k) for k in range(int(g), n + 1)))
+    if q >= 1.0:
+        return 1.0
+    # in log space (thousands of events in the basis-filling regime: the binomial coefficients overflow a double)
+    lq, l1q = math.log(q), math.log1p(-q)
+    logs = [math.lgamma(n + 1) - math.lgamma(k + 1) - math.lgamma(n - k + 1) + k * lq + (n - k) * l1q for k in range(int(g), n + 1)]
+    top = max(logs)
+    return float(min(1.0, math.exp(top) * sum(math.exp(v - top) for v in logs)))
 
 
 def blowup_counts(run_gpu, op, P, n, seeds, res, sz, synth):
