@@ -18,6 +18,8 @@ P, n, RES, SZ = int(os.environ.get("P", "8192")), int(os.environ.get("N", "256")
 M = SZ * SZ
 off, x0, x1, y = synth.make_patches(P, n, res=RES, seed=2)
 ctx = capi.Context(0)
+if os.environ.get("NULL_STREAM"):                       # as bench.py runs it: the context on torch's current (legacy default) stream
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 prm = capi.default_params_dense()
 f_dev, st_dev = ctx.dense_fit_predict_grid(prm, off, x0, x1, y, RES, SZ)          # pageable path once (also the reference result)
 pin = {k: ctx.host_array(a.shape, a.dtype) for k, a in (("off", off), ("x0", x0), ("x1", x1), ("y", y))}
@@ -44,5 +46,5 @@ ts = np.array(ts)
 print(json.dumps({"P": P, "n": n, "ms_median": float(np.median(ts)), "ms_min": float(ts.min()), "ms_max": float(ts.max()),
                   "patches_per_s": P / (np.median(ts) * 1e-3), "equal_to_first_call": bool(np.array_equal(pf, f_dev)),
                   "status_ok": bool(np.all(pst == 0)), "kernel": ctx.last_dense_kernel(),
-                  "mode": "one stream" if os.environ.get("GPC_HOST_ONE_STREAM") else "no pipeline" if os.environ.get("GPC_HOST_NO_PIPELINE") else "default"}))
+                  "null_stream": bool(os.environ.get("NULL_STREAM")), "mode": "one stream" if os.environ.get("GPC_HOST_ONE_STREAM") else "no pipeline" if os.environ.get("GPC_HOST_NO_PIPELINE") else "default"}))
 ctx.close()
