@@ -1459,10 +1459,7 @@ __device__ static inline void sp_ck_chunk(const double* __restrict__ Cg, int ld,
     }
     // Round 4: the A operands of SP_PF K-steps are in flight (a K-step is 8 MFMAs = 512 cycles of the pipe per wave; with one step of
     // look-ahead every step waited out most of a ~2000-cycle load: the sigma path of a 200-vector basis ran at 0.18 of the FP64 peak)
-#ifndef SP_PF_N
-#define SP_PF_N 4
-#endif
-    constexpr int SP_PF = SP_PF_N;
+    constexpr int SP_PF = 4;
     double an[SP_PF][SP_RT];
 #pragma unroll
     for (int u = 0; u < SP_PF; ++u) {
@@ -1629,16 +1626,6 @@ __global__ __launch_bounds__(64) void sparse_predict_small_kernel(SpPredParams A
     const int ld = A.ld, ny = A.ny;
     gpc_exp_table_init(T);
     const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, kstar = sf;
-    constexpr int SP_GI = 8;                      // grid points per lane held in registers (a shared grid of up to 512 points)
-    const bool shared_grid = A.off == nullptr && A.m <= 64 * SP_GI;
-    double g0[SP_GI], g1[SP_GI];
-#pragma unroll
-    for (int u = 0; u < SP_GI; ++u) {
-        const int p = lane + 64 * u;
-        const bool in = shared_grid && p < A.m;
-        g0[u] = in ? A.xs0[p] : 0.0;
-        g1[u] = in ? A.xs1[p] : 0.0;
-    }
     for (int patch = blockIdx.x; patch < A.P; patch += gridDim.x) {
         const int b = __builtin_amdgcn_readfirstlane(A.b[patch]);
         if (b < b_lo || b > BM) continue;
@@ -1666,7 +1653,10 @@ __global__ __launch_bounds__(64) void sparse_predict_small_kernel(SpPredParams A
         double* fs = A.off ? A.f_star + po : A.f_star + (size_t)patch * ny * m;
         double* sg = A.sigma ? (A.off ? A.sigma + po : A.sigma + (size_t)patch * m) : nullptr;
         bool clamped = false;
-        auto point = [&](int p, double q0, double q1) __attribute__((always_inline)) {
+        // (the lane's grid coordinates are loaded per iteration, on purpose: holding a shared grid in registers -- 28 VGPRs, two waves per
+        // SIMD less -- measured 1.24 against 1.12 ms for the sigma-predict of the defaults batch, staging it in LDS once per wave 1.30)
+        for (int p = lane; p < m; p += 64) {
+            const double q0 = xs0[p], q1 = xs1[p];
             double k[BM];
             double s[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -1701,19 +1691,6 @@ __global__ __launch_bounds__(64) void sparse_predict_small_kernel(SpPredParams A
                 }
                 sg[p] = sigma;
             }
-        };
-        if (shared_grid) {
-            // the lane's grid points came into registers once, before the patch loop (a patch of 13 vectors is ~1.5 us of arithmetic per
-            // 64 points: a dependent global load per iteration was most of its time)
-#pragma unroll
-            for (int u = 0; u < SP_GI; ++u) {
-                const int p = lane + 64 * u;
-                if (64 * u < m) {                               // (wave-uniform)
-                    if (p < m) point(p, g0[u], g1[u]);
-                }
-            }
-        } else {
-            for (int p = lane; p < m; p += 64) point(p, xs0[p], xs1[p]);
         }
         const bool any_clamp = __builtin_amdgcn_ballot_w64(clamped) != 0;
         if (lane == 0 && A.status_out) {
