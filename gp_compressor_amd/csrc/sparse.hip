@@ -1655,8 +1655,11 @@ __global__ __launch_bounds__(64) void sparse_predict_small_kernel(SpPredParams A
         bool clamped = false;
         // (the lane's grid coordinates are loaded per iteration, on purpose: holding a shared grid in registers -- 28 VGPRs, two waves per
         // SIMD less -- measured 1.24 against 1.12 ms for the sigma-predict of the defaults batch, staging it in LDS once per wave 1.30)
+        double nq0 = 0.0, nq1 = 0.0;             // the NEXT 64 points' coordinates are requested before this block's arithmetic
+        if (lane < m) { nq0 = xs0[lane]; nq1 = xs1[lane]; }
         for (int p = lane; p < m; p += 64) {
-            const double q0 = xs0[p], q1 = xs1[p];
+            const double q0 = nq0, q1 = nq1;
+            if (p + 64 < m) { nq0 = xs0[p + 64]; nq1 = xs1[p + 64]; }
             double k[BM];
             double s[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -1925,7 +1928,7 @@ static int sp_predict_small_launch(gpc_ctx* ctx, SpPredParams& A)
 {
     A.small_max = -1;
     if (getenv("GPC_SPARSE_NO_SMALL_PREDICT") || A.ld < 1) return GPC_OK;
-    const int waves = std::min(A.P, ctx->num_cus * 16);
+    const int waves = std::min(A.P, ctx->num_cus * (getenv("GPC_SP_SMALL_WAVES") ? atoi(getenv("GPC_SP_SMALL_WAVES")) : 16));
     const size_t l16 = sizeof(double) * (size_t)(64 + 16 * 16 + 5 * 16), l32 = sizeof(double) * (size_t)(64 + 32 * 32 + 5 * 32);
     hipLaunchKernelGGL((sparse_predict_small_kernel<16>), dim3(waves), dim3(64), l16, ctx->stream, A, 0);
     GPC_HIP(ctx, hipGetLastError());
