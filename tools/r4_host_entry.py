@@ -21,6 +21,16 @@ ctx = capi.Context(0)
 if os.environ.get("NULL_STREAM"):                       # as bench.py runs it: the context on torch's current (legacy default) stream
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 prm = capi.default_params_dense()
+if os.environ.get("LIKE_BENCH"):                        # the sequence of bench.py before its host-pointer measurement
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_off, d_x0, d_x1, d_y = tt(off), tt(x0), tt(x1), tt(y)
+    d_f = torch.empty((P, 1, M), dtype=torch.float64, device="cuda")
+    d_st = torch.empty((P,), dtype=torch.int32, device="cuda")
+    for _ in range(25 if "dev" in os.environ["LIKE_BENCH"] or os.environ["LIKE_BENCH"] == "1" else 0):
+        ctx.dense_fit_predict_grid_dev(prm, P, d_off, n, P * n, d_x0, d_x1, d_y, 1, RES, SZ, d_f, status=d_st)
+    torch.cuda.synchronize()
+    for _ in range(3 if "page" in os.environ["LIKE_BENCH"] or os.environ["LIKE_BENCH"] == "1" else 0):
+        ctx.dense_fit_predict_grid(prm, off, x0, x1, y, RES, SZ)
 f_dev, st_dev = ctx.dense_fit_predict_grid(prm, off, x0, x1, y, RES, SZ)          # pageable path once (also the reference result)
 pin = {k: ctx.host_array(a.shape, a.dtype) for k, a in (("off", off), ("x0", x0), ("x1", x1), ("y", y))}
 for k, a in (("off", off), ("x0", x0), ("x1", x1), ("y", y)):
@@ -35,10 +45,10 @@ def call():
     assert rc == 0, rc
 
 
-for _ in range(3):
+for _ in range(1 if os.environ.get("LIKE_BENCH") else 3):
     call()
 ts = []
-for _ in range(15):
+for _ in range(5 if os.environ.get("LIKE_BENCH") else 15):
     t0 = time.perf_counter()
     call()
     ts.append(1e3 * (time.perf_counter() - t0))
