@@ -27,11 +27,11 @@
 #include "gpc_internal.h"
 #include "mfma_tile.h"
 
-#define W1_NPAD 256
+#define W1_NPAD_MAX 512   // the kernel is instantiated for 256 (eight patches per CU) and 512 points (seven: 21 KB of LDS each)
 #define W1_C 4          // tile columns per step
 #define W1_NDT 10       // tiles of a step's diagonal block
-#define W1_NT (W1_NPAD / 16)                 // tile rows of a slot
-#define W1_TRI (W1_NT * (W1_NT + 1) / 2)     // images of a slot
+#define W1_NT_OF(npad) ((npad) / 16)                               // tile rows of a slot
+#define W1_TRI_OF(npad) (W1_NT_OF(npad) * (W1_NT_OF(npad) + 1) / 2)  // images of a slot
 // offset (doubles) of tile (i, j), j <= i, in a slot
 #define W1_TILE(i, j) (((size_t)(i) * (size_t)((i) + 1) / 2 + (size_t)(j)) * MF_IMG)
 // Diagnostic build -DW1_EXP_HOT (results wrong by construction): every j-indexed operand load reads tile column 0 -- what the
@@ -220,8 +220,10 @@ __device__ static __forceinline__ void w1_gram_row(d4 (&v)[W1_C], const double* 
     }
 }
 
+template <int W1_NPAD>
 __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
 {
+    constexpr int W1_NT = W1_NT_OF(W1_NPAD), W1_TRI = W1_TRI_OF(W1_NPAD);
     __shared__ __attribute__((aligned(16))) double T[GPC_EXP_TABLE_SIZE];
     __shared__ __attribute__((aligned(16))) double px0[W1_NPAD], px1[W1_NPAD], zv[W1_NPAD];     // zv: z, then alpha in place
     __shared__ __attribute__((aligned(16))) double rsbuf[32], wsc[32];
@@ -896,10 +898,14 @@ __global__ __launch_bounds__(64, 2) void dense_w1_kernel(W1Params g)
     }
 }
 
+static int w1_npad(const DenseArgs& a) { return a.n_max <= 256 ? 256 : W1_NPAD_MAX; }
+
 bool dense_w1_supported(const DenseArgs& a)
 {
-    // (with the variance: point-wise X* only -- the variance entry has no grid form)
-    return a.n_max <= W1_NPAD && a.ny == 1 && !a.sel && (a.v_star == nullptr || a.xs0 != nullptr);
+    // (with the variance: point-wise X* only -- the variance entry has no grid form -- and n <= 256: the 512-point instance's slots
+    // are not the layout dense_variance_big_kernel reads)
+    if (a.v_star) return a.n_max <= 256 && a.ny == 1 && !a.sel && a.xs0 != nullptr;
+    return a.n_max <= W1_NPAD_MAX && a.ny == 1 && !a.sel;
 }
 
 // One factor slot per patch of a launch (304 KB: 2.5 GB for the 8192 patches of BASELINE config 2 -- sized for 288 GB); a larger
@@ -920,7 +926,8 @@ size_t dense_w1_ws_bytes(const gpc_ctx* ctx, const DenseArgs& a, int* grid_out, 
     const int grid = w1_chunk(a, cap);
     if (grid_out) *grid_out = grid;
     // factor slots | L_kk^-T images | (variance without alpha_out: the weights the variance kernel forms the mean from)
-    return sizeof(double) * ((size_t)(W1_TRI + W1_NT) * MF_IMG * (size_t)grid + (a.v_star ? (size_t)a.n_total : 0));
+    const int npad = w1_npad(a);
+    return sizeof(double) * ((size_t)(W1_TRI_OF(npad) + W1_NT_OF(npad)) * MF_IMG * (size_t)grid + (a.v_star ? (size_t)a.n_total : 0));
 }
 
 int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
@@ -931,7 +938,8 @@ int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
     W1Params g;
     g.c_exp = (double)(-0.5f) / a.prm.l_sq;
     g.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + ctx->ws_off);
-    g.linvt = g.ws + (size_t)W1_TRI * MF_IMG * (size_t)grid;
+    const int npad = w1_npad(a);
+    g.linvt = g.ws + (size_t)W1_TRI_OF(npad) * MF_IMG * (size_t)grid;
     g.export_factor = v_star ? 1 : 0;
     const double sf = a.prm.sigmaf_sq;
     const bool unit = !v_star;                        // unit scale (see the kernel) unless the factor is exported
@@ -945,9 +953,9 @@ int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
         // Predictive variance (gaussian_process::predict_measurements, /root/reference/src/gaussian_process.cpp:35-43): the slots are the
         // factor export dense_variance_kernel<16> reads, the fit predicts nothing (the solve forms the mean from the same K* tiles)
         a.m = 0;
-        if (!a.alpha_out) a.alpha_out = g.linvt + (size_t)W1_NT * MF_IMG * (size_t)grid;
+        if (!a.alpha_out) a.alpha_out = g.linvt + (size_t)W1_NT_OF(npad) * MF_IMG * (size_t)grid;
     }
-    ctx->last_dense_kernel = v_star ? "dense_mfma_w1 + dense_variance" : "dense_mfma_w1";
+    ctx->last_dense_kernel = v_star ? "dense_mfma_w1 + dense_variance" : npad == 256 ? "dense_mfma_w1" : "dense_mfma_w1_512";
 #ifdef W1_STAMPS
     if (getenv("GPC_W1_STAMPS")) {
         GPC_HIP(ctx, hipMalloc(&g.stamps, sizeof(unsigned long long) * W1_NPH));
@@ -966,12 +974,13 @@ int dense_w1_launch(gpc_ctx* ctx, const DenseArgs& a_in, int grid)
         g.a.off = a.off + base;
         g.a.f_star = a.f_star ? a.f_star + (size_t)base * a.ny * a_in.m : nullptr;
         g.a.status = a.status ? a.status + base : nullptr;
-        hipLaunchKernelGGL(dense_w1_kernel, dim3(cnt), dim3(64), pad, ctx->stream, g);
+        if (npad == 256) hipLaunchKernelGGL((dense_w1_kernel<256>), dim3(cnt), dim3(64), pad, ctx->stream, g);
+        else hipLaunchKernelGGL((dense_w1_kernel<W1_NPAD_MAX>), dim3(cnt), dim3(64), pad, ctx->stream, g);
         GPC_HIP(ctx, hipGetLastError());
         if (v_star) {
             DenseArgs av = g.a;
             av.m = a_in.m;
-            const int rc = dense_variance_launch(ctx, av, W1_NT, g.ws, a.alpha_out, v_star + (size_t)base * a_in.m);
+            const int rc = dense_variance_launch(ctx, av, W1_NT_OF(256), g.ws, a.alpha_out, v_star + (size_t)base * a_in.m);
             if (rc != GPC_OK) return rc;
         }
     }

@@ -244,7 +244,11 @@ int gpc_debug_poison_lds(gpc_ctx* ctx)
     hipLaunchKernelGGL(gpc_poison_lds_kernel, dim3(ctx->num_cus * 2), dim3(256), bytes, ctx->stream, bytes / 8);
     GPC_HIP(ctx, hipGetLastError());
     // the device workspace is per-call scratch as well: whatever the previous call left in it becomes NaN (all-ones doubles)
-    if (ctx->ws && ctx->ws_bytes) GPC_HIP(ctx, hipMemsetAsync(ctx->ws, 0xFF, ctx->ws_bytes, ctx->stream));
+    // (only the region of the launch in hand: the host-pointer pipeline runs another chunk's kernel in the other half at the same time)
+    if (ctx->ws && ctx->ws_bytes > ctx->ws_off) {
+        const size_t len = ctx->ws_len ? std::min(ctx->ws_len, ctx->ws_bytes - ctx->ws_off) : ctx->ws_bytes - ctx->ws_off;
+        GPC_HIP(ctx, hipMemsetAsync(static_cast<char*>(ctx->ws) + ctx->ws_off, 0xFF, len, ctx->stream));
+    }
     return GPC_OK;
 }
 
@@ -308,7 +312,7 @@ static int gpc_aux_streams(gpc_ctx* ctx)
 // that one chunk's last workgroups and the next chunk's first ones overlap: the stream and workspace offset of the call in hand, set by
 // the calling thread around its _dev call and applied under the context lock.
 static thread_local hipStream_t tl_stream_override = nullptr;
-static thread_local size_t tl_ws_off = 0;
+static thread_local size_t tl_ws_off = 0, tl_ws_len = 0;
 
 // the one-wave kernel takes this batch (the rule of dense_dispatch_locked, also asked by dense_host before it splits a batch over two streams)
 static bool dense_w1_takes(const gpc_ctx* ctx, const DenseArgs& a)
@@ -316,7 +320,10 @@ static bool dense_w1_takes(const gpc_ctx* ctx, const DenseArgs& a)
     const char* mp = getenv("GPC_W1_MIN_P");
     const int min_p = mp ? atoi(mp) : 4 * ctx->num_cus;
     const bool force = getenv("GPC_FORCE_GENERIC") || getenv("GPC_FORCE_BIG");
-    return !force && a.n_max <= 256 && a.P >= min_p && a.P > 1 && (a.n_max > 192 || !a.v_star) && dense_w1_supported(a) && !getenv("GPC_NO_W1");
+    // (round 4: the kernel's 512-point instance takes the depth plane of batches whose largest patch has 257 .. 512 points -- C3, and the
+    // ragged batches of a cloud cut for 256-point patches, which the size-class split used to deal to three kernels; GPC_NO_W1_512=1: as before)
+    if (a.n_max > 256 && getenv("GPC_NO_W1_512")) return false;
+    return !force && a.n_max <= 512 && a.P >= min_p && a.P > 1 && (a.n_max > 192 || !a.v_star) && dense_w1_supported(a) && !getenv("GPC_NO_W1");
 }
 
 static int dense_dispatch_locked(gpc_ctx* ctx, DenseArgs& a);
@@ -328,9 +335,11 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
     hipStream_t const saved = ctx->stream;
     if (tl_stream_override) ctx->stream = tl_stream_override;
     ctx->ws_off = tl_ws_off;
+    ctx->ws_len = tl_ws_len;
     const int rc = dense_dispatch_locked(ctx, a);
     ctx->stream = saved;
     ctx->ws_off = 0;
+    ctx->ws_len = 0;
     return rc;
 }
 
@@ -778,6 +787,7 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
         double* df = d_f + (size_t)p0 * ny * m;
         tl_stream_override = two ? sc : nullptr;
         tl_ws_off = (two && (c & 1)) ? half : 0;
+        tl_ws_len = two ? half : 0;
         if (grid)
             rc = gpc_dense_fit_predict_grid_dev(ctx, params, Pc, d_off_c, nmax_c, (int)Nc, dx0, dx1, dy, ny, res, sz, df,
                                                 alpha_out ? d_al + r0 * ny : nullptr, d_st + p0);
@@ -786,6 +796,7 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
                                            want_v ? d_v + (size_t)p0 * m : nullptr, alpha_out ? d_al + r0 * ny : nullptr, d_st + p0);
         tl_stream_override = nullptr;
         tl_ws_off = 0;
+        tl_ws_len = 0;
         if (rc != GPC_OK) { fail = rc; break; }
         GPC_HIP(ctx, hipEventRecord(ctx->ev[1][c], sc));
         GPC_HIP(ctx, hipStreamWaitEvent(so, ctx->ev[1][c], 0));

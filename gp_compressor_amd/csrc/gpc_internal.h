@@ -28,6 +28,7 @@ struct gpc_ctx {
     // grow-only device workspace (K / L factors of the generic dense kernel, variance scratch, grid tables)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    size_t ws_len = 0;                 // ... and its length (0: to the end of the workspace); GPC_POISON_LDS poisons only this region
     size_t ws_off = 0;                 // offset of the region the launch in hand may use (the host-pointer pipeline runs the kernels of
                                        // consecutive chunks on two streams, each in its own half; 0 everywhere else)
     int32_t* tickets = nullptr;        // 64 counters (allocated on first use): patches handed out one at a time where their cost varies (dense_mfma_big.hip)

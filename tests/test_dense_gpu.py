@@ -118,6 +118,8 @@ def test_dense_vs_oracle(gp, oracle, kernel_choice, P, n, ny, ragged, seed):
     uniform = int(np.min(np.diff(off))) == n_max        # one size class, known on the host (P n_max == n_total): no split launches
     want_kernel = {"generic": "dense_generic", "big": "dense_mfma_big", "big_w4": "dense_mfma_big"}.get(
         kernel_choice, ("dense_mfma_nt16 + " if (P > 1 and not (uniform and n_max > 272)) else "dense_mfma_big") if n_max > 256 else want_small)
+    if kernel_choice == "dispatch" and 256 < n_max <= 512 and y.shape[0] == 1 and P > 1:
+        want_kernel = "dense_mfma_w1_512"       # round 4: the 512-point instance of the one-wave kernel takes the depth plane up to 512 points
     assert ctx.last_dense_kernel().startswith(want_kernel), ctx.last_dense_kernel()
     assert np.array_equal(st, so)
     _close(f, fo, FTOL)
@@ -254,6 +256,57 @@ def test_dense_one_wave_kernel_edge_cases(gp, oracle, monkeypatch, want_var):
     if want_var:
         assert np.all(np.isnan(v3[1])) and np.all(np.isfinite(v3[[0, 2]]))
     _close(f3[[0, 2]], fo3[[0, 2]], 1e-7)          # (zero noise: conditioned by the closest pairs of points)
+
+
+def test_dense_one_wave_kernel_512_instance(gp, oracle, monkeypatch):
+    """Round 4: the one-wave kernel's 512-point instance (dense_w1_kernel<512>: the depth plane of batches whose largest patch has
+    257 .. 512 points -- BASELINE config 3, and the ragged batches of a cloud cut for 256-point patches, which the size-class split dealt to
+    three kernels).  A batch that mixes every tile count 1 .. 32 with sizes on and next to tile boundaries, empty patches, a single point;
+    against the oracle (f* and the weights), grid and point-wise entries; against the tiled kernel path it replaces (GPC_NO_W1_512); slot
+    reuse gives the same bits; a non-SPD patch in the middle of the batch (failing pivot in tile column 20) leaves its neighbours alone."""
+    capi, ctx = gp
+    monkeypatch.setenv("GPC_W1_MIN_P", "2")
+    res, sz = 0.15, 12
+    sizes = [512, 0, 1, 16, 17, 255, 256, 257, 272, 273, 288, 300, 320, 321, 352, 383, 384, 385, 400, 416, 447, 448, 449, 480, 496, 497, 511, 512, 0, 130, 64]
+    off, x0, x1, y = _mixed_batch(sizes, seed=15)
+    xs0, xs1 = oracle.grid(res, sz)
+    p = capi.default_params_dense()
+    f, _, st, al = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
+    assert ctx.last_dense_kernel() == "dense_mfma_w1_512"
+    fo, _, so, ao = oracle.dense_fit_predict_batch(oracle.dense_params(), off, x0, x1, y, xs0, xs1, want_alpha=True)
+    assert np.array_equal(st, so) and np.all(st == 0)
+    _close(f, fo, FTOL)
+    _close(al, ao, ATOL)
+    fg, stg = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz)
+    assert ctx.last_dense_kernel() == "dense_mfma_w1_512" and np.all(stg == 0)
+    _close(fg, fo, FTOL)
+    monkeypatch.setenv("GPC_W1_SLOTS", "5")
+    f2, _, st2, al2 = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
+    monkeypatch.delenv("GPC_W1_SLOTS")
+    assert np.array_equal(f2, f) and np.array_equal(al2, al) and np.array_equal(st2, st)
+    monkeypatch.setenv("GPC_NO_W1_512", "1")
+    f3, _, st3, al3 = ctx.dense_fit_predict(p, off, x0, x1, y, xs0, xs1, want_alpha=True)
+    monkeypatch.delenv("GPC_NO_W1_512")
+    assert "w1_512" not in ctx.last_dense_kernel() and np.array_equal(st3, st)
+    _close(f3, f, FTOL)
+    # the variance still goes the tiled kernel's way above 256 points
+    pv = capi.default_params_dense(want_variance=1)
+    fv, vv, stv = ctx.dense_fit_predict(pv, off, x0, x1, y, xs0, xs1)
+    assert ctx.last_dense_kernel().endswith("dense_variance_big") and np.all(stv == 0)
+    _close(fv, fo, FTOL)
+    # not SPD: a duplicated point under zero noise, failing pivot at point 330 (tile column 20)
+    kw0 = dict(sigmaf_sq=1.0, l_sq=0.006 ** 2, noise=0.0)
+    p0 = capi.default_params_dense(**kw0)
+    off4, x04, x14, y4 = _mixed_batch([400, 500, 512], seed=16)
+    x04[off4[1] + 330] = x04[off4[1] + 35]
+    x14[off4[1] + 330] = x14[off4[1] + 35]
+    f4, _, st4, al4 = ctx.dense_fit_predict(p0, off4, x04, x14, y4, xs0, xs1, want_alpha=True)
+    fo4, _, so4 = oracle.dense_fit_predict_batch(oracle.dense_params(kw0["sigmaf_sq"], kw0["l_sq"], 0.0), off4, x04, x14, y4, xs0, xs1)
+    assert ctx.last_dense_kernel() == "dense_mfma_w1_512"
+    # (the oracle tests the pivot against 0: whether the duplicate leaves +1e-17 or -1e-17 there is luck; the kernels' threshold is relative)
+    assert st4.tolist() == [0, 1, 0] and so4[0] == 0 and so4[2] == 0
+    assert np.all(np.isnan(f4[1])) and np.all(np.isnan(al4[0, off4[1]:off4[2]])) and np.all(np.isfinite(f4[[0, 2]]))
+    _close(f4[[0, 2]], fo4[[0, 2]], 1e-7)
 
 
 @pytest.mark.parametrize("l_sq,shift,tol", [(0.05 ** 2, 0.0, 1e-8), (0.5 ** 2, 0.0, FTOL), (9.0, 0.4, FTOL), (9.0, 30.0, FTOL)])
@@ -514,7 +567,7 @@ def test_dense_full_size_properties(gp, oracle, P, n, label):
     y2 = rng.normal(0, 0.01, size=y.shape)
     p = capi.default_params_dense()
     fa, sta, ala = ctx.dense_fit_predict_grid(p, off, x0, x1, y, res, sz, want_alpha=True)
-    assert ctx.last_dense_kernel() == "dense_mfma_w1" if n <= 256 else ctx.last_dense_kernel().endswith("dense_mfma_big")
+    assert ctx.last_dense_kernel() == {256: "dense_mfma_w1", 512: "dense_mfma_w1_512", 1024: "dense_mfma_big"}[n], ctx.last_dense_kernel()
     fb, stb = ctx.dense_fit_predict_grid(p, off, x0, x1, y2, res, sz)
     fc, stc = ctx.dense_fit_predict_grid(p, off, x0, x1, y + 2.0 * y2, res, sz)
     assert np.all(sta == 0) and np.all(stb == 0) and np.all(stc == 0)

@@ -26,7 +26,7 @@ DST = os.path.join(ROOT, "profiles")
 WORK = {
     "c2": ("dense_w1_kernel", 5, 1, "dense_mfma_w1", None),
     "c2var": ("dense_variance_kernel<16,", 1, 1, "dense_variance@C2", None),
-    "c3": ("dense_big_kernel<4, 512, 2, 2, false, 4, 1>", 1, 1, "dense_mfma_big@n512", None),
+    "c3": ("dense_w1_kernel<512>", 1, 1, "dense_mfma_w1_512", None),
     "c4fill": ("sparse_add_", 4, 4, "sparse_add@C4_fill", 32768 * 256),      # one pass = 4 add calls (rows + small-basis + regular kernel each)
     "c4defaults": ("sparse_add_", 4, 4, "sparse_add@C4_defaults", 32768 * 256),
     "c4defaults3": ("sparse_add_", 4, 4, "sparse_add@C4_defaults_ny3", 32768 * 256),
