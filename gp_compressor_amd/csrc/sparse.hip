@@ -1924,17 +1924,50 @@ static size_t sp_pred_lds(int ld, bool sigma, bool fast)
 
 // The two instances of the small-basis predict kernel (b <= 16, 17 .. 32), ahead of sparse_predict_kernel on the same stream; sets
 // A.small_max so that the regular kernel skips what they took.  GPC_SPARSE_NO_SMALL_PREDICT=1: everything through the regular kernel.
-static int sp_predict_small_launch(gpc_ctx* ctx, SpPredParams& A)
+// The predict launches: the two instances of the small-basis kernel (b <= 16, 17 .. 32) and sparse_predict_kernel for the rest (it skips what
+// they took: A.small_max).  The three work on disjoint patches, and at the reference's defaults each is a short launch that ends in a tail of a few
+// long patches: they run SIDE BY SIDE on the context's stream and its two copy streams (forked and joined with events; the streams exist since
+// gpc_ctx_create).  GPC_SPARSE_NO_SMALL_PREDICT=1: everything through the regular kernel; GPC_SPARSE_PREDICT_NO_FORK=1: one after the other.
+static int sp_predict_launch(gpc_ctx* ctx, SpPredParams& A, int grid, size_t lds)
 {
     A.small_max = -1;
-    if (getenv("GPC_SPARSE_NO_SMALL_PREDICT") || A.ld < 1) return GPC_OK;
+    hipStream_t main_s = ctx->stream;
+    if (getenv("GPC_SPARSE_NO_SMALL_PREDICT") || A.ld < 1) {
+        hipLaunchKernelGGL(sparse_predict_kernel, dim3(grid), dim3(SP_THREADS), lds, main_s, A);
+        GPC_HIP(ctx, hipGetLastError());
+        return GPC_OK;
+    }
+    const bool fork = ctx->s_in && ctx->s_out && !getenv("GPC_SPARSE_PREDICT_NO_FORK");
+    hipStream_t s32 = fork ? ctx->s_in : main_s, sreg = fork ? ctx->s_out : main_s;
+    // (the legacy default stream does not overlap its kernels with another stream's -- gpc_api.hip, dense_host: the third launch goes to the
+    // context's own stream then)
+    hipStream_t s16 = (fork && (main_s == nullptr || main_s == hipStreamPerThread) && ctx->own_stream) ? ctx->own_stream : main_s;
+    if (fork) {
+        GPC_HIP(ctx, hipEventRecord(ctx->ev[0][14], main_s));
+        GPC_HIP(ctx, hipStreamWaitEvent(s32, ctx->ev[0][14], 0));
+        GPC_HIP(ctx, hipStreamWaitEvent(sreg, ctx->ev[0][14], 0));
+        if (s16 != main_s) GPC_HIP(ctx, hipStreamWaitEvent(s16, ctx->ev[0][14], 0));
+    }
     const int waves = std::min(A.P, ctx->num_cus * (getenv("GPC_SP_SMALL_WAVES") ? atoi(getenv("GPC_SP_SMALL_WAVES")) : 16));
     const size_t l16 = sizeof(double) * (size_t)(64 + 16 * 16 + 5 * 16), l32 = sizeof(double) * (size_t)(64 + 32 * 32 + 5 * 32);
-    hipLaunchKernelGGL((sparse_predict_small_kernel<16>), dim3(waves), dim3(64), l16, ctx->stream, A, 0);
-    GPC_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL((sparse_predict_small_kernel<32>), dim3(std::min(A.P, ctx->num_cus * 12)), dim3(64), l32, ctx->stream, A, 17);
-    GPC_HIP(ctx, hipGetLastError());
     A.small_max = 32;
+    // (the regular kernel first: its few patches are the longest)
+    hipLaunchKernelGGL(sparse_predict_kernel, dim3(grid), dim3(SP_THREADS), lds, sreg, A);
+    GPC_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL((sparse_predict_small_kernel<32>), dim3(std::min(A.P, ctx->num_cus * 12)), dim3(64), l32, s32, A, 17);
+    GPC_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL((sparse_predict_small_kernel<16>), dim3(waves), dim3(64), l16, s16, A, 0);
+    GPC_HIP(ctx, hipGetLastError());
+    if (fork) {
+        GPC_HIP(ctx, hipEventRecord(ctx->ev[1][14], s32));
+        GPC_HIP(ctx, hipEventRecord(ctx->ev[2][14], sreg));
+        GPC_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev[1][14], 0));
+        GPC_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev[2][14], 0));
+        if (s16 != main_s) {
+            GPC_HIP(ctx, hipEventRecord(ctx->ev[1][12], s16));
+            GPC_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev[1][12], 0));
+        }
+    }
     return GPC_OK;
 }
 
@@ -2168,10 +2201,7 @@ int gpc_sparse_predict_dev(gpc_sparse* g, int m, const double* xs0, const double
     { const int cap_blocks = sigma ? 4 : 8;   // mean only: a patch is a few hundred kernel evaluations, more resident blocks hide their latency
       per_cu = per_cu > cap_blocks ? cap_blocks : (per_cu < 1 ? 1 : per_cu); }
     int grid = std::min(g->P, ctx->num_cus * per_cu);
-    if (int rcs = sp_predict_small_launch(ctx, A)) return rcs;
-    hipLaunchKernelGGL(sparse_predict_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
-    GPC_HIP(ctx, hipGetLastError());
-    return GPC_OK;
+    return sp_predict_launch(ctx, A, grid, lds);
 }
 
 // predict_measurements on every patch's OWN point set (ragged, like the add call's batch): the reference's per-patch training-set
@@ -2203,10 +2233,7 @@ int gpc_sparse_predict_points_dev(gpc_sparse* g, const int32_t* off, int n_total
     int per_cu = (int)((160u * 1024u) / lds);
     per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
     int grid = std::min(g->P, ctx->num_cus * per_cu);
-    if (int rcs = sp_predict_small_launch(ctx, A)) return rcs;
-    hipLaunchKernelGGL(sparse_predict_kernel, dim3(grid), dim3(SP_THREADS), lds, ctx->stream, A);
-    GPC_HIP(ctx, hipGetLastError());
-    return GPC_OK;
+    return sp_predict_launch(ctx, A, grid, lds);
 }
 
 // caller holds ctx->mu.  raw != nullptr: the train_sigmaf pass (sigma_f^2 = 1, per-point sums only)
