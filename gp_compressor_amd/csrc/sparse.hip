@@ -1937,7 +1937,9 @@ static int sp_predict_launch(gpc_ctx* ctx, SpPredParams& A, int grid, size_t lds
         GPC_HIP(ctx, hipGetLastError());
         return GPC_OK;
     }
-    const bool fork = ctx->s_in && ctx->s_out && !getenv("GPC_SPARSE_PREDICT_NO_FORK");
+    // (with sigma only: measured at the reference's defaults, 32768 patches -- sigma-predict 1.14 -> 0.84 ms; the mean-only launches are too
+    // short to pay for the fork and join, 0.23 -> 0.28 ms)
+    const bool fork = ctx->s_in && ctx->s_out && A.sigma != nullptr && !getenv("GPC_SPARSE_PREDICT_NO_FORK");
     hipStream_t s32 = fork ? ctx->s_in : main_s, sreg = fork ? ctx->s_out : main_s;
     // (the legacy default stream does not overlap its kernels with another stream's -- gpc_api.hip, dense_host: the third launch goes to the
     // context's own stream then)
