@@ -735,6 +735,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ctx = capi.Context(local_rank)
+    # Everything of the bench runs on ONE non-default stream: torch's current stream is the legacy default stream otherwise, and on this
+    # runtime a kernel on the legacy stream does not overlap with work on any other stream (measured) -- at N > 1 the
+    # all-gather of step k, on its side stream, would serialise with the kernel of step k + 1 instead of hiding under it.
+    if os.environ.get("GPC_BENCH_LEGACY_STREAM") != "1":
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels and events share torch's current stream
     env = {"ctx": ctx, "dev": dev, "world": world, "rank": rank, "use_dist": use_dist}
     cpu = world == 1 and not use_dist and not args.no_cpu_baseline
