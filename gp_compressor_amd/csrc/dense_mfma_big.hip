@@ -127,6 +127,16 @@ __device__ static __forceinline__ d4 bg_mfma4_neg(d4 a, d4 b, d4 acc)
 // eigenvalues >= 1 however far the weights spread; the tile TRSMs here multiply by explicit 16 x 16 inverses, which is only
 // as accurate as the tiles are well conditioned): u = B^-1 W^1/2 t, a = W^1/2 u -- the same Newton iterate.  Definition and stopping rule: oracle/gpc_oracle.c (orc_dense_irls_fit).  ny == 1; the unused colour planes of
 // the solve vectors hold f, d, t and the labels.
+// The link functor of the IRLS instances, called OUT OF LINE: inlined, its ~60 polynomial constants (erfc, log) are materialised ahead of
+// the Newton loop and then live -- as spills -- across the whole factorisation (476 B/lane of scratch in the 1024 instance; 144 with the
+// call, C5 +3 %, round 4).  It runs n times per Newton iteration next to n^3/3 of factorisation work: the call costs nothing measurable.
+struct bg_qr { double q, r; };
+__device__ __attribute__((noinline)) static bg_qr bg_probit_call(int model, double noise, double y, double f)
+{
+    bg_qr o;
+    gpc_probit_q_r(model, noise, y, f, 0.0, &o.q, &o.r);
+    return o;
+}
 template <int BG_WAVES, int BG_NPAD, int BG_RMAX, int BG_OCC, bool BG_IRLS = false, int BG_C = 4, int BG_NYP = 3>
 __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigParams g)
 {
@@ -334,8 +344,8 @@ __global__ __launch_bounds__(BG_WAVES * 64, BG_OCC) void dense_big_kernel(BigPar
             for (int i = tid; i < BG_NPAD; i += BG_THREADS) {
                 double rs = 0.0, ss = 0.0, tt = 0.0;
                 if (i < n) {
-                    double q_, r_;
-                    gpc_probit_q_r(g.irls_model, noise, yl[i], fv[i], 0.0, &q_, &r_);
+                    const bg_qr qr_ = bg_probit_call(g.irls_model, noise, yl[i], fv[i]);
+                    const double q_ = qr_.q, r_ = qr_.r;
                     const double W = -r_;
                     if (!(W > 0.0) || !(W < __builtin_inf()) || q_ != q_) badw = 1;
                     tt = fv[i] + q_ * (1.0 / W);

@@ -687,11 +687,24 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
         DenseArgs probe{};
         probe.prm = *params;
         probe.P = P / 8; probe.n_max = n_max; probe.ny = ny; probe.m = m;
+        probe.n_total = n_total;                       // (upper bound of a chunk's: the variance path keeps one weight per point in its half)
         probe.v_star = want_v ? v_star : nullptr;
         probe.xs0 = grid ? nullptr : xs0;
         // (measured on the C2 batch, same box: 1.95 against 2.12 ms per call, 4.2 against 3.87 M patches/s PCIe-inclusive; at 128 points per
         // patch the kernel is a third of the call and eight chunks only add transfers' fixed costs -- 1.09 against 0.96 ms -- hence n_max > 160)
-        if (C == 4 && P >= 8192 && n_max > 160 && !alpha_out && !getenv("GPC_HOST_ONE_STREAM") && dense_w1_takes(ctx, probe)) {
+        // EVERY chunk must go to the one-wave kernel: the other kernels know nothing of workspace halves (a chunk of small patches with
+        // the variance wanted goes to the register kernel, whose factor export starts at the base of the workspace)
+        bool all_w1 = C == 4 && P >= 8192 && n_max > 160 && !alpha_out && !getenv("GPC_HOST_ONE_STREAM") && ctx->own_stream != nullptr;
+        for (int c = 0; c < 8 && all_w1; ++c) {
+            const int p0 = (int)((long long)P * c / 8), p1 = (int)((long long)P * (c + 1) / 8);
+            int nm = 1;
+            for (int i = p0; i < p1; ++i) nm = std::max(nm, off[i + 1] - off[i]);
+            DenseArgs pc = probe;
+            pc.P = p1 - p0;
+            pc.n_max = nm;
+            all_w1 = dense_w1_takes(ctx, pc);
+        }
+        if (all_w1) {
             probe.P = (P + 7) / 8;
             half = (dense_w1_ws_bytes(ctx, probe, nullptr) + 255) & ~(size_t)255;
             if (gpc_ws_reserve(ctx, 2 * half) == GPC_OK) {
@@ -747,9 +760,12 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
     int p_lo[9];
     for (int c = 0; c <= C; ++c) p_lo[c] = (int)((long long)P * c / C);
     const hipStream_t sc_main = sc;
-    // (the legacy default stream -- what a context bound to torch's current stream runs on -- does not overlap its kernels with another
-    // stream's: 2.49 against 1.98 ms per C2 call; the call is synchronous for the caller anyway, so both compute streams are then ours)
-    const hipStream_t sc_a = (two && (sc_main == nullptr || sc_main == hipStreamPerThread)) ? ctx->own_stream : sc_main;
+    // Both compute streams of the two-stream mode are the context's own (the call is synchronous for the caller anyway; its stream is
+    // ordered in front of and behind them with events).  Two reasons, both measured: the legacy default stream does not overlap its
+    // kernels with another stream's (2.49 against 1.98 ms per C2 call), and HIP deals streams onto its four hardware queues in creation
+    // order, so a caller's stream made before the context can share a queue with s_c2 and serialise the pair (2.46 against 2.0 ms with
+    // the bench on a torch side stream) -- own_stream, s_in, s_out and s_c2 are created back to back and never share one.
+    const hipStream_t sc_a = two ? ctx->own_stream : sc_main;
     int fail = GPC_OK;
     for (int c = 0; c < C && fail == GPC_OK; ++c) {
         const int p0 = p_lo[c], Pc = p_lo[c + 1] - p0;

@@ -1941,9 +1941,9 @@ static int sp_predict_launch(gpc_ctx* ctx, SpPredParams& A, int grid, size_t lds
     // short to pay for the fork and join, 0.23 -> 0.28 ms)
     const bool fork = ctx->s_in && ctx->s_out && A.sigma != nullptr && !getenv("GPC_SPARSE_PREDICT_NO_FORK");
     hipStream_t s32 = fork ? ctx->s_in : main_s, sreg = fork ? ctx->s_out : main_s;
-    // (the legacy default stream does not overlap its kernels with another stream's -- gpc_api.hip, dense_host: the third launch goes to the
-    // context's own stream then)
-    hipStream_t s16 = (fork && (main_s == nullptr || main_s == hipStreamPerThread) && ctx->own_stream) ? ctx->own_stream : main_s;
+    // (the third launch goes to the context's OWN stream: the legacy default stream does not overlap its kernels with another stream's, and
+    // a caller's stream may share a hardware queue with s_in or s_out -- gpc_api.hip, dense_host; own_stream, s_in and s_out never do)
+    hipStream_t s16 = (fork && ctx->own_stream) ? ctx->own_stream : main_s;
     if (fork) {
         GPC_HIP(ctx, hipEventRecord(ctx->ev[0][14], main_s));
         GPC_HIP(ctx, hipStreamWaitEvent(s32, ctx->ev[0][14], 0));

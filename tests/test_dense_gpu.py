@@ -713,3 +713,42 @@ def test_host_pointer_entry_pipeline_and_pinned_buffers(gp, oracle, monkeypatch)
     _, vo, _ = oracle.dense_fit_predict_batch(oracle.dense_params(), np.array([0, off[i + 1] - off[i]], dtype=np.int32), x0[sl], x1[sl],
                                               y[:1, sl], xs0, xs1, variance=True)
     assert np.max(np.abs(vv[i] - vo[0])) <= VTOL
+
+
+@pytest.mark.gpu
+def test_host_pointer_two_stream_mode_with_a_chunk_of_small_patches(gp, oracle, monkeypatch):
+    """The two-stream form of the host-pointer pipeline (eight chunks, kernels of consecutive chunks on two streams, each in its own half of
+    the workspace: csrc/gpc_api.hip, dense_host) is for batches whose EVERY chunk goes to the one-wave kernel.  With the variance wanted a
+    chunk of patches of <= 192 points goes to the register kernel, whose factor export starts at the base of the workspace -- under the
+    other stream's live factor slots if the pipeline forked anyway (round 4 did, up to this test).  Batch: 8192 patches of 250 points with
+    patches 1024 .. 2047 (chunk 1) cut to 150; the call must equal the one-stream form and the oracle on patches of both kinds."""
+    capi, ctx = gp
+    P, res, sz = 8192, 0.15, 8
+    off_f, x0_f, x1_f, y_f = synth.make_patches(P, 250, res=res, seed=131)
+    counts = np.full(P, 250)
+    counts[1024:2048] = 150
+    keep = (np.arange(250)[None, :] < counts[:, None]).reshape(-1)
+    off = np.zeros(P + 1, dtype=np.int32)
+    off[1:] = np.cumsum(counts)
+    x0, x1, y = np.ascontiguousarray(x0_f[keep]), np.ascontiguousarray(x1_f[keep]), np.ascontiguousarray(y_f[:, keep])
+    xs0, xs1 = synth.grid(res, sz)
+    pv = capi.default_params_dense(want_variance=1)
+    f, v, st = ctx.dense_fit_predict(pv, off, x0, x1, y, xs0, xs1)
+    monkeypatch.setenv("GPC_HOST_ONE_STREAM", "1")
+    f1, v1, st1 = ctx.dense_fit_predict(pv, off, x0, x1, y, xs0, xs1)
+    monkeypatch.delenv("GPC_HOST_ONE_STREAM")
+    assert np.all(st == 0) and np.array_equal(st, st1)
+    assert np.max(np.abs(f - f1)) <= 1e-12 * np.max(np.abs(f1)) and np.max(np.abs(v - v1)) <= 1e-12 * np.max(np.abs(v1))
+    for i in (0, 1023, 1024, 1500, 2047, 2048, 5000, 8191):
+        sl = slice(off[i], off[i + 1])
+        fo, vo, _ = oracle.dense_fit_predict_batch(oracle.dense_params(), np.array([0, off[i + 1] - off[i]], dtype=np.int32), x0[sl], x1[sl],
+                                                   y[:, sl], xs0, xs1, variance=True)
+        _close(f[i], fo[0], FTOL)
+        assert np.max(np.abs(v[i] - vo[0])) <= VTOL
+    # the same batch without the variance: every chunk is the one-wave kernel's, the pipeline forks, same results as the single stream's
+    pm = capi.default_params_dense()
+    g2, _, s2 = ctx.dense_fit_predict(pm, off, x0, x1, y, xs0, xs1)
+    monkeypatch.setenv("GPC_HOST_ONE_STREAM", "1")
+    g1, _, s1 = ctx.dense_fit_predict(pm, off, x0, x1, y, xs0, xs1)
+    assert np.all(s2 == 0) and np.array_equal(s1, s2) and np.array_equal(g1, g2)
+    _close(g2[:, 0, :], f1[:, 0, :], 1e-9)
