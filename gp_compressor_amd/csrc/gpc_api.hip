@@ -124,7 +124,7 @@ int gpc_ctx_synchronize(gpc_ctx* ctx)
 {
     if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     GPC_HIP(ctx, hipSetDevice(ctx->device));
-    GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GPC_HIP(ctx, hipStreamSynchronize(gpc_stream_of(ctx)));
     return GPC_OK;
 }
 
@@ -143,7 +143,7 @@ int gpc_dev_free(gpc_ctx* ctx, void* p)
     if (!ctx || ctx->dead.load()) return GPC_EINVAL;
     if (!p) return GPC_OK;
     GPC_HIP(ctx, hipSetDevice(ctx->device));
-    GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));     // nothing enqueued may still be using it
+    GPC_HIP(ctx, hipStreamSynchronize(gpc_stream_of(ctx)));     // nothing enqueued may still be using it
     GPC_HIP(ctx, hipFree(p));
     return GPC_OK;
 }
@@ -175,8 +175,9 @@ int gpc_dev_memcpy(gpc_ctx* ctx, void* dst, const void* src, size_t bytes, int k
                           : kind == GPC_COPY_D2D ? hipMemcpyDeviceToDevice : hipMemcpyDefault;
     if (k == hipMemcpyDefault) return gpc_fail(ctx, GPC_EINVAL, "kind must be GPC_COPY_H2D, _D2H or _D2D");
     GPC_HIP(ctx, hipSetDevice(ctx->device));
-    GPC_HIP(ctx, hipMemcpyAsync(dst, src, bytes, k, ctx->stream));
-    GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t s = gpc_stream_of(ctx);
+    GPC_HIP(ctx, hipMemcpyAsync(dst, src, bytes, k, s));
+    GPC_HIP(ctx, hipStreamSynchronize(s));
     return GPC_OK;
 }
 
@@ -313,6 +314,7 @@ static int gpc_aux_streams(gpc_ctx* ctx)
 // the calling thread around its _dev call and applied under the context lock.
 static thread_local hipStream_t tl_stream_override = nullptr;
 static thread_local size_t tl_ws_off = 0, tl_ws_len = 0;
+static thread_local unsigned tl_seen_gen[2] = {0, 0};   // gpc_ctx::foreign_gen as the pipeline's two compute streams last saw it
 
 // the one-wave kernel takes this batch (the rule of dense_dispatch_locked, also asked by dense_host before it splits a batch over two streams)
 static bool dense_w1_takes(const gpc_ctx* ctx, const DenseArgs& a)
@@ -333,7 +335,20 @@ static int dense_dispatch(gpc_ctx* ctx, DenseArgs& a)
     if (a.n_max < 1) a.n_max = 1;
     std::lock_guard<std::mutex> lk(ctx->mu);
     hipStream_t const saved = ctx->stream;
-    if (tl_stream_override) ctx->stream = tl_stream_override;
+    if (tl_stream_override) {
+        // a chunk of the two-stream host pipeline.  If a call of another thread touched the workspace since this compute stream's last
+        // chunk (gpc_ws_reserve counts them and orders them behind the chunks enqueued before), the chunk goes behind the context's stream
+        // as it stands now: that call may use -- or re-grow and clear -- the region this chunk is about to write.
+        unsigned& seen = tl_seen_gen[tl_ws_off ? 1 : 0];
+        if (seen != ctx->foreign_gen) {
+            seen = ctx->foreign_gen;
+            if (saved != tl_stream_override) {
+                GPC_HIP(ctx, hipEventRecord(ctx->ev[2][10], saved));
+                GPC_HIP(ctx, hipStreamWaitEvent(tl_stream_override, ctx->ev[2][10], 0));
+            }
+        }
+        ctx->stream = tl_stream_override;
+    }
     ctx->ws_off = tl_ws_off;
     ctx->ws_len = tl_ws_len;
     const int rc = dense_dispatch_locked(ctx, a);
@@ -681,6 +696,16 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
     // through in EIGHT chunks: the first upload and the last download, which nothing overlaps, halve.  GPC_HOST_ONE_STREAM=1: as before.
     bool two = false;
     size_t half = 0;
+    struct PipeFlag {           // gpc_ctx::pipe_active for the duration of a two-stream call, whichever way it ends
+        gpc_ctx* c;
+        bool on;
+        ~PipeFlag()
+        {
+            if (!on) return;
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->pipe_active = false;
+        }
+    } pipe{ctx, false};
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         if ((rc = gpc_aux_streams(ctx))) return rc;
@@ -710,6 +735,8 @@ static int dense_host(gpc_ctx* ctx, const gpc_params* params, int P, const int32
             if (gpc_ws_reserve(ctx, 2 * half) == GPC_OK) {
                 two = true;
                 C = 8;
+                pipe.on = ctx->pipe_active = true;                 // (calls of other threads on this context: see gpc_ws_reserve)
+                tl_seen_gen[0] = tl_seen_gen[1] = ctx->foreign_gen;
             } else {
                 (void)hipGetLastError();
             }
@@ -949,7 +976,7 @@ int gpc_dense_irls_fit_predict(gpc_ctx* ctx, const gpc_params* params, const gpc
         (rc = d_fh.alloc(ctx, 8 * N)) || (rc = d_it.alloc(ctx, sizeof(int32_t) * P)) || (rc = d_st.alloc(ctx, sizeof(int32_t) * P)))
         return rc;
     if (!grid && ((rc = d_xs0.alloc(ctx, 8 * (size_t)m)) || (rc = d_xs1.alloc(ctx, 8 * (size_t)m)))) return rc;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = gpc_stream_of(ctx);
     GPC_HIP(ctx, hipMemcpyAsync(d_off.p, off, sizeof(int32_t) * (P + 1), hipMemcpyHostToDevice, s));
     if (N) {
         GPC_HIP(ctx, hipMemcpyAsync(d_x0.p, x0, 8 * N, hipMemcpyHostToDevice, s));

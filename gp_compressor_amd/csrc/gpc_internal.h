@@ -42,7 +42,9 @@ struct gpc_ctx {
     void* pin_out = nullptr;
     size_t pin_out_bytes = 0;
     hipStream_t s_in = nullptr, s_out = nullptr, s_c2 = nullptr;   // copy-in, copy-out, second compute stream
-    hipEvent_t ev[3][16] = {};       // [.][0 .. 7] the chunks of the host-pointer pipeline, [.][13] the class fork, [0][15] the arena
+    bool pipe_active = false;          // a two-stream host-pointer call is in flight on own_stream / s_c2 (under mu): see gpc_ws_reserve
+    unsigned foreign_gen = 0;          // ... and the number of calls of other threads that touched the workspace meanwhile
+    hipEvent_t ev[3][16] = {};       // [.][0 .. 7] the chunks of the host-pointer pipeline, [.][10] the pipeline against other threads' calls, [.][13] the class fork, [0][15] the arena
     std::mutex host_mu;                // one host-pointer call at a time per context (they share the arena)
     // size classes of the last batch gpc_project_cloud produced on this context (its `off` buffer, how many of its P patches have
     // <= 256 / <= 272 points): lets the dense dispatch size its class launches exactly instead of P workgroups each
@@ -83,9 +85,29 @@ static inline int gpc_fail(gpc_ctx* ctx, int code, const char* fmt, ...)
                             #call, hipGetErrorString(e_));                                              \
     } while (0)
 
+// The context's stream as the caller configured it, for code that does NOT hold ctx->mu: the dispatchers swap ctx->stream for the length of
+// a fork (class streams, the host pipeline's compute streams) and put it back before they unlock, so a read under the lock never sees a
+// fork's stream while a bare read from another thread can.
+static inline hipStream_t gpc_stream_of(gpc_ctx* ctx)
+{
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ctx->stream;
+}
+
 // grow-only workspace; returns nullptr + sets error on failure.  Caller holds ctx->mu.
 static inline int gpc_ws_reserve(gpc_ctx* ctx, size_t bytes)
 {
+    // "Thread-safe per context" (include/gpc.h) while a two-stream host-pointer call is in flight: its chunk kernels use the workspace from
+    // the context's two compute streams, which the stream of ANOTHER thread's call (ws_len == 0: not a chunk of the pipeline) is not
+    // ordered against.  Every user of the workspace comes through here first: that call goes behind the chunks already enqueued; the
+    // chunks enqueued after it go behind the context's stream in turn (dense_dispatch).
+    if (ctx->pipe_active && ctx->ws_len == 0 && !getenv("GPC_NO_PIPE_ORDER")) {   // (the switch: what the test of this looks like without it)
+        ++ctx->foreign_gen;
+        GPC_HIP(ctx, hipEventRecord(ctx->ev[0][10], ctx->own_stream));
+        GPC_HIP(ctx, hipEventRecord(ctx->ev[1][10], ctx->s_c2));
+        GPC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[0][10], 0));
+        GPC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[1][10], 0));
+    }
     if (bytes <= ctx->ws_bytes) return GPC_OK;
     // The new block is allocated BEFORE the old one is released: a request the device cannot serve leaves the context with the
     // workspace it had.  Only when old + new do not fit side by side is the old one given up first.

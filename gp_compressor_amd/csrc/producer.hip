@@ -836,7 +836,7 @@ int gpc_project_cloud(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, double
     void* d_cloud = nullptr;
     if (n > 0) {
         GPC_HIP(ctx, hipMalloc(&d_cloud, sizeof(gpc_point_xyzrgb) * (size_t)n));
-        hipError_t e = hipMemcpyAsync(d_cloud, cloud, sizeof(gpc_point_xyzrgb) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = hipMemcpyAsync(d_cloud, cloud, sizeof(gpc_point_xyzrgb) * (size_t)n, hipMemcpyHostToDevice, gpc_stream_of(ctx));
         if (e != hipSuccess) {
             (void)hipFree(d_cloud);
             return gpc_fail(ctx, GPC_EHIP, "gpc_project_cloud: upload failed: %s", hipGetErrorString(e));
@@ -844,7 +844,7 @@ int gpc_project_cloud(gpc_ctx* ctx, const gpc_point_xyzrgb* cloud, int n, double
     }
     const int rc = gpc_project_cloud_dev(ctx, (const gpc_point_xyzrgb*)d_cloud, n, res, sz, out);
     if (d_cloud) {
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(gpc_stream_of(ctx));
         (void)hipFree(d_cloud);
     }
     return rc;
@@ -870,9 +870,10 @@ int gpc_patches_fetch(const gpc_patches* p, int32_t* off, double* x0, double* x1
         {off, v.off, 4 * (P + 1)}, {x0, v.x0, 8 * N}, {x1, v.x1, 8 * N}, {y, v.y, 8 * N}, {rgb, v.rgb, 24 * N},
         {rotations, v.rotations, 72 * P}, {means, v.means, 24 * P}, {rgb_means, v.rgb_means, 24 * P}, {W, v.W, P * (size_t)v.m},
         {src, v.src, 4 * N}};
+    hipStream_t s = gpc_stream_of(ctx);
     for (auto& c : cp)
-        if (c.dst && c.bytes) GPC_HIP(ctx, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToHost, ctx->stream));
-    GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (c.dst && c.bytes) GPC_HIP(ctx, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToHost, s));
+    GPC_HIP(ctx, hipStreamSynchronize(s));
     return GPC_OK;
 }
 

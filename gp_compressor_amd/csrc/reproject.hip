@@ -130,7 +130,7 @@ int gpc_reproject(gpc_ctx* ctx, int P, int m, const int32_t* bv_count, const dou
     if (!xs0 || !xs1 || !f_star || !rotations || !means || !cloud) return gpc_fail(ctx, GPC_EINVAL, "xs0/xs1/f_star/rotations/means/cloud is NULL");
     if (c_star && !rgb_means) return gpc_fail(ctx, GPC_EINVAL, "c_star needs rgb_means");
     GPC_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    hipStream_t s = gpc_stream_of(ctx);
     const size_t Pm = (size_t)P * m;
     void *d_bv = nullptr, *d_xs0 = nullptr, *d_xs1 = nullptr, *d_f = nullptr, *d_c = nullptr, *d_R = nullptr, *d_mu = nullptr,
          *d_cm = nullptr, *d_cloud = nullptr, *d_n = nullptr;

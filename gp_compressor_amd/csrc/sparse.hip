@@ -2343,7 +2343,7 @@ int gpc_sparse_train_sigmaf(gpc_sparse* g, const int32_t* off, const double* x0,
         for (void* p : {d_off, d_x0, d_x1, d_y, d_p0, d_it, d_ls, d_de})
             if (p) (void)hipFree(p);
     };
-    hipStream_t s = ctx->stream;
+    hipStream_t s = gpc_stream_of(ctx);
     hipError_t e = hipMalloc(&d_off, 4 * (Pz + 1));
     if (e == hipSuccess) e = hipMalloc(&d_x0, 8 * (N + 1));
     if (e == hipSuccess) e = hipMalloc(&d_x1, 8 * (N + 1));
@@ -2396,7 +2396,7 @@ int gpc_sparse_likelihood(gpc_sparse* g, const int32_t* off, const double* x0, c
         for (void* p : {d_off, d_x0, d_x1, d_y, d_dX, d_l})
             if (p) (void)hipFree(p);
     };
-    hipStream_t s = ctx->stream;
+    hipStream_t s = gpc_stream_of(ctx);
     hipError_t e = hipMalloc(&d_off, 4 * (size_t)(P + 1));
     if (e == hipSuccess) e = hipMalloc(&d_x0, 8 * N);
     if (e == hipSuccess) e = hipMalloc(&d_x1, 8 * N);
@@ -2452,7 +2452,7 @@ int gpc_sparse_add(gpc_sparse* g, const int32_t* off, const double* x0, const do
         for (void* p : {d_off, d_x0, d_x1, d_y, d_perm, d_st})
             if (p) (void)hipFree(p);
     };
-    hipStream_t s = ctx->stream;
+    hipStream_t s = gpc_stream_of(ctx);
     hipError_t e = hipMalloc(&d_off, 4 * (size_t)(P + 1));
     if (e == hipSuccess) e = hipMalloc(&d_x0, 8 * std::max<size_t>(N, 1));
     if (e == hipSuccess) e = hipMalloc(&d_x1, 8 * std::max<size_t>(N, 1));
@@ -2495,7 +2495,7 @@ int gpc_sparse_predict(gpc_sparse* g, int m, const double* xs0, const double* xs
         for (void* p : {d_xs0, d_xs1, d_f, d_s, d_st})
             if (p) (void)hipFree(p);
     };
-    hipStream_t s = ctx->stream;
+    hipStream_t s = gpc_stream_of(ctx);
     const size_t fbytes = 8 * (size_t)P * g->ny * m, sbytes = 8 * (size_t)P * m;
     hipError_t e = hipMalloc(&d_xs0, 8 * (size_t)m);
     if (e == hipSuccess) e = hipMalloc(&d_xs1, 8 * (size_t)m);
@@ -2541,7 +2541,7 @@ int gpc_sparse_predict_points(gpc_sparse* g, const int32_t* off, const double* x
         for (void* p : {d_off, d_x0, d_x1, d_f, d_s, d_st})
             if (p) (void)hipFree(p);
     };
-    hipStream_t s = ctx->stream;
+    hipStream_t s = gpc_stream_of(ctx);
     const size_t N1 = std::max<size_t>(N, 1);
     hipError_t e = hipMalloc(&d_off, 4 * (size_t)(P + 1));
     if (e == hipSuccess) e = hipMalloc(&d_x0, 8 * N1);
@@ -2577,8 +2577,9 @@ int gpc_sparse_sizes(gpc_sparse* g, int32_t* bv_count)
     if (!bv_count) return gpc_fail(ctx, GPC_EINVAL, "bv_count is NULL");
     if (g->P == 0) return GPC_OK;
     GPC_HIP(ctx, hipSetDevice(ctx->device));
-    GPC_HIP(ctx, hipMemcpyAsync(bv_count, g->b, 4 * (size_t)g->P, hipMemcpyDeviceToHost, ctx->stream));
-    GPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t s = gpc_stream_of(ctx);
+    GPC_HIP(ctx, hipMemcpyAsync(bv_count, g->b, 4 * (size_t)g->P, hipMemcpyDeviceToHost, s));
+    GPC_HIP(ctx, hipStreamSynchronize(s));
     return GPC_OK;
 }
 
@@ -2590,7 +2591,7 @@ int gpc_sparse_get_state(gpc_sparse* g, double* alpha, double* C, double* Q, dou
     if (g->P == 0) return GPC_OK;
     GPC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t ld = (size_t)g->ld, P = (size_t)g->P;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = gpc_stream_of(ctx);
     if (alpha) GPC_HIP(ctx, hipMemcpyAsync(alpha, g->alpha, 8 * P * g->ny * ld, hipMemcpyDeviceToHost, s));
     if (C) GPC_HIP(ctx, hipMemcpyAsync(C, g->C, 8 * P * ld * ld, hipMemcpyDeviceToHost, s));
     if (Q) GPC_HIP(ctx, hipMemcpyAsync(Q, g->Q, 8 * P * ld * ld, hipMemcpyDeviceToHost, s));

@@ -752,3 +752,69 @@ def test_host_pointer_two_stream_mode_with_a_chunk_of_small_patches(gp, oracle, 
     g1, _, s1 = ctx.dense_fit_predict(pm, off, x0, x1, y, xs0, xs1)
     assert np.all(s2 == 0) and np.array_equal(s1, s2) and np.array_equal(g1, g2)
     _close(g2[:, 0, :], f1[:, 0, :], 1e-9)
+
+
+@pytest.mark.gpu
+def test_two_stream_pipeline_beside_another_threads_call(gp):
+    """include/gpc.h: a context is thread-safe.  While a host-pointer call runs its chunks on the context's two compute streams, another
+    thread's device-pointer call on the same context uses the SAME workspace from the context's stream: here 2040 patches of 190 points
+    with the variance -- the register kernel, whose factor export (2040 x 288 KB from the base of the workspace) reaches across both
+    halves the pipeline's chunks keep their factor slots in.  csrc/gpc_internal.h, gpc_ws_reserve, orders the two against each other;
+    every result of both threads must equal what the same call gives alone."""
+    import threading
+    import torch
+    capi, ctx = gp
+    dev = torch.device("cuda:0")
+    P, res, sz = 8192, 0.15, 8
+    m = sz * sz
+    off, x0, x1, y = synth.make_patches(P, 250, res=res, seed=141)
+    xs0, xs1 = synth.grid(res, sz)
+    pm = capi.default_params_dense()
+    fa_ref, _, sa_ref = ctx.dense_fit_predict(pm, off, x0, x1, y, xs0, xs1)
+    assert np.all(sa_ref == 0)
+    PB = 2040                       # (its export ends just below the end of the pipeline's two halves: 602 of 637 MB -- no re-growth)
+    offb, xb0, xb1, yb = synth.make_patches(PB, 190, res=res, seed=142)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = [t(a) for a in (offb, xb0, xb1, yb, xs0, xs1)]
+    torch.cuda.synchronize()
+    pv = capi.default_params_dense(want_variance=1)
+
+    def run_b():
+        f = torch.empty((PB, 1, m), dtype=torch.float64, device=dev)
+        v = torch.empty((PB, m), dtype=torch.float64, device=dev)
+        st = torch.empty((PB,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.dense_fit_predict_dev(pv, PB, d[0], 190, int(offb[-1]), d[1], d[2], d[3], 1, m, d[4], d[5], f, v_star=v, status=st)
+        ctx.synchronize()
+        return f.cpu().numpy(), v.cpu().numpy(), st.cpu().numpy()
+    fb_ref, vb_ref, sb_ref = run_b()
+    assert np.all(sb_ref == 0)
+    bad, done, err = {"a": 0, "b": 0}, {"a": 0, "b": 0}, []
+    gate = threading.Barrier(2)
+
+    def check_a(r):
+        return np.array_equal(r[2], sa_ref) and np.array_equal(r[0], fa_ref)        # the one-wave kernel is deterministic
+
+    def check_b(r):                                                                 # (the register kernel's LDS atomics meet in arrival order)
+        f, v, st = r
+        return (np.array_equal(st, sb_ref) and np.max(np.abs(f - fb_ref)) <= 1e-12 * np.max(np.abs(fb_ref))
+                and np.max(np.abs(v - vb_ref)) <= 1e-12 * np.max(np.abs(vb_ref)))
+
+    def worker(name, fn, check, reps):
+        try:
+            gate.wait(timeout=60)
+            for _ in range(reps):
+                bad[name] += 0 if check(fn()) else 1
+                done[name] += 1
+        except Exception as e:       # noqa: BLE001 -- reported below
+            err.append((name, repr(e)))
+    # (a call of A takes ~2 ms, one of B ~5 ms with its allocations: ~0.4 s side by side)
+    ths = [threading.Thread(target=worker, args=("a", lambda: ctx.dense_fit_predict(pm, off, x0, x1, y, xs0, xs1), check_a, 120), daemon=True),
+           threading.Thread(target=worker, args=("b", run_b, check_b, 60), daemon=True)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=240)
+    assert not err and not any(th.is_alive() for th in ths), err
+    assert done == {"a": 120, "b": 60}
+    assert bad == {"a": 0, "b": 0}, bad
