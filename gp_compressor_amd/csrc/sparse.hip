@@ -1282,16 +1282,18 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                                     jj[q] = ok[q] ? j : 0;
                                     sj[q] = svL[jj[q]];
                                     cv[q] = Cl[i + G * jj[q]];
-                                    kj[q] = fuse ? knL[jj[q]] : 0.0;
-                                    qw[q] = fuse ? Ql[i + G * jj[q]] : 0.0;
+                                    // (an absent slot contributes c * (+0.0) and q * (+0.0): a sum that starts at +0.0 is unchanged by it, bit for
+                                    // bit, as long as c and q are finite -- one select on k instead of two on the sums; without a next point the
+                                    // sums are never read, so what knL holds then does not matter)
+                                    kj[q] = ok[q] ? knL[jj[q]] : 0.0;
+                                    qw[q] = Ql[i + G * jj[q]];
                                 }
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     const double c = cv[q] + (re * sh) * sj[q];
                                     if (ok[q]) Cl[i + G * jj[q]] = c;
-                                    const double a1 = acc_[q] + c * kj[q], a2 = acq_[q] + qw[q] * kj[q];
-                                    acc_[q] = ok[q] ? a1 : acc_[q];
-                                    acq_[q] = ok[q] ? a2 : acq_[q];
+                                    acc_[q] += c * kj[q];
+                                    acq_[q] += qw[q] * kj[q];
                                 }
                             }
 #pragma unroll
@@ -1345,7 +1347,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                                         ej[q] = ehL[jj[q]];
                                         cv[q] = Cl[i + G * jj[q]];
                                         qw[q] = Ql[i + G * jj[q]];
-                                        kj[q] = fuse ? knL[jj[q]] : 0.0;
+                                        kj[q] = ok[q] ? knL[jj[q]] : 0.0;         // (see the sparse update above)
                                     }
 #pragma unroll
                                     for (int q = 0; q < 4; ++q) {
@@ -1356,9 +1358,8 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                                             Cl[i + G * jj[q]] = c;
                                             Ql[i + G * jj[q]] = qn_;
                                         }
-                                        const double a1 = acc_[q] + c * kj[q], a2 = acq_[q] + qn_ * kj[q];
-                                        acc_[q] = ok[q] ? a1 : acc_[q];
-                                        acq_[q] = ok[q] ? a2 : acq_[q];
+                                        acc_[q] += c * kj[q];
+                                        acq_[q] += qn_ * kj[q];
                                     }
                                 }
 #pragma unroll
