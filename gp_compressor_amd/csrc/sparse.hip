@@ -1089,6 +1089,24 @@ __device__ static __forceinline__ double sp_row_sum(double v)
     return v + 0.0;
 }
 
+// SLOT layout of the rows phase (round 4).  The mat-vec sums of every kernel shape run over four QUARTERS of the columns, quarter q =
+// columns [(b q) >> 2, (b (q + 1)) >> 2), each summed in column order -- that is what makes the shapes agree bit for bit.  Indexed by column,
+// a lane pays for every slot (q, t) of its row an index, a bound check, a clamp and two addresses: ~7 of the ~10 VALU operations of the
+// slot, in a kernel whose time is its VALU count.  So the rows phase keeps C, Q and the vectors k, s, e_hat, k_next by SLOT instead:
+// column j of quarter q sits at physical column QN q + (j - start_q), and the slots a quarter does not fill hold +0.0 in every row and
+// vector.  A pass is then 16 slots at compile-time addresses with no mask at all: an empty slot computes 0 + x * 0 = +0.0, stores it back
+// and adds (+0.0) * (+0.0) to a sum that started at +0.0 -- the same bits as skipping it, as long as x is finite.  The layout moves only
+// when the basis grows (columns shift LEFT, never onto a column that has not been read yet if they are taken in column order --
+// tests/test_sparse_gpu.py checks the states bit for bit against the other shapes).
+template <int QN>
+__device__ static __forceinline__ int sp_slot(int j, int b)
+{
+    const int s1 = b >> 2, s2 = b >> 1, s3 = (3 * b) >> 2;
+    const int q = (j >= s1 ? 1 : 0) + (j >= s2 ? 1 : 0) + (j >= s3 ? 1 : 0);
+    const int s = q == 0 ? 0 : q == 1 ? s1 : q == 2 ? s2 : s3;
+    return QN * q + (j - s);
+}
+
 #define SP_FOR_C(c) _Pragma("unroll") for (int c = 0; c < 3; ++c) if (c < ny)   /* static index: the planes stay in registers */
 template <int G>
 __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
@@ -1099,9 +1117,9 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* T = reinterpret_cast<double*>(smem);   // 64
     const int lane = threadIdx.x, r = lane / G, i = lane % G;
-    double* Cl = T + 64 + r * ROWD;                // C [G][G] column-major
+    double* Cl = T + 64 + r * ROWD;                // C [G slots][G rows]: row i of the column in slot p at i + G p (see sp_slot)
     double* Ql = Cl + G * G;
-    double* kvL = Ql + G * G;                      // k of the current point (read by column index)
+    double* kvL = Ql + G * G;                      // k of the current point, by slot
     double* svL = kvL + G;                         // s / s_hat
     double* ehL = svL + G;                         // e_hat
     double* knL = ehL + G;                         // k of the next point
@@ -1128,17 +1146,33 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
         bool take = valid && n > 0 && it0 < n && b <= G;
         // state of the patch: rows in registers, blocks in LDS
         double al[3] = {0.0, 0.0, 0.0}, bv0 = 0.0, bv1 = 0.0;
+        int ms = (i < b) ? sp_slot<QN>(i, b) : 0;                 // the slot of this lane's own column
+        int p00 = b > 0 ? G * sp_slot<QN>(0, b) : 0;              // where C(0, 0) sits
+        if (take) {
+            // every slot starts from +0.0 -- rows, columns and vectors; the columns the basis has go to their slots
+#pragma unroll
+            for (int p = 0; p < G; ++p) {
+                Cl[i + G * p] = 0.0;
+                Ql[i + G * p] = 0.0;
+            }
+            kvL[i] = 0.0;
+            svL[i] = 0.0;
+            ehL[i] = 0.0;
+            knL[i] = 0.0;
+        }
         if (take && i < b) {
             bv0 = BVg[2 * i];
             bv1 = BVg[2 * i + 1];
             SP_FOR_C(c) al[c] = alphag[c * ldg + i];
             for (int j = 0; j < b; ++j) {
-                Cl[i + G * j] = Cg[i + (size_t)j * ldg];
-                Ql[i + G * j] = Qg[i + (size_t)j * ldg];
+                const int pj = sp_slot<QN>(j, b);
+                Cl[i + G * pj] = Cg[i + (size_t)j * ldg];
+                Ql[i + G * pj] = Qg[i + (size_t)j * ldg];
             }
         }
+        __builtin_amdgcn_wave_barrier();
         {   // a state that already asks for a geometric deletion (possible only for one loaded with gpc_sparse_set_state) is not ours
-            const bool asks = take && i < b && b > 1 && (double)1.0f / Ql[i + G * i] < (double)1e-9f;
+            const bool asks = take && i < b && b > 1 && (double)1.0f / Ql[i + G * ms] < (double)1e-9f;
             if (__builtin_amdgcn_ballot_w64(asks) & rowmask) take = false;
         }
         if (valid && !take && i == 0) {
@@ -1179,10 +1213,12 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                 int dec = 0;
                 if (b == 0) {
                     // First point (src/sparse_gp.hpp:100-114)
+                    ms = sp_slot<QN>(i, 1);                                  // (meaningful for lane 0)
+                    p00 = G * sp_slot<QN>(0, 1);
                     if (i == 0) {
                         SP_FOR_C(c) al[c] = yv[c] / (kstar + s20);
-                        Cl[0] = (double)(-1.0f) / (kstar + s20);
-                        Ql[0] = (double)(1.0f) / kstar;
+                        Cl[G * ms] = (double)(-1.0f) / (kstar + s20);
+                        Ql[G * ms] = (double)(1.0f) / kstar;
                         bv0 = px0;
                         bv1 = px1;
                     }
@@ -1198,30 +1234,25 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                     } else {
                         if (i < b) {
                             k_i = gpc_rbf(sf, A.c_exp, px0, px1, bv0, bv1, T);
-                            kvL[i] = k_i;
+                            kvL[ms] = k_i;
                         }
                         __builtin_amdgcn_wave_barrier();
-                        // the four quarters side by side, one column of each per trip: their loads are issued together (clamped column,
-                        // masked value) -- QN LDS round trips per pass instead of one per column
+                        // the four quarters side by side, one slot of each per trip: their loads are issued together -- QN LDS round trips
+                        // per pass instead of one per column; empty slots hold +0.0 (see sp_slot)
                         double acc_[4] = {0.0, 0.0, 0.0, 0.0}, acq_[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll UNR
                         for (int t = 0; t < QN; ++t) {
                             double cv[4], qw[4], kj[4];
-                            bool ok[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const int j = ((b * q) >> 2) + t;
-                                ok[q] = j < ((b * (q + 1)) >> 2) && i < b;
-                                const int jc = ok[q] ? j : 0;
-                                kj[q] = kvL[jc];
-                                cv[q] = Cl[i + G * jc];
-                                qw[q] = Ql[i + G * jc];
+                                kj[q] = kvL[QN * q + t];
+                                cv[q] = Cl[i + G * (QN * q + t)];
+                                qw[q] = Ql[i + G * (QN * q + t)];
                             }
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const double a1 = acc_[q] + cv[q] * kj[q], a2 = acq_[q] + qw[q] * kj[q];
-                                acc_[q] = ok[q] ? a1 : acc_[q];
-                                acq_[q] = ok[q] ? a2 : acq_[q];
+                                acc_[q] += cv[q] * kj[q];
+                                acq_[q] += qw[q] * kj[q];
                             }
                         }
 #pragma unroll
@@ -1259,39 +1290,33 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                         double sh = 0.0;
                         if (i < b) {
                             sh = ck_i + eh_i;                        // s_hat = C*k + e_hat
-                            svL[i] = sh;
+                            svL[ms] = sh;
                             SP_FOR_C(c) al[c] += sh * (qv[c] * eta);
                         }
                         const double re = rr * eta;
                         if (fuse && i < b) {
                             kn_i = gpc_rbf(sf, A.c_exp, nx0, nx1, bv0, bv1, T);
-                            knL[i] = kn_i;
+                            knL[ms] = kn_i;
                         }
                         __builtin_amdgcn_wave_barrier();
                         {
                             double acc_[4] = {0.0, 0.0, 0.0, 0.0}, acq_[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll UNR
                             for (int t = 0; t < QN; ++t) {
+                                // (no mask: an empty slot is 0 + x * 0 = +0.0 stored back and (+0.0)(+0.0) added to the sums, a row beyond
+                                // the basis has s_hat = 0 and stays +0.0; without a next point the sums are never read)
                                 double cv[4], qw[4], kj[4], sj[4];
-                                bool ok[4];
-                                int jj[4];
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
-                                    const int j = ((b * q) >> 2) + t;
-                                    ok[q] = j < ((b * (q + 1)) >> 2) && i < b;
-                                    jj[q] = ok[q] ? j : 0;
-                                    sj[q] = svL[jj[q]];
-                                    cv[q] = Cl[i + G * jj[q]];
-                                    // (an absent slot contributes c * (+0.0) and q * (+0.0): a sum that starts at +0.0 is unchanged by it, bit for
-                                    // bit, as long as c and q are finite -- one select on k instead of two on the sums; without a next point the
-                                    // sums are never read, so what knL holds then does not matter)
-                                    kj[q] = ok[q] ? knL[jj[q]] : 0.0;
-                                    qw[q] = Ql[i + G * jj[q]];
+                                    sj[q] = svL[QN * q + t];
+                                    cv[q] = Cl[i + G * (QN * q + t)];
+                                    kj[q] = knL[QN * q + t];
+                                    qw[q] = Ql[i + G * (QN * q + t)];
                                 }
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     const double c = cv[q] + (re * sh) * sj[q];
-                                    if (ok[q]) Cl[i + G * jj[q]] = c;
+                                    Cl[i + G * (QN * q + t)] = c;
                                     acc_[q] += c * kj[q];
                                     acq_[q] += qw[q] * kj[q];
                                 }
@@ -1307,7 +1332,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                         const double eh_x = (i < b) ? eh_i : (double)(-1.0f);
                         bool geo = false;
                         if (i < nb) {
-                            const double q0 = (i < b) ? Ql[i + G * i] : 0.0;
+                            const double q0 = (i < b) ? Ql[i + G * ms] : 0.0;
                             const double qd = q0 + (ig * eh_x) * eh_x;           // the updated diagonal of Q, as the update forms it
                             geo = (double)1.0f / qd < (double)1e-9f;              // :226-242 would delete
                         }
@@ -1317,9 +1342,10 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                         } else {
                             dec = 1;
                             const double si = (i < b) ? ck_i : (double)1.0f;
+                            const int msn = sp_slot<QN>(i, nb);                  // this lane's slot in the basis of nb
                             if (i < nb) {
-                                svL[i] = si;
-                                ehL[i] = eh_x;
+                                svL[msn] = si;
+                                ehL[msn] = eh_x;
                                 SP_FOR_C(c) {
                                     const double a0 = (i < b) ? al[c] : 0.0;
                                     al[c] = a0 + qv[c] * si;
@@ -1327,39 +1353,42 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                                 if (i == b) { bv0 = px0; bv1 = px1; }
                                 if (fuse) {
                                     kn_i = gpc_rbf(sf, A.c_exp, nx0, nx1, bv0, bv1, T);
-                                    knL[i] = kn_i;
+                                    knL[msn] = kn_i;
                                 }
                             }
                             __builtin_amdgcn_wave_barrier();
                             {
+                                // The update and the move to the slots of nb columns in one pass, quarter by quarter in COLUMN order: a
+                                // column's new slot is never to the right of its old one and never the old slot of a later column, so a
+                                // row is rewritten in place (the loads of a quarter precede its stores).  The sums come out in the same
+                                // order as everywhere else: quarter q over its columns, ascending.
                                 double acc_[4] = {0.0, 0.0, 0.0, 0.0}, acq_[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll UNR
-                                for (int t = 0; t < QN; ++t) {
-                                    double cv[4], qw[4], kj[4], sj[4], ej[4];
-                                    bool ok[4];
-                                    int jj[4];
 #pragma unroll
-                                    for (int q = 0; q < 4; ++q) {
-                                        const int j = ((nb * q) >> 2) + t;
-                                        ok[q] = j < ((nb * (q + 1)) >> 2) && i < nb;
-                                        jj[q] = ok[q] ? j : 0;
-                                        sj[q] = svL[jj[q]];
-                                        ej[q] = ehL[jj[q]];
-                                        cv[q] = Cl[i + G * jj[q]];
-                                        qw[q] = Ql[i + G * jj[q]];
-                                        kj[q] = ok[q] ? knL[jj[q]] : 0.0;         // (see the sparse update above)
+                                for (int q = 0; q < 4; ++q) {
+                                    const int s0 = (nb * q) >> 2, s1 = (nb * (q + 1)) >> 2;
+                                    double cv[QN], qw[QN];
+                                    bool ok[QN];
+#pragma unroll
+                                    for (int t = 0; t < QN; ++t) {
+                                        const int j = s0 + t;
+                                        ok[t] = j < s1 && i < nb;
+                                        const bool old = ok[t] && i < b && j < b;     // the new row / column starts from zero
+                                        const int po = old ? sp_slot<QN>(j, b) : 0;
+                                        cv[t] = old ? Cl[i + G * po] : 0.0;
+                                        qw[t] = old ? Ql[i + G * po] : 0.0;
                                     }
 #pragma unroll
-                                    for (int q = 0; q < 4; ++q) {
-                                        const bool old = (i < b) && (jj[q] < b);      // the new row / column starts from zero
-                                        const double c = (old ? cv[q] : 0.0) + (rr * si) * sj[q];
-                                        const double qn_ = (old ? qw[q] : 0.0) + (ig * eh_x) * ej[q];
-                                        if (ok[q]) {
-                                            Cl[i + G * jj[q]] = c;
-                                            Ql[i + G * jj[q]] = qn_;
+                                    for (int t = 0; t < QN; ++t) {
+                                        const int pn = QN * q + t;
+                                        const double c = cv[t] + (rr * si) * svL[pn];              // (an empty slot: s = e_hat = k = +0.0)
+                                        const double qn_ = qw[t] + (ig * eh_x) * ehL[pn];
+                                        if (ok[t]) {
+                                            Cl[i + G * pn] = c;
+                                            Ql[i + G * pn] = qn_;
                                         }
-                                        acc_[q] += c * kj[q];
-                                        acq_[q] += qn_ * kj[q];
+                                        const double kj = knL[pn];
+                                        acc_[q] += c * kj;
+                                        acq_[q] += qn_ * kj;
                                     }
                                 }
 #pragma unroll
@@ -1367,6 +1396,8 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                             }
                             have_next = fuse;
                             b = nb;
+                            ms = msn;
+                            p00 = G * sp_slot<QN>(0, nb);
                         }
                     }
                 }
@@ -1376,7 +1407,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                 } else {
                     __builtin_amdgcn_wave_barrier();
                     // isnan(C(0,0)) -> "sparse_gp::C has become Nan" (:245)
-                    const double c00 = Cl[0];
+                    const double c00 = Cl[p00];
                     if (c00 != c00 && st == GPC_STATUS_OK) st = GPC_STATUS_NAN;
                     if (A.trace && i == 0) A.trace[o + it] = (uint8_t)dec;
                     ++it;
@@ -1394,8 +1425,9 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                 BVg[2 * i + 1] = bv1;
                 SP_FOR_C(c) alphag[c * ldg + i] = al[c];
                 for (int j = 0; j < b; ++j) {
-                    Cg[i + (size_t)j * ldg] = Cl[i + G * j];
-                    Qg[i + (size_t)j * ldg] = Ql[i + G * j];
+                    const int pj = sp_slot<QN>(j, b);
+                    Cg[i + (size_t)j * ldg] = Cl[i + G * pj];
+                    Qg[i + (size_t)j * ldg] = Ql[i + G * pj];
                 }
             }
             if (i == 0) {
