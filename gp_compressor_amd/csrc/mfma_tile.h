@@ -278,8 +278,9 @@ __device__ static __forceinline__ double mf_row_dot(const double* img, int mr, c
 template <int CTRL>
 __device__ static __forceinline__ double mf_dpp(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // (row rotations: every lane has a source lane, the destination's previous value never shows -- the mov form needs no zeroed destination)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // sum over the 16 lanes of a DPP row (l & 15); every lane gets the total.  row_ror:1,2,4,8 (no LDS traffic).

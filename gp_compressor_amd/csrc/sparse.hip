@@ -48,8 +48,11 @@ struct SpState {
 #endif
 // ---- block-wide helpers (all SP_NTH threads call) -------------------------------------------------------
 
+// (every control used here -- quad permutes, row mirrors, row rotate -- has a source lane for every lane, so the destination's previous
+// value never shows: the mov form with bound_ctrl spares the `v_mov_b32 dst, 0` that update_dpp(0, ...) puts in front of each of the two
+// halves of a double -- 3 instead of 5 VALU operations per step of a row sum, in kernels whose time is their VALU count)
 template <int CTRL>
-__device__ static __forceinline__ int sp_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ static __forceinline__ int sp_dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
 template <int CTRL>
 __device__ static __forceinline__ double sp_dpp(double v)
 {
@@ -1108,7 +1111,7 @@ __device__ static __forceinline__ int sp_slot(int j, int b)
 }
 
 #define SP_FOR_C(c) _Pragma("unroll") for (int c = 0; c < 3; ++c) if (c < ny)   /* static index: the planes stay in registers */
-template <int G>
+template <int G, int NY>
 __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
 {
     constexpr int R = 64 / G, QN = G / 4;
@@ -1125,7 +1128,9 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
     double* knL = ehL + G;                         // k of the next point
     gpc_exp_table_init(T);
     __syncthreads();
-    const int ldg = A.ld, ny = A.ny;
+    const int ldg = A.ld;
+    constexpr int ny = NY;                         // the channel count is a compile-time value here: with a run-time one the compiler
+                                                   // evaluates all three channels and selects (6 .. 9 VALU operations per channel loop)
     const double sf = A.prm.sigmaf_sq, s20 = A.prm.noise, eps_tol = A.prm.eps_tol;
     const int capacity = A.prm.capacity;
     const double kstar = sf;
@@ -1226,15 +1231,13 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                     dec = 0x81;
                 } else {
                     // k, C k, e_hat = Q k (:119, :140, :160): from the previous point's update pass, or from scratch
-                    double k_i = 0.0, pcq[4], pqq[4];
-                    if (from_prev) {
-                        k_i = kn_i;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { pcq[q] = pcn[q]; pqq[q] = pqn[q]; }
-                    } else {
+                    // (one set of registers for both: the from-scratch form leaves its k and partial sums where the previous point's pass
+                    // leaves them -- eight doubles and k copied per point otherwise)
+                    if (!from_prev) {
+                        kn_i = 0.0;
                         if (i < b) {
-                            k_i = gpc_rbf(sf, A.c_exp, px0, px1, bv0, bv1, T);
-                            kvL[ms] = k_i;
+                            kn_i = gpc_rbf(sf, A.c_exp, px0, px1, bv0, bv1, T);
+                            kvL[ms] = kn_i;
                         }
                         __builtin_amdgcn_wave_barrier();
                         // the four quarters side by side, one slot of each per trip: their loads are issued together -- QN LDS round trips
@@ -1256,13 +1259,14 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                             }
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { pcq[q] = acc_[q]; pqq[q] = acq_[q]; }
+                        for (int q = 0; q < 4; ++q) { pcn[q] = acc_[q]; pqn[q] = acq_[q]; }
                     }
+                    const double k_i = kn_i;
                     double ck_i = 0.0, eh_i = 0.0;
                     double dots[2] = {0.0, 0.0}, sums[3] = {0.0, 0.0, 0.0};
                     if (i < b) {
-                        const double c_ = pcq[0] + pcq[1] + pcq[2] + pcq[3];
-                        const double q_ = pqq[0] + pqq[1] + pqq[2] + pqq[3];
+                        const double c_ = pcn[0] + pcn[1] + pcn[2] + pcn[3];
+                        const double q_ = pqn[0] + pqn[1] + pqn[2] + pqn[3];
                         ck_i = c_;
                         eh_i = q_;
                         dots[0] += k_i * c_;                        // k^T C k   (:122)
@@ -2176,7 +2180,8 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
                 GPC_HIP(ctx, hipMemsetAsync(A.list_n, 0, 4 * sizeof(int32_t), ctx->stream));
             }
             const int waves = (g->P + R - 1) / R;
-            hipLaunchKernelGGL((sparse_add_rows_kernel<G>), dim3(std::min(waves, ctx->num_cus * per_cu_r)), dim3(64), lds_r, ctx->stream, A);
+            if (A.ny == 1) hipLaunchKernelGGL((sparse_add_rows_kernel<G, 1>), dim3(std::min(waves, ctx->num_cus * per_cu_r)), dim3(64), lds_r, ctx->stream, A);
+            else hipLaunchKernelGGL((sparse_add_rows_kernel<G, 3>), dim3(std::min(waves, ctx->num_cus * per_cu_r)), dim3(64), lds_r, ctx->stream, A);
             GPC_HIP(ctx, hipGetLastError());
             A.start_it = g->done_it;
         }
