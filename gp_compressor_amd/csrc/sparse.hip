@@ -1201,7 +1201,9 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
         }
         double nx0 = 0.0, nx1 = 0.0, nyv[3] = {0.0, 0.0, 0.0};
         int r_nxt2 = 0;
-        while (__builtin_amdgcn_ballot_w64(active)) {
+        // (bottom-tested: with the test at the top the compiler keeps a second copy of every loop-carried value for the exit path and
+        // moves ~18 registers there and back per point)
+        if (__builtin_amdgcn_ballot_w64(active)) do {
             if (active) {
                 const double px0 = cx0, px1 = cx1;
                 const double yv[3] = {cy[0], cy[1], cy[2]};
@@ -1420,7 +1422,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                     if (it >= n) active = false;
                 }
             }
-        }
+        } while (__builtin_amdgcn_ballot_w64(active));
         // write the state back (a patch handed over continues from it in the next kernel)
         if (take) {
             __builtin_amdgcn_wave_barrier();
