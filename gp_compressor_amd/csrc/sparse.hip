@@ -1111,21 +1111,25 @@ __device__ static __forceinline__ int sp_slot(int j, int b)
 }
 
 #define SP_FOR_C(c) _Pragma("unroll") for (int c = 0; c < 3; ++c) if (c < ny)   /* static index: the planes stay in registers */
-template <int G, int NY>
+// G lanes per patch, B <= G rows / slots of state (B = G = 16: the first phase, four patches per wave; G = 32, B = 24 = SP_BMAX: the SECOND
+// phase, two patches per wave, which takes the patches of the work list -- by ticket -- that the first phase handed over, until they
+// outgrow 24 vectors: what the one-wave kernel sparse_add_kernel<true> used to do at ~560 VALU operations per point and patch).
+template <int G, int NY, int B = G, bool LIST = false>
 __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
 {
-    constexpr int R = 64 / G, QN = G / 4;
+    constexpr int R = 64 / G, QN = B / 4;
+    static_assert(B % 4 == 0 && B <= G, "rows of state per patch");
     constexpr int UNR = G == 16 ? QN : 2;                        // trips of the column loops unrolled together (registers)
-    constexpr int ROWD = 2 * G * G + 4 * G + 16;                 // doubles of LDS per patch row (+16: de-phases the rows' banks)
+    constexpr int ROWD = 2 * B * B + 4 * B + (B == G ? 16 : 0);      // doubles of LDS per patch row (+16: de-phases the rows' banks)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* T = reinterpret_cast<double*>(smem);   // 64
     const int lane = threadIdx.x, r = lane / G, i = lane % G;
     double* Cl = T + 64 + r * ROWD;                // C [G slots][G rows]: row i of the column in slot p at i + G p (see sp_slot)
-    double* Ql = Cl + G * G;
-    double* kvL = Ql + G * G;                      // k of the current point, by slot
-    double* svL = kvL + G;                         // s / s_hat
-    double* ehL = svL + G;                         // e_hat
-    double* knL = ehL + G;                         // k of the next point
+    double* Ql = Cl + B * B;
+    double* kvL = Ql + B * B;                      // k of the current point, by slot
+    double* svL = kvL + B;                         // s / s_hat
+    double* ehL = svL + B;                         // e_hat
+    double* knL = ehL + B;                         // k of the next point
     gpc_exp_table_init(T);
     __syncthreads();
     const int ldg = A.ld;
@@ -1135,9 +1139,23 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
     const int capacity = A.prm.capacity;
     const double kstar = sf;
 
-    for (int base = blockIdx.x * R; base < A.P; base += gridDim.x * R) {
-        const int patch = base + r;
-        const bool valid = patch < A.P;
+    for (int base = blockIdx.x * R;; base += gridDim.x * R) {
+        int patch;
+        bool valid;
+        if (LIST) {
+            // the patches of the work list, one ticket per group of G lanes (a group that finds the list exhausted idles while the
+            // other one works; the wave leaves when every group has)
+            int idx = 0;
+            if (i == 0) idx = atomicAdd(A.list_n + A.ticket_slot, 1);
+            idx = __shfl(idx, r * G, 64);
+            valid = idx < A.list_n[0];
+            patch = valid ? A.list[idx] : 0;
+            if (!__builtin_amdgcn_ballot_w64(valid)) break;
+        } else {
+            if (base >= A.P) break;
+            patch = base + r;
+            valid = patch < A.P;
+        }
         const int pc = valid ? patch : A.P - 1;
         const int o = A.off[pc], n = A.off[pc + 1] - o;
         int b = A.b[pc];
@@ -1148,17 +1166,17 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
         double* const Qg = A.Q + (size_t)pc * ldg * ldg;
         const unsigned long long rowmask = ((G == 64) ? ~0ull : ((1ull << G) - 1ull)) << (r * G);   // the lanes of this patch
         const int it0 = A.start_it ? A.start_it[pc] : 0;          // points of this call an earlier phase already took
-        bool take = valid && n > 0 && it0 < n && b <= G;
+        bool take = valid && n > 0 && it0 < n && b <= B;
         // state of the patch: rows in registers, blocks in LDS
         double al[3] = {0.0, 0.0, 0.0}, bv0 = 0.0, bv1 = 0.0;
         int ms = (i < b) ? sp_slot<QN>(i, b) : 0;                 // the slot of this lane's own column
-        int p00 = b > 0 ? G * sp_slot<QN>(0, b) : 0;              // where C(0, 0) sits
-        if (take) {
+        int p00 = b > 0 ? B * sp_slot<QN>(0, b) : 0;              // where C(0, 0) sits
+        if (take && i < B) {
             // every slot starts from +0.0 -- rows, columns and vectors; the columns the basis has go to their slots
 #pragma unroll
-            for (int p = 0; p < G; ++p) {
-                Cl[i + G * p] = 0.0;
-                Ql[i + G * p] = 0.0;
+            for (int p = 0; p < B; ++p) {
+                Cl[i + B * p] = 0.0;
+                Ql[i + B * p] = 0.0;
             }
             kvL[i] = 0.0;
             svL[i] = 0.0;
@@ -1171,19 +1189,23 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
             SP_FOR_C(c) al[c] = alphag[c * ldg + i];
             for (int j = 0; j < b; ++j) {
                 const int pj = sp_slot<QN>(j, b);
-                Cl[i + G * pj] = Cg[i + (size_t)j * ldg];
-                Ql[i + G * pj] = Qg[i + (size_t)j * ldg];
+                Cl[i + B * pj] = Cg[i + (size_t)j * ldg];
+                Ql[i + B * pj] = Qg[i + (size_t)j * ldg];
             }
         }
         __builtin_amdgcn_wave_barrier();
         {   // a state that already asks for a geometric deletion (possible only for one loaded with gpc_sparse_set_state) is not ours
-            const bool asks = take && i < b && b > 1 && (double)1.0f / Ql[i + G * ms] < (double)1e-9f;
+            const bool asks = take && i < b && b > 1 && (double)1.0f / Ql[i + B * ms] < (double)1e-9f;
             if (__builtin_amdgcn_ballot_w64(asks) & rowmask) take = false;
         }
         if (valid && !take && i == 0) {
-            if (!A.start_it) A.done_it[patch] = 0;                  // (a later phase leaves the earlier phase's count)
-            if (A.list && n > 0 && it0 < n) A.list[atomicAdd(A.list_n, 1)] = patch;   // all of it is the later phases' work
-            else if (A.list && A.status_out) A.status_out[patch] = st;                // nothing to do: nobody else visits it
+            if (LIST) {
+                A.done_it[patch] = it0;                             // still on the list: the regular kernel finds it there
+            } else {
+                if (!A.start_it) A.done_it[patch] = 0;              // (a later phase leaves the earlier phase's count)
+                if (A.list && n > 0 && it0 < n) A.list[atomicAdd(A.list_n, 1)] = patch;   // all of it is the later phases' work
+                else if (A.list && A.status_out) A.status_out[patch] = st;                // nothing to do: nobody else visits it
+            }
         }
         bool active = take;
         int it = it0, it_end = n;
@@ -1221,11 +1243,11 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                 if (b == 0) {
                     // First point (src/sparse_gp.hpp:100-114)
                     ms = sp_slot<QN>(i, 1);                                  // (meaningful for lane 0)
-                    p00 = G * sp_slot<QN>(0, 1);
+                    p00 = B * sp_slot<QN>(0, 1);
                     if (i == 0) {
                         SP_FOR_C(c) al[c] = yv[c] / (kstar + s20);
-                        Cl[G * ms] = (double)(-1.0f) / (kstar + s20);
-                        Ql[G * ms] = (double)(1.0f) / kstar;
+                        Cl[B * ms] = (double)(-1.0f) / (kstar + s20);
+                        Ql[B * ms] = (double)(1.0f) / kstar;
                         bv0 = px0;
                         bv1 = px1;
                     }
@@ -1251,8 +1273,8 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 kj[q] = kvL[QN * q + t];
-                                cv[q] = Cl[i + G * (QN * q + t)];
-                                qw[q] = Ql[i + G * (QN * q + t)];
+                                cv[q] = Cl[i + B * (QN * q + t)];
+                                qw[q] = Ql[i + B * (QN * q + t)];
                             }
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
@@ -1308,21 +1330,21 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                         {
                             double acc_[4] = {0.0, 0.0, 0.0, 0.0}, acq_[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll UNR
-                            for (int t = 0; t < QN; ++t) {
+                            for (int t = 0; t < QN; ++t) if (B == G || i < B) {        // (lanes beyond the rows of state have no row)
                                 // (no mask: an empty slot is 0 + x * 0 = +0.0 stored back and (+0.0)(+0.0) added to the sums, a row beyond
                                 // the basis has s_hat = 0 and stays +0.0; without a next point the sums are never read)
                                 double cv[4], qw[4], kj[4], sj[4];
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     sj[q] = svL[QN * q + t];
-                                    cv[q] = Cl[i + G * (QN * q + t)];
+                                    cv[q] = Cl[i + B * (QN * q + t)];
                                     kj[q] = knL[QN * q + t];
-                                    qw[q] = Ql[i + G * (QN * q + t)];
+                                    qw[q] = Ql[i + B * (QN * q + t)];
                                 }
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     const double c = cv[q] + (re * sh) * sj[q];
-                                    Cl[i + G * (QN * q + t)] = c;
+                                    Cl[i + B * (QN * q + t)] = c;
                                     acc_[q] += c * kj[q];
                                     acq_[q] += qw[q] * kj[q];
                                 }
@@ -1338,12 +1360,12 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                         const double eh_x = (i < b) ? eh_i : (double)(-1.0f);
                         bool geo = false;
                         if (i < nb) {
-                            const double q0 = (i < b) ? Ql[i + G * ms] : 0.0;
+                            const double q0 = (i < b) ? Ql[i + B * ms] : 0.0;
                             const double qd = q0 + (ig * eh_x) * eh_x;           // the updated diagonal of Q, as the update forms it
                             geo = (double)1.0f / qd < (double)1e-9f;              // :226-242 would delete
                         }
                         const bool any_geo = (__builtin_amdgcn_ballot_w64(geo) & rowmask) != 0;
-                        if (nb > G || nb > ldg || (capacity > 0 && nb > capacity) || any_geo) {
+                        if (nb > B || nb > ldg || (capacity > 0 && nb > capacity) || any_geo) {
                             stop = true;                    // nothing of this point has been applied
                         } else {
                             dec = 1;
@@ -1380,8 +1402,8 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                                         ok[t] = j < s1 && i < nb;
                                         const bool old = ok[t] && i < b && j < b;     // the new row / column starts from zero
                                         const int po = old ? sp_slot<QN>(j, b) : 0;
-                                        cv[t] = old ? Cl[i + G * po] : 0.0;
-                                        qw[t] = old ? Ql[i + G * po] : 0.0;
+                                        cv[t] = old ? Cl[i + B * po] : 0.0;
+                                        qw[t] = old ? Ql[i + B * po] : 0.0;
                                     }
 #pragma unroll
                                     for (int t = 0; t < QN; ++t) {
@@ -1389,8 +1411,8 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                                         const double c = cv[t] + (rr * si) * svL[pn];              // (an empty slot: s = e_hat = k = +0.0)
                                         const double qn_ = qw[t] + (ig * eh_x) * ehL[pn];
                                         if (ok[t]) {
-                                            Cl[i + G * pn] = c;
-                                            Ql[i + G * pn] = qn_;
+                                            Cl[i + B * pn] = c;
+                                            Ql[i + B * pn] = qn_;
                                         }
                                         const double kj = knL[pn];
                                         acc_[q] += c * kj;
@@ -1403,7 +1425,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                             have_next = fuse;
                             b = nb;
                             ms = msn;
-                            p00 = G * sp_slot<QN>(0, nb);
+                            p00 = B * sp_slot<QN>(0, nb);
                         }
                     }
                 }
@@ -1432,12 +1454,12 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                 SP_FOR_C(c) alphag[c * ldg + i] = al[c];
                 for (int j = 0; j < b; ++j) {
                     const int pj = sp_slot<QN>(j, b);
-                    Cg[i + (size_t)j * ldg] = Cl[i + G * pj];
-                    Qg[i + (size_t)j * ldg] = Ql[i + G * pj];
+                    Cg[i + (size_t)j * ldg] = Cl[i + B * pj];
+                    Qg[i + (size_t)j * ldg] = Ql[i + B * pj];
                 }
             }
             if (i == 0) {
-                if (A.list && it_end < n) A.list[atomicAdd(A.list_n, 1)] = patch;    // handed over: the next phase continues it
+                if (!LIST && A.list && it_end < n) A.list[atomicAdd(A.list_n, 1)] = patch;    // handed over: the next phase continues it
                 A.done_it[patch] = it_end;
                 A.b[patch] = b;
                 A.count[patch] += it_end - it0;
@@ -2187,6 +2209,25 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
             GPC_HIP(ctx, hipGetLastError());
             A.start_it = g->done_it;
         }
+        // A SECOND rows phase (Gaussian noise, round 4; GPC_SPARSE_ROWS2=1 -- measured and not the default): the patches of the list with
+        // at most SP_BMAX vectors, two per wave by ticket, until they outgrow SP_BMAX or ask for a deletion, in place of the one-wave
+        // kernel below.  A third of that kernel's instructions per point and bit-identical states, but level in time at the reference's
+        // defaults (0.44 against 0.51 ms per add call, and the regular kernel 0.59 against 0.51: a patch that asks for a geometric
+        // deletion leaves for the regular kernel for the rest of the call, where the one-wave kernel deletes in place), and 80 us per
+        // call for nothing where the list is empty (the colour GP at its defaults).
+        bool rows2 = false;
+        if (gauss && A.list && A.start_it && getenv("GPC_SPARSE_ROWS2")) {
+            constexpr int G2 = 32, B2 = SP_BMAX, R2 = 64 / G2;
+            static_assert(B2 == 24, "the second rows phase is built for a resident block of 24");
+            const size_t lds_2 = sizeof(double) * (size_t)(64 + R2 * (2 * B2 * B2 + 4 * B2));
+            const int per_cu_2 = std::min(8, (int)((160u * 1024u) / lds_2));
+            A.ticket_slot = 1;
+            const int waves2 = (g->P + R2 - 1) / R2;
+            if (A.ny == 1) hipLaunchKernelGGL((sparse_add_rows_kernel<G2, 1, B2, true>), dim3(std::min(waves2, ctx->num_cus * per_cu_2)), dim3(64), lds_2, ctx->stream, A);
+            else hipLaunchKernelGGL((sparse_add_rows_kernel<G2, 3, B2, true>), dim3(std::min(waves2, ctx->num_cus * per_cu_2)), dim3(64), lds_2, ctx->stream, A);
+            GPC_HIP(ctx, hipGetLastError());
+            rows2 = true;
+        }
         // small-basis phase: one wave per patch, C and Q in LDS, until a patch outgrows SP_BMAX basis vectors
         const size_t lds_s = sp_add_lds_small();
         int per_cu_s = (int)((160u * 1024u) / lds_s);
@@ -2196,7 +2237,7 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
         A.ticket_slot = 1;
         if (!gauss)
             hipLaunchKernelGGL((sparse_add_kernel<true, true>), dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
-        else
+        else if (!rows2)
             hipLaunchKernelGGL((sparse_add_kernel<true, false>), dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
         GPC_HIP(ctx, hipGetLastError());
         A.start_it = g->done_it;
