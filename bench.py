@@ -365,9 +365,14 @@ def sparse_add_roofline(regime, ny, bytes_total, add_stats, P, point_updates, ca
     if per_pt is None:
         per_pt, src = 650.0 / 4.0, "model: ~650 wave-instructions per wave-point for four patches (DESIGN 5.4a); no PMC pass on file"
     ginst = per_pt * point_updates / (add_ms * 1e-3) / 1e9
+    # the VALU side of the same counters: a 64-lane FP64 operation occupies its SIMD's VALU for FOUR cycles, so the fraction of the
+    # chip's VALU cycles the add kernels use is 4 x the VALU share of `frac` -- the number that says how close to instruction-bound they are
+    valu_pt = _traffic(tkey, "valu_insts_per_point_update")
+    valu_busy = None if valu_pt is None else 4.0 * valu_pt * point_updates / (add_ms * 1e-3) / 1e9 / ISSUE_PEAK_GINST
     return {"bound": "issue", "achieved": ginst, "peak": ISSUE_PEAK_GINST, "unit": "G wave-instructions/s", "frac": ginst / ISSUE_PEAK_GINST,
             "traffic": _traffic(tkey), "kernel_ms": add_ms, "kernel_ms_stats": add_stats,
             "wave_insts_per_point_update": per_pt, "wave_insts_source": src, "point_updates": point_updates,
+            "valu_insts_per_point_update": valu_pt, "valu_cycles_frac": valu_busy,
             "hbm_algorithmic_GBps": gbps, "bytes_per_patch": bytes_total / P,
             "what": "instruction-issue roofline of the add calls (rows phase + small-basis phase + regular kernel): counted wave-instructions "
                     "per point update x point updates of the pass / MEDIAN HIP-event time, against 1024 SIMDs x 1 instruction / cycle x 2.4 GHz; "

@@ -123,13 +123,17 @@ def main():
             tr["kernel_ms_timed_rocprof_stats"] = rec["family_ms_per_pass"]
         # wave-instructions per pass (sparse): every counted instruction class of every add kernel, per pass
         if pts:
-            tot_i, have = 0.0, 0
+            tot_i, tot_v, have = 0.0, 0.0, 0
             for cs in counters.values():
                 for c in INSTS:
                     v = cs.get(c, [])
                     if v:
                         tot_i += sum(v) / max(1, len(v) // per_launch)
+                        if c == "SQ_INSTS_VALU":
+                            tot_v += sum(v) / max(1, len(v) // per_launch)
                         have += 1
+            if have and tot_v:
+                tr["valu_insts_per_point_update"] = tot_v / pts      # (a 64-lane FP64 operation occupies the SIMD's VALU for four cycles)
             if have:
                 rec["wave_insts_per_pass"] = tot_i
                 tr["wave_insts_per_launch"] = tot_i
