@@ -46,6 +46,7 @@ struct SpState {
 #ifndef SP_BMAX
 #define SP_BMAX 24   // resident block of the small-basis add kernel (see sparse_add_kernel)
 #endif
+#define SP_BMID 48   // ... and of its second instance, which takes the patches that have outgrown SP_BMAX (round 4)
 // ---- block-wide helpers (all SP_NTH threads call) -------------------------------------------------------
 
 // (every control used here -- quad permutes, row mirrors, row rotate -- has a source lane for every lane, so the destination's previous
@@ -192,7 +193,7 @@ template <bool WRITE_Q = true, int RB = SP_RMW_NEXT, class F>
 __device__ static inline void sp_rmw_cq_next(double* C, double* Q, int ld, int lv, int nb, const double* kvn, double* pnext, F f)
 {
     const int lane = threadIdx.x & 63;
-    if (SP_NTH == 64 && nb <= 32 && ld == SP_BMAX) {     // (ld == SP_BMAX: C and Q are the LDS blocks of the small-basis kernel)
+    if (SP_NTH == 64 && nb <= 32 && (ld == SP_BMAX || ld == SP_BMID)) {     // (ld == SP_BMAX / SP_BMID: C and Q are the LDS blocks of a one-wave kernel)
         // One wave and a small basis (the reference's default hyper-parameters keep it around 13): with a lane per row most of the
         // wave idles and the four column quarters run one after the other -- ~30 instructions per column, 13 columns, every point.
         // Here the lanes form 4 groups of 16 rows (nb <= 16) or 2 groups of 32: group g takes the quarters g, g + G, .. at the same
@@ -637,15 +638,15 @@ struct SpAddParams {
 // of 16 b^2 per POINT.  Fits while 2 x (capacity + 1)(capacity + 2) / 2 doubles + the vectors stay within the CU's 160 KB: capacity <= 120,
 // which covers the reference's default of 100 (/root/reference/src/sparse_gp.h:48).  One workgroup of four waves per CU.  Every patch runs
 // the triangular passes (whatever basis it arrives with); same element updates, same summation order as the HBM-resident triangular mode.
-template <bool SMALL, bool PROBIT = false, bool TRI = false, bool RES = false>
+template <bool SMALL, bool PROBIT = false, bool TRI = false, bool RES = false, int BM = SP_BMAX>
 __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse_add_kernel(SpAddParams A)   // <= 256 VGPRs (128 for the small-basis phase)
 {
     static_assert(!RES || (TRI && !SMALL && !PROBIT), "the LDS-resident mode is a form of the triangular mode");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ldg = A.ld, ny = A.ny;               // ldg: strides of the state in global memory
-    const int ld = SMALL ? SP_BMAX + 1 : ldg;      // stride of the LDS vectors (and of alpha / BV while they live in LDS)
-    const int ldm = SMALL ? SP_BMAX : ldg;         // stride of C and Q where the update loops see them
+    const int ld = SMALL ? BM + 1 : ldg;      // stride of the LDS vectors (and of alpha / BV while they live in LDS)
+    const int ldm = SMALL ? BM : ldg;         // stride of C and Q where the update loops see them
     constexpr int RB = SMALL ? 2 : SP_RMW;         // elements per thread and trip of the update passes (LDS needs no deep batches)
     double* T = reinterpret_cast<double*>(smem);   // 64
     double* red = T + 64;                          // 16
@@ -664,8 +665,8 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
     double* kvn = pnext + 8 * ld;                  // ... and its k  [ld]
     double* alphaL = kvn + ld;                     // alpha [ny][ld] and BV [ld][2] of the patch in flight: read and updated at every
     double* BVL = alphaL + 3 * ld;                 // point, so they live here between the first and the last point of the call
-    double* Cl = BVL + 2 * ld;                     // SMALL: C, Q [SP_BMAX][SP_BMAX]
-    double* Ql = Cl + SP_BMAX * SP_BMAX;
+    double* Cl = BVL + 2 * ld;                     // SMALL: C, Q [BM][BM]
+    double* Ql = Cl + BM * BM;
     double* part_col = BVL + 2 * ld;               // TRI: column parts of the mat-vecs [2][ld], this point's and the next one's
     double* pnext_col = part_col + 2 * ld;
     const int ldp = A.prm.capacity + 1;            // RES: leading dimension of the packed triangles
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
         [[maybe_unused]] const bool tri = RES || (TRI && b >= A.tri_min);
         const int it0 = A.start_it ? A.start_it[patch] : 0;     // an earlier phase (rows / small-basis) already took these
         __syncthreads();
-        if (SMALL && (b > SP_BMAX || n == 0)) {          // too large from the start (or nothing to do): all of it is the regular kernel's
+        if (SMALL && (b > BM || n == 0)) {          // too large from the start (or nothing to do): all of it is the regular kernel's
             if (tid == 0) A.done_it[patch] = it0;
             continue;
         }
@@ -725,8 +726,8 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
         if (SMALL) {
             for (int e = tid; e < b * b; e += SP_NTH) {
                 const int i = e % b, j = e / b;
-                Cl[i + j * SP_BMAX] = Cg[i + (size_t)j * ldg];
-                Ql[i + j * SP_BMAX] = Qg[i + (size_t)j * ldg];
+                Cl[i + j * BM] = Cg[i + (size_t)j * ldg];
+                Ql[i + j * BM] = Qg[i + (size_t)j * ldg];
             }
         }
         if (RES) {                                       // the lower triangles come on chip (the upper ones are redundant: every producer mirrors)
@@ -904,7 +905,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                     }
                 }
                 __syncthreads();
-            } else if (SMALL && b + 1 > SP_BMAX && !(capacity > 0 && capacity <= SP_BMAX)) {
+            } else if (SMALL && b + 1 > BM && !(capacity > 0 && capacity <= BM)) {
                 it_end = it;                                // this point would grow the basis beyond the resident block: nothing of it
                 break;                                      // has been applied yet -- the regular kernel redoes it from the state as it is
             } else if (b >= ldg) {
@@ -1021,8 +1022,8 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
         if (SMALL) {
             for (int e = tid; e < b * b; e += SP_NTH) {
                 const int i = e % b, j = e / b;
-                Cg[i + (size_t)j * ldg] = Cl[i + j * SP_BMAX];
-                Qg[i + (size_t)j * ldg] = Ql[i + j * SP_BMAX];
+                Cg[i + (size_t)j * ldg] = Cl[i + j * BM];
+                Qg[i + (size_t)j * ldg] = Ql[i + j * BM];
             }
             if (tid == 0) A.done_it[patch] = it_end;
         }
@@ -1972,7 +1973,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_train_kernel(SpTrainParams 
 
 // ------------------------------------------------------------------------------------------------ host side
 
-static size_t sp_add_lds_small() { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (SP_BMAX + 2) + 22 * (SP_BMAX + 1) + 2 * SP_BMAX * SP_BMAX); }
+static size_t sp_add_lds_small(int bm = SP_BMAX) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (bm + 2) + 22 * (bm + 1) + 2 * bm * bm); }
 static size_t sp_add_lds(int ld, bool tri = false) { return sizeof(double) * (size_t)(64 + 16 + 6 + 4 * (ld + 1) + 8 * ld + 9 * ld + 5 * ld + (tri ? 4 * ld : 0)); }
 static size_t sp_lik_lds(int ld, bool fast)
 {
@@ -2241,6 +2242,18 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
             hipLaunchKernelGGL((sparse_add_kernel<true, false>), dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
         GPC_HIP(ctx, hipGetLastError());
         A.start_it = g->done_it;
+        // mid phase (Gaussian noise, round 4): the patches that have outgrown SP_BMAX vectors -- a few hundred of 32768 at the reference's
+        // defaults, each a chain of up to n points -- go through a second instance of the one-wave kernel with a resident block of
+        // SP_BMID before the regular kernel sees them: their state in LDS instead of round trips to HBM at every point
+        // (GPC_SPARSE_NO_MID=1: straight to the regular kernel)
+        if (gauss && A.list && !getenv("GPC_SPARSE_NO_MID") && g->ld > SP_BMAX) {
+            const size_t lds_m = sp_add_lds_small(SP_BMID);
+            const int per_cu_m = std::max(1, (int)((160u * 1024u) / lds_m));
+            A.ticket_slot = 2;
+            hipLaunchKernelGGL((sparse_add_kernel<true, false, false, false, SP_BMID>), dim3(std::min(g->P, ctx->num_cus * per_cu_m)), dim3(64), lds_m,
+                               ctx->stream, A);
+            GPC_HIP(ctx, hipGetLastError());
+        }
         A.ticket_slot = 3;
         A.done_it = nullptr;
     }

@@ -758,7 +758,8 @@ def test_sparse_rows_phase_is_bit_identical(gp, ny, cap, kernel, P, n, monkeypat
     p = capi.default_params_sparse(ny, **kw)
     results = []
     # (GPC_SPARSE_ROWS2: the opt-in second rows phase -- two patches per wave, 24 rows of state, by ticket -- in place of the one-wave kernel)
-    for env in (None, "GPC_SPARSE_NO_LIST", "GPC_SPARSE_NO_ROWS", "GPC_SPARSE_NO_SMALL", "GPC_SPARSE_ROWS2"):
+    # (GPC_SPARSE_NO_MID: without the one-wave kernel's second instance for bases of 25 .. 48 vectors)
+    for env in (None, "GPC_SPARSE_NO_LIST", "GPC_SPARSE_NO_ROWS", "GPC_SPARSE_NO_SMALL", "GPC_SPARSE_ROWS2", "GPC_SPARSE_NO_MID"):
         if env:
             monkeypatch.setenv(env, "1")
         g = capi.Sparse(ctx, p, P, ny)
@@ -812,6 +813,9 @@ def test_sparse_triangular_mode(gp, oracle, ny, cap, kernel, monkeypatch):
     # (the mode is chosen per patch and call from the basis it arrives with, >= 96 vectors by default: here every patch the four-wave
     # kernel takes runs it)
     monkeypatch.setenv("GPC_SPARSE_TRI_MIN", "0")
+    # (round 4: bases of 25 .. 48 vectors go through a second instance of the one-wave kernel first -- full matrices, like the small-basis
+    # kernel's; this test is about the four-wave kernel's triangular passes at EVERY size it can see, so that instance stays out of it)
+    monkeypatch.setenv("GPC_SPARSE_NO_MID", "1")
     for full in (False, True):
         if full:
             monkeypatch.setenv("GPC_SPARSE_FULL", "1")
@@ -884,6 +888,7 @@ def test_sparse_lds_resident_mode_is_bit_identical(gp, ny, cap, kernel, monkeypa
     p = capi.default_params_sparse(ny, **kw)
     xs0, xs1 = synth.grid(res, 20)
     monkeypatch.setenv("GPC_SPARSE_TRI_MIN", "0")
+    monkeypatch.setenv("GPC_SPARSE_NO_MID", "1")    # (the four-wave shapes at every size they can see: see test_sparse_triangular_mode)
     monkeypatch.setenv("GPC_SPARSE_RES", "1")       # (measured slower than the HBM-resident shape and not the default: DESIGN 5.4c)
     out = []
     for hbm in (False, True):

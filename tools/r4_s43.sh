@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 O=gpurun_out/r4; mkdir -p $O
 B=${1:-rows5}
 V=$PWD/gp_compressor_amd/libgpc_hip_$B.so
-GPC_LIB_PATH=$V timeout -k 10 900 python -m pytest tests/test_sparse_gpu.py tests/test_probit_gpu.py -q -m gpu -x > $O/pytest43_$B.log 2>&1; echo "pytest($B) rc=$?"; tail -5 $O/pytest43_$B.log | cut -c1-200
+GPC_LIB_PATH=$V timeout -k 10 900 python -m pytest tests/test_sparse_gpu.py tests/test_probit_gpu.py -q -m gpu > $O/pytest43_$B.log 2>&1; echo "pytest($B) rc=$?"; tail -5 $O/pytest43_$B.log | cut -c1-200
 for rep in 1 2; do
   for v in base $B; do
     if [ $v = base ]; then unset GPC_LIB_PATH; else export GPC_LIB_PATH=$V; fi
