@@ -618,7 +618,9 @@ struct SpAddParams {
     // that follow take list entries by ticket (one atomic per patch) instead of a static share of all P patches: only a fifth of the
     // patches reach them, and with static shares the wave that happens to own eight of those decides the launch time.
     int32_t* list;             // [P] patch ids (nullptr: static shares)
-    int32_t* list_n;           // [0] entries in `list`, [1], [3] ticket counters of the small-basis and the regular launch
+    int32_t* list_n;           // [0] entries in `list`, [1] .. [3] ticket counters of the launches that draw from it
+    int32_t* out_list;         // where a phase that draws from `list` puts what it hands on (round 4: every later phase walks only the
+    int32_t* out_list_n;       // entries it has work in, not the first phase's whole list: a ticket costs ~23 ns device-wide), or nullptr
     int ticket_slot;           // which counter this launch draws from
     int tri_min;               // triangular mode (sparse_add_kernel<false, ., true>): for patches that arrive with at least this many basis vectors
 };
@@ -714,7 +716,10 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
         const int it0 = A.start_it ? A.start_it[patch] : 0;     // an earlier phase (rows / small-basis) already took these
         __syncthreads();
         if (SMALL && (b > BM || n == 0)) {          // too large from the start (or nothing to do): all of it is the regular kernel's
-            if (tid == 0) A.done_it[patch] = it0;
+            if (tid == 0) {
+                A.done_it[patch] = it0;
+                if (A.out_list && n > 0 && it0 < n) A.out_list[atomicAdd(A.out_list_n, 1)] = patch;
+            }
             continue;
         }
         if (A.start_it && n > 0 && it0 >= n) continue;   // an earlier phase finished this patch (and wrote its state, status and done_it)
@@ -1025,7 +1030,10 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                 Cg[i + (size_t)j * ldg] = Cl[i + j * BM];
                 Qg[i + (size_t)j * ldg] = Ql[i + j * BM];
             }
-            if (tid == 0) A.done_it[patch] = it_end;
+            if (tid == 0) {
+                A.done_it[patch] = it_end;
+                if (A.out_list && it_end < n) A.out_list[atomicAdd(A.out_list_n, 1)] = patch;      // handed on: the next phase continues it
+            }
         }
         if (RES) {
             // the state goes back to HBM, both triangles (every other kernel reads full matrices): 16 b^2 bytes once per call
@@ -1120,7 +1128,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
 {
     constexpr int R = 64 / G, QN = B / 4;
     static_assert(B % 4 == 0 && B <= G, "rows of state per patch");
-    constexpr int UNR = G == 16 ? QN : 2;                        // trips of the column loops unrolled together (registers)
+    constexpr int UNR = (G == 16 || B == 24) ? QN : 2;           // trips of the column loops unrolled together (registers; all of them: slot addresses are immediates)
     constexpr int ROWD = 2 * B * B + 4 * B + (B == G ? 16 : 0);      // doubles of LDS per patch row (+16: de-phases the rows' banks)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* T = reinterpret_cast<double*>(smem);   // 64
@@ -1146,9 +1154,13 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
         if (LIST) {
             // the patches of the work list, one ticket per group of G lanes (a group that finds the list exhausted idles while the
             // other one works; the wave leaves when every group has)
-            int idx = 0;
-            if (i == 0) idx = atomicAdd(A.list_n + A.ticket_slot, 1);
-            idx = __shfl(idx, r * G, 64);
+            // (the first entry of a group is its own index, as in sparse_add_kernel: tickets to one counter are served at ~23 ns each
+            // device-wide, and at launch every group asks at once)
+            int idx = base + r;
+            if (base != (int)blockIdx.x * R) {
+                if (i == 0) idx = (int)gridDim.x * R + atomicAdd(A.list_n + A.ticket_slot, 1);
+                idx = __shfl(idx, r * G, 64);
+            }
             valid = idx < A.list_n[0];
             patch = valid ? A.list[idx] : 0;
             if (!__builtin_amdgcn_ballot_w64(valid)) break;
@@ -1201,7 +1213,8 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
         }
         if (valid && !take && i == 0) {
             if (LIST) {
-                A.done_it[patch] = it0;                             // still on the list: the regular kernel finds it there
+                A.done_it[patch] = it0;                             // all of it is the later phases' work
+                if (A.out_list && n > 0 && it0 < n) A.out_list[atomicAdd(A.out_list_n, 1)] = patch;
             } else {
                 if (!A.start_it) A.done_it[patch] = 0;              // (a later phase leaves the earlier phase's count)
                 if (A.list && n > 0 && it0 < n) A.list[atomicAdd(A.list_n, 1)] = patch;   // all of it is the later phases' work
@@ -1461,6 +1474,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
             }
             if (i == 0) {
                 if (!LIST && A.list && it_end < n) A.list[atomicAdd(A.list_n, 1)] = patch;    // handed over: the next phase continues it
+                if (LIST && A.out_list && it_end < n) A.out_list[atomicAdd(A.out_list_n, 1)] = patch;
                 A.done_it[patch] = it_end;
                 A.b[patch] = b;
                 A.count[patch] += it_end - it0;
@@ -2074,7 +2088,7 @@ int gpc_sparse_create(gpc_ctx* ctx, const gpc_params* params, int P, int ny, gpc
     if (e == hipSuccess) e = hipMalloc(&g->count, 4 * Pn);
     if (e == hipSuccess) e = hipMalloc(&g->stat, 4 * Pn);
     if (e == hipSuccess) e = hipMalloc(&g->done_it, 4 * Pn);
-    if (e == hipSuccess) e = hipMalloc(&g->list, 4 * (Pn + 4));
+    if (e == hipSuccess) e = hipMalloc(&g->list, 4 * (3 * Pn + 12));      // three work lists of P entries, then their 3 x 4 counters
     if (e == hipSuccess) e = hipMemsetAsync(g->b, 0, 4 * Pn, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(g->count, 0, 4 * Pn, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(g->stat, 0, 4 * Pn, ctx->stream);
@@ -2188,8 +2202,14 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
     A.done_it = nullptr;
     A.list = nullptr;
     A.list_n = nullptr;
+    A.out_list = nullptr;
+    A.out_list_n = nullptr;
     A.ticket_slot = 0;
     const bool gauss = A.prm.noise_model == GPC_NOISE_GAUSSIAN;
+    // three work lists in a row, then their counters (4 each): a phase draws from one and appends what it hands on to the next
+    int32_t* const L[3] = {g->list, g->list + g->P, g->list + 2 * (size_t)g->P};
+    int32_t* const N[3] = {g->list + 3 * (size_t)g->P, g->list + 3 * (size_t)g->P + 4, g->list + 3 * (size_t)g->P + 8};
+    int cur = 0;                                   // the list the next phase draws from
     if (!getenv("GPC_SPARSE_NO_SMALL")) {
         // rows phase first (Gaussian noise): four patches per wave while a patch needs at most 16 basis vectors and no deletion;
         // what it does not finish goes on the work list of the phases below
@@ -2200,9 +2220,9 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
             if (const char* e = getenv("GPC_SPARSE_ROWS_PER_CU")) per_cu_r = std::max(1, std::min(per_cu_r, atoi(e)));   // diagnostic
             A.done_it = g->done_it;
             if (!getenv("GPC_SPARSE_NO_LIST")) {
-                A.list = g->list;
-                A.list_n = g->list + g->P;
-                GPC_HIP(ctx, hipMemsetAsync(A.list_n, 0, 4 * sizeof(int32_t), ctx->stream));
+                A.list = L[0];
+                A.list_n = N[0];
+                GPC_HIP(ctx, hipMemsetAsync(N[0], 0, 12 * sizeof(int32_t), ctx->stream));
             }
             const int waves = (g->P + R - 1) / R;
             if (A.ny == 1) hipLaunchKernelGGL((sparse_add_rows_kernel<G, 1>), dim3(std::min(waves, ctx->num_cus * per_cu_r)), dim3(64), lds_r, ctx->stream, A);
@@ -2210,24 +2230,29 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
             GPC_HIP(ctx, hipGetLastError());
             A.start_it = g->done_it;
         }
-        // A SECOND rows phase (Gaussian noise, round 4; GPC_SPARSE_ROWS2=1 -- measured and not the default): the patches of the list with
-        // at most SP_BMAX vectors, two per wave by ticket, until they outgrow SP_BMAX or ask for a deletion, in place of the one-wave
-        // kernel below.  A third of that kernel's instructions per point and bit-identical states, but level in time at the reference's
-        // defaults (0.44 against 0.51 ms per add call, and the regular kernel 0.59 against 0.51: a patch that asks for a geometric
-        // deletion leaves for the regular kernel for the rest of the call, where the one-wave kernel deletes in place), and 80 us per
-        // call for nothing where the list is empty (the colour GP at its defaults).
+        // SECOND rows phase (Gaussian noise, round 4): the patches of the list with at most SP_BMAX vectors, two per wave by ticket, until
+        // they outgrow SP_BMAX or ask for a deletion, in place of the one-wave kernel below -- a third of that kernel's instructions per
+        // point, and a chain of points is as long as the instructions of its steps: 0.36 against 0.51 ms per add call at the reference's
+        // defaults (with the first entry of a group taken by index, not by ticket: 4096 tickets at launch were 0.1 ms), bit-identical
+        // states.  A patch that asks for a geometric deletion leaves for the mid phase.  GPC_SPARSE_NO_ROWS2=1: the one-wave kernel.
         bool rows2 = false;
-        if (gauss && A.list && A.start_it && getenv("GPC_SPARSE_ROWS2")) {
+        if (gauss && A.list && A.start_it && !getenv("GPC_SPARSE_NO_ROWS2")) {
             constexpr int G2 = 32, B2 = SP_BMAX, R2 = 64 / G2;
             static_assert(B2 == 24, "the second rows phase is built for a resident block of 24");
             const size_t lds_2 = sizeof(double) * (size_t)(64 + R2 * (2 * B2 * B2 + 4 * B2));
             const int per_cu_2 = std::min(8, (int)((160u * 1024u) / lds_2));
             A.ticket_slot = 1;
+            A.out_list = L[cur + 1];
+            A.out_list_n = N[cur + 1];
             const int waves2 = (g->P + R2 - 1) / R2;
             if (A.ny == 1) hipLaunchKernelGGL((sparse_add_rows_kernel<G2, 1, B2, true>), dim3(std::min(waves2, ctx->num_cus * per_cu_2)), dim3(64), lds_2, ctx->stream, A);
             else hipLaunchKernelGGL((sparse_add_rows_kernel<G2, 3, B2, true>), dim3(std::min(waves2, ctx->num_cus * per_cu_2)), dim3(64), lds_2, ctx->stream, A);
             GPC_HIP(ctx, hipGetLastError());
             rows2 = true;
+            ++cur;
+            A.list = L[cur];
+            A.list_n = N[cur];
+            A.out_list = A.out_list_n = nullptr;
         }
         // small-basis phase: one wave per patch, C and Q in LDS, until a patch outgrows SP_BMAX basis vectors
         const size_t lds_s = sp_add_lds_small();
@@ -2236,11 +2261,21 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
         if (const char* e = getenv("GPC_SPARSE_SMALL_PER_CU")) per_cu_s = std::max(1, std::min(per_cu_s, atoi(e)));   // diagnostic: occupancy experiments
         A.done_it = g->done_it;
         A.ticket_slot = 1;
+        if (!rows2 && A.list) {
+            A.out_list = L[cur + 1];
+            A.out_list_n = N[cur + 1];
+        }
         if (!gauss)
             hipLaunchKernelGGL((sparse_add_kernel<true, true>), dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
         else if (!rows2)
             hipLaunchKernelGGL((sparse_add_kernel<true, false>), dim3(std::min(g->P, ctx->num_cus * per_cu_s)), dim3(64), lds_s, ctx->stream, A);
         GPC_HIP(ctx, hipGetLastError());
+        if (!rows2 && A.list) {
+            ++cur;
+            A.list = L[cur];
+            A.list_n = N[cur];
+            A.out_list = A.out_list_n = nullptr;
+        }
         A.start_it = g->done_it;
         // mid phase (Gaussian noise, round 4): the patches that have outgrown SP_BMAX vectors -- a few hundred of 32768 at the reference's
         // defaults, each a chain of up to n points -- go through a second instance of the one-wave kernel with a resident block of
@@ -2249,12 +2284,18 @@ int gpc_sparse_add_dev(gpc_sparse* g, const int32_t* off, int n_max, int n_total
         if (gauss && A.list && !getenv("GPC_SPARSE_NO_MID") && g->ld > SP_BMAX) {
             const size_t lds_m = sp_add_lds_small(SP_BMID);
             const int per_cu_m = std::max(1, (int)((160u * 1024u) / lds_m));
-            A.ticket_slot = 2;
+            A.ticket_slot = 1;
+            A.out_list = L[cur + 1];
+            A.out_list_n = N[cur + 1];
             hipLaunchKernelGGL((sparse_add_kernel<true, false, false, false, SP_BMID>), dim3(std::min(g->P, ctx->num_cus * per_cu_m)), dim3(64), lds_m,
                                ctx->stream, A);
             GPC_HIP(ctx, hipGetLastError());
+            ++cur;
+            A.list = L[cur];
+            A.list_n = N[cur];
+            A.out_list = A.out_list_n = nullptr;
         }
-        A.ticket_slot = 3;
+        A.ticket_slot = 1;
         A.done_it = nullptr;
     }
     if (!gauss) hipLaunchKernelGGL((sparse_add_kernel<false, true>), dim3(grid), dim3(nth), lds, ctx->stream, A);

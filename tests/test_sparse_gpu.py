@@ -757,9 +757,9 @@ def test_sparse_rows_phase_is_bit_identical(gp, ny, cap, kernel, P, n, monkeypat
         kw.update(sigmaf_sq=1.0, l_sq=(res / 3) ** 2, noise=1e-3 if ny == 1 else 1.0, eps_tol=1e-3)
     p = capi.default_params_sparse(ny, **kw)
     results = []
-    # (GPC_SPARSE_ROWS2: the opt-in second rows phase -- two patches per wave, 24 rows of state, by ticket -- in place of the one-wave kernel)
+    # (GPC_SPARSE_NO_ROWS2: the one-wave small-basis kernel instead of the second rows phase -- two patches per wave, 24 rows of state, by ticket)
     # (GPC_SPARSE_NO_MID: without the one-wave kernel's second instance for bases of 25 .. 48 vectors)
-    for env in (None, "GPC_SPARSE_NO_LIST", "GPC_SPARSE_NO_ROWS", "GPC_SPARSE_NO_SMALL", "GPC_SPARSE_ROWS2", "GPC_SPARSE_NO_MID"):
+    for env in (None, "GPC_SPARSE_NO_LIST", "GPC_SPARSE_NO_ROWS", "GPC_SPARSE_NO_SMALL", "GPC_SPARSE_NO_ROWS2", "GPC_SPARSE_NO_MID"):
         if env:
             monkeypatch.setenv(env, "1")
         g = capi.Sparse(ctx, p, P, ny)
