@@ -448,7 +448,9 @@ def bench_sparse_c4(env, regime, P, n, chunks, cap, steps, budget_s, ny=1, with_
     hyp = (" -- basis-filling kernel l=res/8, sigma_f^2=1, s20=1e-4" if regime == "fill"
            else (" -- the reference's default hyper-parameters (sigma_f^2=100, l^2=1, s20=0.1)" if ny == 1
                  else " -- the reference's default hyper-parameters of the colour GP (sigma_f^2=100, l^2=1, s20=100, eps_tol=1e-4)"))
-    kern = ("sparse_add_rows_kernel<16> (rows phase) + sparse_add_kernel<true, false> (small-basis phase) + "
+    kern = ("sparse_add_rows_kernel<16, ny> (rows phase: four patches per wave, bases <= 16) + sparse_add_rows_kernel<32, ny, 24, true> (second "
+            "rows phase: two per wave by ticket, bases <= 24) + sparse_add_kernel<true, ., ., ., 48> (mid phase: one wave per patch, bases <= 48, "
+            "deletions in place) + "
             + ("sparse_add_kernel<false, false, true> (triangular passes from 32 basis vectors on)" if tri_on
                else "sparse_add_kernel<false, false>") + (" in its two-wave shape" if 64 < cap <= 100 else "")
             + " + sparse_predict_small_kernel<16 / 32> (patches of at most 32 basis vectors) + sparse_predict_kernel")
