@@ -1128,6 +1128,12 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
 {
     constexpr int R = 64 / G, QN = B / 4;
     static_assert(B % 4 == 0 && B <= G, "rows of state per patch");
+    // B == 16: a lane keeps its rows of C and Q in REGISTERS between full updates (the passes touch nothing else of the matrices, and
+    // every slot index in them is a compile-time value): the update pass reads two vectors from LDS instead of two vectors and two
+    // matrices -- 16 KB instead of 40 KB per wave and point through the CU's one LDS pipe, which was as busy as the VALUs.  The LDS
+    // blocks stay the place where a patch is loaded, grown (the full update moves columns between slots) and written back; Q in LDS
+    // is always current (only the full update writes it), C in LDS only after rows_to_lds().
+    constexpr bool REG = B == 16 && G == 16;
     constexpr int UNR = (G == 16 || B == 24) ? QN : 2;           // trips of the column loops unrolled together (registers; all of them: slot addresses are immediates)
     constexpr int ROWD = 2 * B * B + 4 * B + (B == G ? 16 : 0);      // doubles of LDS per patch row (+16: de-phases the rows' banks)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1207,6 +1213,27 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
             }
         }
         __builtin_amdgcn_wave_barrier();
+        double Cr[REG ? B : 1], Qr[REG ? B : 1];
+        double c00r = 0.0;                         // REG: C(0, 0) as lane 0 carries it (the NaN check of :245 reads it every point)
+#pragma unroll
+        for (int p = 0; p < (REG ? B : 1); ++p) { Cr[p] = 0.0; Qr[p] = 0.0; }
+        auto rows_to_regs = [&]() {
+            if constexpr (REG) {
+#pragma unroll
+                for (int p = 0; p < B; ++p) {
+                    Cr[p] = Cl[i + B * p];
+                    Qr[p] = Ql[i + B * p];
+                }
+                c00r = Cl[p00];
+            }
+        };
+        auto rows_to_lds = [&]() {
+            if constexpr (REG) {
+#pragma unroll
+                for (int p = 0; p < B; ++p) Cl[i + B * p] = Cr[p];
+            }
+        };
+        if (take) rows_to_regs();
         {   // a state that already asks for a geometric deletion (possible only for one loaded with gpc_sparse_set_state) is not ours
             const bool asks = take && i < b && b > 1 && (double)1.0f / Ql[i + B * ms] < (double)1e-9f;
             if (__builtin_amdgcn_ballot_w64(asks) & rowmask) take = false;
@@ -1265,6 +1292,8 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                         bv0 = px0;
                         bv1 = px1;
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    rows_to_regs();
                     b = 1;
                     dec = 0x81;
                 } else {
@@ -1287,8 +1316,8 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 kj[q] = kvL[QN * q + t];
-                                cv[q] = Cl[i + B * (QN * q + t)];
-                                qw[q] = Ql[i + B * (QN * q + t)];
+                                cv[q] = REG ? Cr[REG ? QN * q + t : 0] : Cl[i + B * (QN * q + t)];
+                                qw[q] = REG ? Qr[REG ? QN * q + t : 0] : Ql[i + B * (QN * q + t)];
                             }
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
@@ -1336,6 +1365,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                             SP_FOR_C(c) al[c] += sh * (qv[c] * eta);
                         }
                         const double re = rr * eta;
+                        if constexpr (REG) c00r = c00r + (re * sh) * sh;          // lane 0: C(0, 0) exactly as the pass below forms it
                         if (fuse && i < b) {
                             kn_i = gpc_rbf(sf, A.c_exp, nx0, nx1, bv0, bv1, T);
                             knL[ms] = kn_i;
@@ -1351,14 +1381,15 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     sj[q] = svL[QN * q + t];
-                                    cv[q] = Cl[i + B * (QN * q + t)];
+                                    cv[q] = REG ? Cr[REG ? QN * q + t : 0] : Cl[i + B * (QN * q + t)];
                                     kj[q] = knL[QN * q + t];
-                                    qw[q] = Ql[i + B * (QN * q + t)];
+                                    qw[q] = REG ? Qr[REG ? QN * q + t : 0] : Ql[i + B * (QN * q + t)];
                                 }
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     const double c = cv[q] + (re * sh) * sj[q];
-                                    Cl[i + B * (QN * q + t)] = c;
+                                    if constexpr (REG) Cr[REG ? QN * q + t : 0] = c;
+                                    else Cl[i + B * (QN * q + t)] = c;
                                     acc_[q] += c * kj[q];
                                     acq_[q] += qw[q] * kj[q];
                                 }
@@ -1383,6 +1414,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                             stop = true;                    // nothing of this point has been applied
                         } else {
                             dec = 1;
+                            rows_to_lds();                                       // (REG: the update and the move between slots happen in LDS)
                             const double si = (i < b) ? ck_i : (double)1.0f;
                             const int msn = sp_slot<QN>(i, nb);                  // this lane's slot in the basis of nb
                             if (i < nb) {
@@ -1440,6 +1472,8 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                             b = nb;
                             ms = msn;
                             p00 = B * sp_slot<QN>(0, nb);
+                            __builtin_amdgcn_wave_barrier();
+                            rows_to_regs();
                         }
                     }
                 }
@@ -1449,7 +1483,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                 } else {
                     __builtin_amdgcn_wave_barrier();
                     // isnan(C(0,0)) -> "sparse_gp::C has become Nan" (:245)
-                    const double c00 = Cl[p00];
+                    const double c00 = REG ? c00r : Cl[p00];      // (REG: meaningful in lane 0, which is the one that writes the status)
                     if (c00 != c00 && st == GPC_STATUS_OK) st = GPC_STATUS_NAN;
                     if (A.trace && i == 0) A.trace[o + it] = (uint8_t)dec;
                     ++it;
@@ -1461,6 +1495,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
         } while (__builtin_amdgcn_ballot_w64(active));
         // write the state back (a patch handed over continues from it in the next kernel)
         if (take) {
+            rows_to_lds();
             __builtin_amdgcn_wave_barrier();
             if (i < b) {
                 BVg[2 * i] = bv0;
