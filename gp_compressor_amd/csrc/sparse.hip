@@ -1128,12 +1128,14 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
 {
     constexpr int R = 64 / G, QN = B / 4;
     static_assert(B % 4 == 0 && B <= G, "rows of state per patch");
-    // B == 16: a lane keeps its rows of C and Q in REGISTERS between full updates (the passes touch nothing else of the matrices, and
+    // A lane keeps its rows of C and Q in REGISTERS between full updates (the passes touch nothing else of the matrices, and
     // every slot index in them is a compile-time value): the update pass reads two vectors from LDS instead of two vectors and two
     // matrices -- 16 KB instead of 40 KB per wave and point through the CU's one LDS pipe, which was as busy as the VALUs.  The LDS
     // blocks stay the place where a patch is loaded, grown (the full update moves columns between slots) and written back; Q in LDS
     // is always current (only the full update writes it), C in LDS only after rows_to_lds().
-    constexpr bool REG = B == 16 && G == 16;
+    // (B == 24, the second phase: 96 registers of rows, and still fewer spilled ones than with the pass's operands in flight -- 176
+    // against 256 B of scratch -- and 24 KB instead of 60 KB of LDS traffic per step: 4.90 -> 4.68 ms of add kernels per defaults pass)
+    constexpr bool REG = (B == 16 && G == 16) || B == 24;
     constexpr int UNR = (G == 16 || B == 24) ? QN : 2;           // trips of the column loops unrolled together (registers; all of them: slot addresses are immediates)
     constexpr int ROWD = 2 * B * B + 4 * B + (B == G ? 16 : 0);      // doubles of LDS per patch row (+16: de-phases the rows' banks)
     extern __shared__ __attribute__((aligned(16))) char smem[];
