@@ -589,7 +589,7 @@ __device__ static int sp_full_update_delete(const SpState& S, int b, double rr, 
     if (nxt) {
         // k' against the updated basis (BV[loc] was replaced above, behind a barrier)
         const double n0 = nxt[0], n1 = nxt[1];
-        for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
+        for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf_neg(sf, c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
         __syncthreads();
         if (tri) sp_tri_pass<1 | 2 | 4, PK>(S.C, S.Q, ldm, ld, nb, kvn, pnext, pnext_col, element);
         else sp_rmw_cq_next<true, RB>(S.C, S.Q, ldm, ld, nb, kvn, pnext, element);
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
             if (from_prev) {
                 double* t_ = kv; kv = kvn; kvn = t_;       // formed with the update pass of the previous point
             } else {
-                for (int i = tid; i < b; i += SP_NTH) kv[i] = gpc_rbf(sf, A.c_exp, px0, px1, S.BV[2 * i], S.BV[2 * i + 1], T);
+                for (int i = tid; i < b; i += SP_NTH) kv[i] = gpc_rbf_neg(sf, A.c_exp, px0, px1, S.BV[2 * i], S.BV[2 * i + 1], T);
             }
             __syncthreads();
 
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                 if (A.fuse_next && it + 1 < n) {
                     // the basis does not change: the next point's k against it, and its mat-vecs out of this pass (Q is only read)
                     const double n0 = nx0, n1 = nx1;
-                    for (int i = tid; i < b; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
+                    for (int i = tid; i < b; i += SP_NTH) kvn[i] = gpc_rbf_neg(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
                     auto proj = [&](int i, int j, double& c, double&) { c = c + (re * sv[i]) * sv[j]; };
                     if (TRI && tri) sp_tri_pass<1 | 4, RES>(S.C, S.Q, S.ldm, ld, b, kvn, pnext, pnext_col, proj);
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
                 if (A.fuse_next && it + 1 < n) {
                     // the next point's k against the grown basis, and its mat-vecs out of this pass
                     const double n0 = nx0, n1 = nx1;
-                    for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
+                    for (int i = tid; i < nb; i += SP_NTH) kvn[i] = gpc_rbf_neg(sf, A.c_exp, n0, n1, S.BV[2 * i], S.BV[2 * i + 1], T);
                     __syncthreads();
                     if (TRI && tri) sp_tri_pass<1 | 2 | 4, RES>(S.C, S.Q, S.ldm, ld, nb, kvn, pnext, pnext_col, grow);
                     else sp_rmw_cq_next<true, RB>(S.C, S.Q, ldm, ld, nb, kvn, pnext, grow);
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                     if (!from_prev) {
                         kn_i = 0.0;
                         if (i < b) {
-                            kn_i = gpc_rbf(sf, A.c_exp, px0, px1, bv0, bv1, T);
+                            kn_i = gpc_rbf_neg(sf, A.c_exp, px0, px1, bv0, bv1, T);
                             kvL[ms] = kn_i;
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                         const double re = rr * eta;
                         if constexpr (REG) c00r = c00r + (re * sh) * sh;          // lane 0: C(0, 0) exactly as the pass below forms it
                         if (fuse && i < b) {
-                            kn_i = gpc_rbf(sf, A.c_exp, nx0, nx1, bv0, bv1, T);
+                            kn_i = gpc_rbf_neg(sf, A.c_exp, nx0, nx1, bv0, bv1, T);
                             knL[ms] = kn_i;
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -1428,7 +1428,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
                                 }
                                 if (i == b) { bv0 = px0; bv1 = px1; }
                                 if (fuse) {
-                                    kn_i = gpc_rbf(sf, A.c_exp, nx0, nx1, bv0, bv1, T);
+                                    kn_i = gpc_rbf_neg(sf, A.c_exp, nx0, nx1, bv0, bv1, T);
                                     knL[msn] = kn_i;
                                 }
                             }
@@ -1661,7 +1661,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_predict_kernel(SpPredParams
             const double q0 = xs0[p], q1 = xs1[p];
             double s[3] = {0.0, 0.0, 0.0};
             for (int i = 0; i < b; ++i) {
-                const double k = gpc_rbf(sf, A.c_exp, q0, q1, bv[2 * i], bv[2 * i + 1], T);
+                const double k = gpc_rbf_neg(sf, A.c_exp, q0, q1, bv[2 * i], bv[2 * i + 1], T);
                 for (int c = 0; c < ny; ++c) s[c] += al[c * ld + i] * k;
             }
             for (int c = 0; c < ny; ++c) fs[(size_t)c * fstride + p] = s[c];
@@ -1674,7 +1674,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_predict_kernel(SpPredParams
                 __syncthreads();
                 for (int e = tid; e < b * SP_PC; e += SP_THREADS) {
                     const int pp = e & (SP_PC - 1), i = e / SP_PC;
-                    Kc[i * SP_PC + pp] = (pp < pc) ? gpc_rbf(sf, A.c_exp, xs0[p0 + pp], xs1[p0 + pp], bv[2 * i], bv[2 * i + 1], T) : 0.0;
+                    Kc[i * SP_PC + pp] = (pp < pc) ? gpc_rbf_neg(sf, A.c_exp, xs0[p0 + pp], xs1[p0 + pp], bv[2 * i], bv[2 * i + 1], T) : 0.0;
                 }
                 __syncthreads();
                 if (A.fast) {
@@ -1779,7 +1779,7 @@ __global__ __launch_bounds__(64) void sparse_predict_small_kernel(SpPredParams A
             for (int i = 0; i < BM; ++i) {
                 k[i] = 0.0;
                 if (i < b) {                                    // (wave-uniform)
-                    k[i] = gpc_rbf(sf, A.c_exp, q0, q1, bv[2 * i], bv[2 * i + 1], T);
+                    k[i] = gpc_rbf_neg(sf, A.c_exp, q0, q1, bv[2 * i], bv[2 * i + 1], T);
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
                         if (c < ny) s[c] += al[c * BM + i] * k[i];   // f = alpha^T k (:329), in sparse_predict_kernel's order
@@ -1869,7 +1869,7 @@ __global__ __launch_bounds__(SP_THREADS) void sparse_likelihood_kernel(SpLikPara
             __syncthreads();
             for (int e = tid; e < b * SP_PC; e += SP_THREADS) {
                 const int pp = e & (SP_PC - 1), i = e / SP_PC;
-                Kc[i * SP_PC + pp] = (pp < pc) ? gpc_rbf(sf, A.c_exp, A.x0[o + p0 + pp], A.x1[o + p0 + pp], bv[2 * i], bv[2 * i + 1], T) : 0.0;
+                Kc[i * SP_PC + pp] = (pp < pc) ? gpc_rbf_neg(sf, A.c_exp, A.x0[o + p0 + pp], A.x1[o + p0 + pp], bv[2 * i], bv[2 * i + 1], T) : 0.0;
             }
             __syncthreads();
             if (A.fast) {
