@@ -1079,11 +1079,14 @@ __global__ __launch_bounds__(SMALL ? 64 : SP_THREADS, SMALL ? 4 : 2) void sparse
 // and 95 % of its points take the projected update (src/sparse_gp.hpp:155-163): one wave per patch leaves 50 of 64 lanes idle
 // and the pass is bound by the instruction count of a point's serial skeleton.  Here a patch owns G = 16 (or 32) lanes -- a DPP
 // row, where the reductions of a point already live (sp_wave_sum_dpp) -- so a wave carries 4 (2) patches through the same
-// instruction stream.  Lane i of a patch holds row i of the basis (k_i, (C k)_i, e_hat_i, alpha_i, BV_i in registers); C and Q
-// are G x G blocks in LDS; the lanes of different patches diverge only where their branch decisions differ (predication).
-// The phase covers what needs no dynamic row movement -- first point, projected updates, and full updates that keep the
-// basis within G vectors and trigger no deletion -- and hands a patch over (state written back, points consumed in done_it)
-// BEFORE the first point that needs anything else; sparse_add_kernel<true> continues from there, then the regular kernel.
+// instruction stream.  Lane i of a patch holds row i of the basis (k_i, (C k)_i, e_hat_i, alpha_i, BV_i and -- round 4 -- its rows of
+// C and Q in registers, in the SLOT layout described below); the B x B blocks in LDS are where a patch is loaded, grown and written
+// back; the lanes of different patches diverge only where their branch decisions differ (predication).
+// The phase covers what needs no deletion -- first point, projected updates, and full updates that keep the basis within B
+// vectors -- and hands a patch over (state written back, points consumed in done_it) BEFORE the first point that needs anything
+// else.  Round 4: a second instance (two patches per wave, 24 rows, the listed patches by ticket) continues from there, then the
+// one-wave kernel with a resident block of 48 (deletions in place), then the regular kernel; each phase appends what it hands on to
+// the next phase's list (gpc_sparse_add_dev).
 // A geometric deletion (src/sparse_gp.hpp:226-242) can only follow a full update (the projected update leaves Q alone), and
 // whether one would follow is decided from the updated diagonal before anything is written.
 // Same operations in the same order per patch as sparse_add_kernel (quarter-wise mat-vec sums, DPP row sums, the next
@@ -1141,7 +1144,7 @@ __global__ __launch_bounds__(64, 2) void sparse_add_rows_kernel(SpAddParams A)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* T = reinterpret_cast<double*>(smem);   // 64
     const int lane = threadIdx.x, r = lane / G, i = lane % G;
-    double* Cl = T + 64 + r * ROWD;                // C [G slots][G rows]: row i of the column in slot p at i + G p (see sp_slot)
+    double* Cl = T + 64 + r * ROWD;                // C [B slots][B rows]: row i of the column in slot p at i + B p (see sp_slot)
     double* Ql = Cl + B * B;
     double* kvL = Ql + B * B;                      // k of the current point, by slot
     double* svL = kvL + B;                         // s / s_hat
