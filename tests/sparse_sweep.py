@@ -31,7 +31,7 @@ def draw(rng, synth, res=0.15):
     return dict(ny=ny, cap=cap, kernel=kernel, P=P, n=n, off=off, x0=x0, x1=x1, y=y, perm=perm, kw=kw)
 
 
-def run(capi, ctx, c, env=None):
+def run(capi, ctx, c, env=None, predict=None):
     """three add calls (the first in a drawn insertion order) under the environment switches `env` ("A+B" for two); returns
     (status / trace per call, basis sizes, state)"""
     names = env.split("+") if env else []
@@ -44,6 +44,17 @@ def run(capi, ctx, c, env=None):
             st, tr = g.add(c["off"], c["x0"], c["x1"], c["y"], c["perm"] if call == 0 else None, trace=True)
             r += [st, tr]
         out = (r, g.sizes(), g.state())
+        if predict is not None:
+            # the mean on a grid through the small-basis predict kernels and through the regular one: the same bits (sigma differs in the
+            # order of a sum and is held by test_sparse_small_basis_predict_kernel)
+            xs0, xs1 = predict
+            f_small = g.predict(xs0, xs1)[0]
+            os.environ["GPC_SPARSE_NO_SMALL_PREDICT"] = "1"
+            try:
+                f_reg = g.predict(xs0, xs1)[0]
+            finally:
+                os.environ.pop("GPC_SPARSE_NO_SMALL_PREDICT", None)
+            out = out + (bool(np.array_equal(f_small, f_reg, equal_nan=True)),)
         g.close()
     finally:
         for e in names:
@@ -52,7 +63,7 @@ def run(capi, ctx, c, env=None):
 
 
 def same(a, b, P):
-    (ra, ba, sa), (rb, bb, sb) = a, b
+    (ra, ba, sa), (rb, bb, sb) = a[:3], b[:3]
     if not all(np.array_equal(u, v) for u, v in zip(ra, rb)) or not np.array_equal(ba, bb):
         return False
     for i in range(P):
@@ -67,18 +78,21 @@ def sweep(capi, synth, ctx, ncfg, seed, progress=None):
     """-> (mismatching configurations, histogram of the final basis sizes seen).  The caller sets GPC_SPARSE_FULL=1 (kernel SHAPES are compared
     in the full mode: the triangular passes of the four-wave shape sum a row in another order)."""
     rng = np.random.default_rng(seed)
+    grid = synth.grid(0.15, 12)
     bad, hist = [], {"max_b": 0, "le16": 0, "17_24": 0, "25_48": 0, "gt48": 0}
     for k in range(ncfg):
         c = draw(rng, synth)
-        a, b = run(capi, ctx, c), run(capi, ctx, c, "GPC_SPARSE_NO_SMALL")
+        a, b = run(capi, ctx, c, predict=grid), run(capi, ctx, c, "GPC_SPARSE_NO_SMALL")
+        pred_ok = a[3]
+        a = a[:3]
         ba = a[1]
         hist["max_b"] = max(hist["max_b"], int(ba.max()))
         hist["le16"] += int((ba <= 16).sum())
         hist["17_24"] += int(((ba > 16) & (ba <= 24)).sum())
         hist["25_48"] += int(((ba > 24) & (ba <= 48)).sum())
         hist["gt48"] += int((ba > 48).sum())
-        if not same(a, b, c["P"]):
-            bad.append({"config": k, "ny": c["ny"], "cap": c["cap"], "kernel": c["kernel"], "P": c["P"], "n": c["n"]})
+        if not same(a, b, c["P"]) or not pred_ok:
+            bad.append({"config": k, "ny": c["ny"], "cap": c["cap"], "kernel": c["kernel"], "P": c["P"], "n": c["n"], "predict_ok": pred_ok})
         if progress:
             progress(k, bad)
     return bad, hist

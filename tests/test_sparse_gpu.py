@@ -789,7 +789,8 @@ def test_sparse_phases_random_sweep(gp, monkeypatch):
     """tests/sparse_sweep.py: 300 random configurations (channels, capacity from 5 to unbounded, five kernel regimes, 1 .. 89 patches of
     1 .. 199 points, ragged or not, three add calls, the first in a random insertion order) through the default path -- rows phase, second
     rows phase, mid phase, regular kernel over chained work lists -- and through the regular kernel alone: states, basis sizes, status
-    words, point counts and decision bytes bit for bit.  Seed 1 on purpose: its configurations 41 and 147 are the ones that caught the
+    words, point counts and decision bytes bit for bit; and the mean on a grid through the small-basis predict kernels and through the regular
+    predict kernel: the same bits.  Seed 1 on purpose: its configurations 41 and 147 are the ones that caught the
     divisions sharing one reciprocal (round 4, not kept); 2000 configurations of seeds 1 .. 4 passed on the library as committed."""
     import sparse_sweep as SW
     capi, ctx = gp
